@@ -1,0 +1,35 @@
+"""Import the UNMODIFIED reference modules from /root/reference.  TEST INFRASTRUCTURE; build container only
+(/root/reference does not exist on the GPU box -- nothing on the `-m gpu` / smoke / bench path imports this).
+
+The reference's `models/*.py` need `diffusers` and (at call time) `xformers`; neither is installed, so
+oracle/ref_shims/ is put on sys.path first.  The reference package is loaded under the alias
+`cvvae_ref_models` so it cannot collide with this repo's own drop-in `models/` package.
+"""
+import importlib
+import importlib.util
+import os
+import sys
+
+REF_ROOT = os.environ.get("CVVAE_REFERENCE_ROOT", "/root/reference")
+_SHIMS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_shims")
+
+
+def reference_available() -> bool:
+    return os.path.isfile(os.path.join(REF_ROOT, "models", "modeling_vae.py"))
+
+
+def load_reference():
+    """returns the reference `models.modeling_vae` module (classes CVVAEModel, CVVAESD3Model)."""
+    if "cvvae_ref_models.modeling_vae" in sys.modules:
+        return sys.modules["cvvae_ref_models.modeling_vae"]
+    if not reference_available():
+        raise FileNotFoundError(f"reference not found under {REF_ROOT}")
+    if _SHIMS not in sys.path:
+        sys.path.insert(0, _SHIMS)
+    pkg_dir = os.path.join(REF_ROOT, "models")
+    spec = importlib.util.spec_from_file_location(
+        "cvvae_ref_models", os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])
+    pkg = importlib.util.module_from_spec(spec)
+    sys.modules["cvvae_ref_models"] = pkg
+    spec.loader.exec_module(pkg)
+    return importlib.import_module("cvvae_ref_models.modeling_vae")

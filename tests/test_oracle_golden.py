@@ -1,0 +1,34 @@
+"""The CPU oracle (oracle/cvvae_oracle.py) must reproduce the golden vectors that were produced by the
+reference's own modules (oracle/make_golden.py).  Runs everywhere (no GPU, no /root/reference needed)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvvae_oracle as O
+from oracle.golden_cases import CASES
+from oracle.seeded import seeded_input, seeded_state_dict
+from oracle.shapes import state_dict_shapes
+
+# fp32 CPU vs fp32 CPU, different op order (explicit softmax vs SDPA, folded frames): rounding-level only
+TOL_MOMENTS = 2e-5
+TOL_RECON = 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_oracle_matches_reference_golden(name, golden_dir):
+    family, over, shape, wseed, xseed = CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    cfg = dict(over)
+    sd = seeded_state_dict(state_dict_shapes(family, cfg), wseed)
+    assert len(sd) == int(gold["n_tensors"])
+    wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(wsum - float(gold["weight_abs_sum"])) < 1e-6 * wsum, "oracle/seeded.py drifted from the fixtures"
+    x = seeded_input(shape, xseed)
+    with torch.no_grad():
+        mom = O.encode_moments(x, sd, cfg, family)
+        rec = O.decode_sample(O.posterior_mode(mom), sd, cfg, family)
+    assert tuple(mom.shape) == gold["moments"].shape and tuple(rec.shape) == gold["recon"].shape
+    assert np.abs(mom.numpy() - gold["moments"]).max() <= TOL_MOMENTS
+    assert np.abs(rec.numpy() - gold["recon"]).max() <= TOL_RECON
