@@ -1,0 +1,94 @@
+"""ctypes binding of libcvvae_hip.so (include/cvvae.h).  There is NO fallback: if the HIP library is missing
+the import of any compute entry fails loudly -- build it with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C cv-vae_amd/csrc -j8`."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcvvae_hip.so")
+
+F16, BF16, F32 = 0, 1, 2
+PAD_ZERO, PAD_REPLICATE = 0, 1
+PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
+OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
+ABI_VERSION = 1
+
+
+class ConvDesc(ctypes.Structure):
+    """mirror of `cvvae_conv_desc` (include/cvvae.h) -- field order and types must match."""
+
+    _fields_ = [
+        ("dtype", ctypes.c_int32),
+        ("B", ctypes.c_int32), ("Ti", ctypes.c_int32), ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32),
+        ("Cin", ctypes.c_int32),
+        ("in_pix_stride", ctypes.c_int64),
+        ("upsample2x", ctypes.c_int32),
+        ("kT", ctypes.c_int32), ("kH", ctypes.c_int32), ("kW", ctypes.c_int32),
+        ("sT", ctypes.c_int32), ("sH", ctypes.c_int32), ("sW", ctypes.c_int32),
+        ("pad_t", ctypes.c_int32), ("pad_h", ctypes.c_int32), ("pad_w", ctypes.c_int32),
+        ("pad_mode_t", ctypes.c_int32), ("pad_mode_hw", ctypes.c_int32),
+        ("prologue", ctypes.c_int32),
+        ("gn_rows_per_batch", ctypes.c_int32),
+        ("To", ctypes.c_int32), ("Ho", ctypes.c_int32), ("Wo", ctypes.c_int32), ("Cout", ctypes.c_int32),
+        ("out_mode", ctypes.c_int32),
+        ("out_f32", ctypes.c_int32),
+        ("out_pix_stride", ctypes.c_int64),
+        ("alpha", ctypes.c_float),
+    ]
+
+
+_vp, _i32, _i64, _f32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_float
+
+# name -> (restype, argtypes): every symbol include/cvvae.h declares
+PROTOTYPES = {
+    "cvvae_abi_version": (_i32, []),
+    "cvvae_packed_weight_bytes": (ctypes.c_size_t, [_i32, _i32, _i32]),
+    "cvvae_pack_weights": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "cvvae_conv_fwd": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvvae_conv_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc)]),
+    "cvvae_gn_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
+    "cvvae_gn_stats": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvvae_layernorm": (_i32, [_i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
+    "cvvae_softmax_rows": (_i32, [_i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp]),
+    "cvvae_transpose": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp]),
+    "cvvae_temporal_attention": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp]),
+    "cvvae_ncdhw_to_ndhwc": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_ndhwc_to_ncdhw": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "cvvae_blend": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+class CvvaeError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libcvvae_hip.so and type every entry point.  Raises (never falls back) when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise CvvaeError(
+            f"{LIB_PATH} not found: the MI355X HIP extension is not built and there is no CPU/eager fallback. "
+            "Run `make -C cv-vae_amd/csrc -j8` (or __graft_entry__.build()).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cvvae_abi_version() != ABI_VERSION:
+        raise CvvaeError("libcvvae_hip.so ABI version mismatch; rebuild it")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc == 0:
+        return
+    if rc == -1:
+        raise ValueError(f"{what}: invalid argument (CVVAE_EINVAL)")
+    if rc == -2:
+        raise NotImplementedError(f"{what}: unsupported shape/option (CVVAE_EUNSUPPORTED)")
+    raise CvvaeError(f"{what}: HIP error {rc}")

@@ -1,0 +1,380 @@
+// conv_kernel.h -- implicit-GEMM convolution for CDNA4 (gfx950): the hot kernel of the CV-VAE codec.
+//
+// One workgroup = 512 threads = 8 wave64.  It owns an output tile of BM = TT*TH*TW pixels x BN = 32*WN
+// output channels and walks K = taps x Cin in chunks of CK = 16*KSUB input channels:
+//
+//   * the INPUT HALO TILE of the chunk ((TT-1)*sT+kT) x ((TH-1)*sH+kH) x ((TW-1)*sW+kW) pixels x CK channels
+//     is staged ONCE into LDS (register-staged: pad-mode / nearest-2x coordinate mapping, GroupNorm affine +
+//     SiLU are applied on the way, so neither F.pad, F.interpolate, GroupNorm nor SiLU ever touch HBM);
+//     im2col is then pure LDS addressing: tap (dt,dy,dx) is an immediate offset on the ds_read_b128.
+//     Pixel stride in LDS is CK*2+16 bytes, which makes every 16-lane ds_read_b128 group conflict-free.
+//   * the halo tile is DOUBLE BUFFERED and the 8 waves are split in two groups with opposite phase order
+//     (X: stage next chunk -> MFMA; Y: MFMA -> stage next chunk), so on every SIMD one wave's staging VALU /
+//     global-load latency hides under its partner's MFMA stream.  One s_barrier per chunk.
+//   * WEIGHTS never go through LDS: they are pre-packed in MFMA-fragment order (cvvae_pack_weights) and each
+//     wave streams its own 32-output-channel slice straight HBM/L2 -> VGPR (1 KiB per wave per k16 step,
+//     contiguous, software-prefetched PF steps ahead).
+//   * MFMA is v_mfma_f32_32x32x16 with SWAPPED operands (A = weights, B = activations): the accumulator
+//     lane then holds, for ONE pixel, 4 consecutive output channels per register quad -> 8-byte NDHWC stores.
+//
+// Reference semantics implemented here (file:line in /root/reference): see include/cvvae.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace cvvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <typename T>
+struct Tr;
+template <>
+struct Tr<__bf16> {
+  using v8 = bf16x8;
+  using v4 = bf16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <>
+struct Tr<_Float16> {
+  using v8 = f16x8;
+  using v4 = f16x4;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+
+struct ConvArgs {
+  const void* in;
+  const void* w;
+  const float* bias;
+  const void* res;
+  const float* gsc;
+  const float* gsh;
+  void* out;
+  int B, Ti, Hi, Wi;  // stored input dims
+  int Tl, Hl, Wl;     // logical input dims seen by the taps (Hl = 2*Hi when upsample2x)
+  int Cin;
+  long long in_ps;
+  int To, Ho, Wo, Cout;
+  long long out_ps;
+  int pt, ph, pw;
+  int mode_t, mode_hw;
+  int tiles_t, tiles_h, tiles_w, ntiles_n;
+  int nchunks;   // Cin / CK
+  int nblk32;    // ceil(Cout/32): number of packed 32-channel weight blocks
+  int out_mode, out_f32;
+  int gn_rpb;
+  float alpha;
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB>
+struct Geo {
+  static constexpr int NTAPS = KT * KH * KW;
+  static constexpr int BM = TT * TH * TW;
+  static constexpr int BN = 32 * WN;
+  static constexpr int MREP = BM / 32 / WM;
+  static constexpr int FT = (TT - 1) * ST + KT, FH = (TH - 1) * SH + KH, FW = (TW - 1) * SW + KW;
+  static constexpr int NPIX = FT * FH * FW;
+  static constexpr int CK = 16 * KSUB;
+  static constexpr int PIXB = CK * 2 + 16;
+  static constexpr int BUFB = NPIX * PIXB;
+  static constexpr int LDSB = 2 * BUFB;
+  static constexpr int IPP = 2 * KSUB;   // 16-byte items per pixel
+  static constexpr int PPP = 256 / IPP;  // pixels per staging pass of one 256-thread group
+  static constexpr int NPH = ((NPIX + 1) / 2 + PPP - 1) / PPP * PPP;  // pixels staged by group X
+  static constexpr int NPASS = (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
+  static constexpr int SBATCH = NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4);
+  static constexpr int STEPS = NTAPS * KSUB;
+  static constexpr int PF = (STEPS % 4 == 0) ? 4 : 3;
+  static_assert(WM * WN == 8, "8 waves per workgroup");
+  static_assert(BM % (32 * WM) == 0, "tile rows must split into 32-row MFMA fragments per wave");
+  static_assert(STEPS % PF == 0, "weight prefetch ring must divide the steps of a chunk");
+  static_assert(LDSB <= 160 * 1024, "LDS budget");
+  static_assert(NPH <= NPIX || NPIX <= PPP, "split");
+};
+
+template <typename T>
+__device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+  typename Tr<T>::v8 x = __builtin_bit_cast(typename Tr<T>::v8, u);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) f[j] = (float)x[j];
+}
+template <typename T>
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  typename Tr<T>::v8 x;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) x[j] = (T)f[j];
+  return __builtin_bit_cast(uint4, x);
+}
+
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// out-of-range tap handling: replicate = clamp, zero = flag
+__device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
+  if (mode) return c < 0 ? 0 : (c >= L ? L - 1 : c);
+  if (c < 0 || c >= L) {
+    zero = true;
+    return 0;
+  }
+  return c;
+}
+
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB,
+          int PRO, bool UPS>
+__global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
+  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KSUB>;
+  using v8 = typename Tr<T>::v8;
+  using v4 = typename Tr<T>::v4;
+  constexpr int MREP = G::MREP, PIXB = G::PIXB, NPASS = G::NPASS, STEPS = G::STEPS, PF = G::PF, CK = G::CK;
+
+  __shared__ __attribute__((aligned(16))) char smem[G::LDSB];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
+  const int wave_n = wave % WN;
+  const int wave_m = wave / WN;
+
+  // ---- XCD-aware, bijective block remap: each XCD (bid % 8) gets a contiguous run of logical tiles, so
+  //      neighbouring halo tiles and all N-tiles of one M-tile share one L2.
+  int logical;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int ntile = logical % p.ntiles_n;
+  int mt = logical / p.ntiles_n;
+  const int tw_i = mt % p.tiles_w;
+  mt /= p.tiles_w;
+  const int th_i = mt % p.tiles_h;
+  mt /= p.tiles_h;
+  const int tt_i = mt % p.tiles_t;
+  const int b = mt / p.tiles_t;
+  const int t0 = tt_i * TT, y0 = th_i * TH, x0 = tw_i * TW;
+
+  // ---- staging plan (chunk independent): which stored pixel feeds each of my halo slots
+  const int tl = tid & 255;
+  const int sq = tl % G::IPP;  // my 16-byte slice (8 channels) inside the chunk -- fixed for the whole kernel
+  const int spl = tl / G::IPP;
+  const int pstart = grp ? G::NPH : 0;
+  const int pend = grp ? G::NPIX : (G::NPH < G::NPIX ? G::NPH : G::NPIX);
+  int srcpix[NPASS];
+#pragma unroll
+  for (int k = 0; k < NPASS; ++k) {
+    const int hp = pstart + spl + k * G::PPP;
+    int sp = -2;  // -2: slot not mine / beyond tile, -1: zero padding
+    if (hp < pend) {
+      const int f = hp / (G::FH * G::FW);
+      const int rem = hp - f * (G::FH * G::FW);
+      const int hy = rem / G::FW;
+      const int hx = rem - hy * G::FW;
+      bool zero = false;
+      int ts = map_coord(t0 * ST + f - p.pt, p.Tl, p.mode_t, zero);
+      int ys = map_coord(y0 * SH + hy - p.ph, p.Hl, p.mode_hw, zero);
+      int xs = map_coord(x0 * SW + hx - p.pw, p.Wl, p.mode_hw, zero);
+      if (UPS) {
+        ys >>= 1;
+        xs >>= 1;
+      }
+      sp = zero ? -1 : ((b * p.Ti + ts) * p.Hi + ys) * p.Wi + xs;
+    }
+    srcpix[k] = sp;
+  }
+  const int lds_w0 = (pstart + spl) * PIXB + sq * 16;
+  const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
+  const size_t gn_row = (size_t)(b * p.gn_rpb + (p.gn_rpb > 1 ? t0 : 0)) * (size_t)p.Cin;
+
+  auto stage = [&](int chunk, int bufsel) {
+    const int c0 = chunk * CK + sq * 8;
+    float sc[8], sh[8];
+    if (PRO != 0) {
+      const float4* ps = reinterpret_cast<const float4*>(p.gsc + gn_row + c0);
+      const float4* pb = reinterpret_cast<const float4*>(p.gsh + gn_row + c0);
+      float4 a0 = ps[0], a1 = ps[1], b0 = pb[0], b1 = pb[1];
+      sc[0] = a0.x; sc[1] = a0.y; sc[2] = a0.z; sc[3] = a0.w; sc[4] = a1.x; sc[5] = a1.y; sc[6] = a1.z; sc[7] = a1.w;
+      sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+    }
+    char* dst = smem + bufsel * G::BUFB + lds_w0;
+    constexpr int SB = G::SBATCH;  // passes in flight together (bounds the staging registers)
+#pragma unroll
+    for (int k0 = 0; k0 < NPASS; k0 += SB) {
+      uint4 raw[SB];
+#pragma unroll
+      for (int kk = 0; kk < SB; ++kk) {
+        const int k = k0 + kk;
+        if (k < NPASS) {
+          // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
+          const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
+          raw[kk] = *reinterpret_cast<const uint4*>(inp + (size_t)sp * (size_t)p.in_ps + c0);
+        }
+      }
+#pragma unroll
+      for (int kk = 0; kk < SB; ++kk) {
+        const int k = k0 + kk;
+        if (k < NPASS) {
+          if (srcpix[k] == -2) continue;
+          uint4 o = raw[kk];
+          if (PRO != 0) {
+            float f[8];
+            unpack8<T>(raw[kk], f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float v = f[j] * sc[j] + sh[j];
+              f[j] = (PRO == 1) ? silu_f(v) : v;
+            }
+            o = pack8<T>(f);
+          }
+          if (srcpix[k] < 0) o = make_uint4(0, 0, 0, 0);  // zero padding is applied AFTER GroupNorm+SiLU
+          *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = o;
+        }
+      }
+    }
+  };
+
+  // ---- MFMA plan
+  const int nb = ntile * WN + wave_n;  // my 32-output-channel block
+  const bool active = nb < p.nblk32;
+  int aoff[MREP];
+#pragma unroll
+  for (int r = 0; r < MREP; ++r) {
+    const int m = (wave_m * MREP + r) * 32 + (lane & 31);
+    const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
+    aoff[r] = (((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16;
+  }
+  const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + lane * 8;
+  v8 wf[PF];
+#pragma unroll
+  for (int i = 0; i < PF; ++i) wf[i] = *reinterpret_cast<const v8*>(wq + i * 512);
+
+  f32x16 acc[MREP];
+#pragma unroll
+  for (int r = 0; r < MREP; ++r)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+
+  // ---- pipeline
+  stage(0, 0);
+  __syncthreads();
+  for (int c = 0; c < p.nchunks; ++c) {
+    const int cur = c & 1;
+    const bool more = (c + 1) < p.nchunks;
+    if (grp == 0 && more) stage(c + 1, cur ^ 1);
+    if (active) {
+      const char* lb = smem + cur * G::BUFB;
+      const T* wc = wq + (size_t)c * (STEPS * 512);
+#pragma unroll
+      for (int tap = 0; tap < G::NTAPS; ++tap) {
+        const int dt = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
+        const int tapoff = ((dt * G::FH + dy) * G::FW + dx) * PIXB;
+#pragma unroll
+        for (int ks = 0; ks < KSUB; ++ks) {
+          const int st = tap * KSUB + ks;
+          const v8 wv = wf[st % PF];
+#pragma unroll
+          for (int r = 0; r < MREP; ++r) {
+            const v8 av = *reinterpret_cast<const v8*>(lb + aoff[r] + tapoff + ks * 32);
+            acc[r] = Tr<T>::mfma(wv, av, acc[r]);
+          }
+          wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF) * 512);
+        }
+      }
+    }
+    if (grp == 1 && more) stage(c + 1, cur ^ 1);
+    __syncthreads();
+  }
+  if (!active) return;
+
+  // ---- epilogue: lane = one pixel, register quad g = 4 consecutive output channels
+  const int C2 = p.Cout >> 1;
+#pragma unroll
+  for (int r = 0; r < MREP; ++r) {
+    const int m = (wave_m * MREP + r) * 32 + (lane & 31);
+    const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
+    const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
+    if (to >= p.To || yo >= p.Ho || xo >= p.Wo) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int cb = nb * 32 + g * 8 + (lane >> 5) * 4;
+      if (cb >= p.Cout) continue;
+      float v[4];
+      const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb);
+      v[0] = acc[r][g * 4 + 0] * p.alpha + bv.x;
+      v[1] = acc[r][g * 4 + 1] * p.alpha + bv.y;
+      v[2] = acc[r][g * 4 + 2] * p.alpha + bv.z;
+      v[3] = acc[r][g * 4 + 3] * p.alpha + bv.w;
+      if (p.out_mode == 1) {  // NCDHW, dtype T
+        T* o = reinterpret_cast<T*>(p.out);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (cb + j < p.Cout)
+            o[((((size_t)b * p.Cout + (cb + j)) * p.To + to) * p.Ho + yo) * (size_t)p.Wo + xo] = (T)v[j];
+        continue;
+      }
+      int cc = cb, tq = to, Tq = p.To;
+      if (p.out_mode == 2) {  // channel -> time shuffle, drop frame -1
+        const int n = cb >= C2 ? 1 : 0;
+        cc = cb - n * C2;
+        tq = 2 * to + n - 1;
+        Tq = 2 * p.To - 1;
+        if (tq < 0) continue;
+      }
+      const size_t off = ((((size_t)b * Tq + tq) * p.Ho + yo) * (size_t)p.Wo + xo) * (size_t)p.out_ps + cc;
+      const bool full = (cb + 3 < p.Cout);
+      if (p.res) {
+        const T* rp = reinterpret_cast<const T*>(p.res) + off;
+        if (full) {
+          const v4 rv = *reinterpret_cast<const v4*>(rp);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cb + j < p.Cout) v[j] += (float)rp[j];
+        }
+      }
+      if (p.out_f32) {
+        float* o = reinterpret_cast<float*>(p.out) + off;
+        if (full) {
+          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cb + j < p.Cout) o[j] = v[j];
+        }
+      } else {
+        T* o = reinterpret_cast<T*>(p.out) + off;
+        if (full) {
+          v4 ov;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) ov[j] = (T)v[j];
+          *reinterpret_cast<v4*>(o) = ov;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (cb + j < p.Cout) o[j] = (T)v[j];
+        }
+      }
+    }
+  }
+}
+
+// host-side launcher, one per instantiation (defined in conv_inst_*.hip)
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB,
+          int PRO, bool UPS>
+int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KSUB, PRO, UPS>), dim3(grid), dim3(512),
+                     0, s, a);
+  return (int)hipGetLastError();
+}
+
+}  // namespace cvvae

@@ -1,0 +1,142 @@
+// cvvae_api.hip -- extern "C" entry for the convolution: argument checking, tile/instance selection, launch.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/cvvae.h"
+#include "conv_kernel.h"
+#include "conv_table.h"
+
+namespace cvvae {
+
+// the instantiations live in conv_inst_*.hip
+#define CVVAE_EXTERN(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS) \
+  extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t); \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_ALL(CVVAE_EXTERN)
+
+typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
+
+struct Instance {
+  int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, ksub, pro, ups;
+  launch_fn fn[2];  // [CVVAE_F16], [CVVAE_BF16]
+  char name[96];
+};
+
+#define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,(UPS) ? 1 : 0, \
+   {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>, \
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>}, ""},
+
+static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW)};
+static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
+
+static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
+
+// pick the instance with the least padded work (tile overhang x inactive N waves); ties -> larger tile
+static const Instance* select_instance(const cvvae_conv_desc* d) {
+  const Instance* best = nullptr;
+  double best_cost = 0;
+  for (int i = 0; i < g_ntable; ++i) {
+    const Instance& e = g_table[i];
+    if (e.kt != d->kT || e.kh != d->kH || e.kw != d->kW || e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
+    if (e.pro != d->prologue || e.ups != (d->upsample2x ? 1 : 0)) continue;
+    const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
+    const long long tiles = cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
+    const long long ntn = cdiv(d->Cout, bn);
+    // cost ~ MFMA work issued (padded) + staging work (halo per N tile)
+    double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
+    cost *= 1.0 + 0.15 * 256.0 / (double)bn;   // staging share grows as BN shrinks
+    cost *= 1.0 + 0.05 * 256.0 / (double)bm;   // weight traffic share grows as BM shrinks
+    if (!best || cost < best_cost) {
+      best = &e;
+      best_cost = cost;
+    }
+  }
+  return best;
+}
+
+static const char* instance_name(Instance* e, int dtype) {
+  if (!e->name[0])
+    snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%d_pro%d_ups%d", e->kt, e->kh, e->kw, e->st, e->sh,
+             e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->pro, e->ups);
+  (void)dtype;
+  return e->name;
+}
+
+static int check_desc(const cvvae_conv_desc* d) {
+  if (!d) return CVVAE_EINVAL;
+  if (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16) return CVVAE_EINVAL;
+  if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0)
+    return CVVAE_EINVAL;
+  const int ck = cvvae_conv_kchunk(d->kT, d->kH, d->kW);
+  if (!ck) return CVVAE_EUNSUPPORTED;
+  if (d->Cin <= 0 || d->Cin % ck) return CVVAE_EINVAL;
+  if (d->in_pix_stride < d->Cin || d->in_pix_stride % 8) return CVVAE_EINVAL;
+  if (d->out_mode < 0 || d->out_mode > 2) return CVVAE_EINVAL;
+  if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride < (d->out_mode == 2 ? d->Cout / 2 : d->Cout))) return CVVAE_EINVAL;
+  if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride % 4)) return CVVAE_EINVAL;
+  if (d->out_f32 && d->out_mode != CVVAE_OUT_NDHWC) return CVVAE_EINVAL;
+  if (d->out_mode == CVVAE_OUT_TIME_SHUFFLE && (d->Cout % 8)) return CVVAE_EINVAL;
+  if (d->prologue < 0 || d->prologue > 2) return CVVAE_EINVAL;
+  if (d->gn_rows_per_batch < 1) return CVVAE_EINVAL;
+  if (d->gn_rows_per_batch > 1 && (d->kT != 1 || d->gn_rows_per_batch != d->Ti)) return CVVAE_EINVAL;
+  if ((long long)d->B * d->Ti * d->Hi * d->Wi >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
+  return CVVAE_OK;
+}
+
+}  // namespace cvvae
+
+using namespace cvvae;
+
+extern "C" {
+
+const char* cvvae_conv_kernel_name(const cvvae_conv_desc* d) {
+  if (check_desc(d) != CVVAE_OK) return nullptr;
+  const Instance* e = select_instance(d);
+  return e ? instance_name(const_cast<Instance*>(e), d->dtype) : nullptr;
+}
+
+int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+                   const float* gn_scale, const float* gn_shift, void* out, void* stream) {
+  int rc = check_desc(d);
+  if (rc != CVVAE_OK) return rc;
+  if (!in || !w_packed || !bias || !out) return CVVAE_EINVAL;
+  if (d->prologue != CVVAE_PRO_NONE && (!gn_scale || !gn_shift)) return CVVAE_EINVAL;
+  if (residual && d->out_mode != CVVAE_OUT_NDHWC) return CVVAE_EINVAL;
+  const Instance* e = select_instance(d);
+  if (!e) return CVVAE_EUNSUPPORTED;
+
+  ConvArgs a;
+  memset(&a, 0, sizeof(a));
+  a.in = in;
+  a.w = w_packed;
+  a.bias = bias;
+  a.res = residual;
+  a.gsc = gn_scale;
+  a.gsh = gn_shift;
+  a.out = out;
+  a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi;
+  a.Tl = d->Ti; a.Hl = d->upsample2x ? 2 * d->Hi : d->Hi; a.Wl = d->upsample2x ? 2 * d->Wi : d->Wi;
+  a.Cin = d->Cin;
+  a.in_ps = d->in_pix_stride;
+  a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.out_ps = d->out_pix_stride;
+  a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;
+  a.mode_t = d->pad_mode_t; a.mode_hw = d->pad_mode_hw;
+  a.tiles_t = (int)cdiv(d->To, e->tt);
+  a.tiles_h = (int)cdiv(d->Ho, e->th);
+  a.tiles_w = (int)cdiv(d->Wo, e->tw);
+  a.ntiles_n = (int)cdiv(d->Cout, 32LL * e->wn);
+  a.nchunks = d->Cin / (16 * e->ksub);
+  a.nblk32 = (d->Cout + 31) / 32;
+  a.out_mode = d->out_mode;
+  a.out_f32 = d->out_f32;
+  a.gn_rpb = d->gn_rows_per_batch;
+  a.alpha = d->alpha;
+  const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
+  if (grid <= 0 || grid >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
+  return e->fn[d->dtype](a, (int)grid, (hipStream_t)stream);
+}
+
+}  // extern "C"

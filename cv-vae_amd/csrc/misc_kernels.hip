@@ -1,0 +1,583 @@
+// misc_kernels.hip -- the HBM-bound kernels around the conv: weight packing, GroupNorm statistics, LayerNorm,
+// row softmax, transpose, temporal attention, NCDHW<->NDHWC, tile blending.  gfx950 only.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cvvae.h"
+#include "conv_kernel.h"
+
+namespace cvvae {
+
+// ---------------------------------------------------------------------------------------------------------
+// weight packing: dst[(((nb*nchunks + chunk)*taps + tap)*KSUB + ks)*512 + lane*8 + j]
+//   = src(co = nb*32 + (lane&31), ci = chunk*CK + ks*16 + (lane>>5)*8 + j, tap)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
+                                    long long s_ci, long long s_tap, int nchunks, int ksub, T* __restrict__ dst,
+                                    long long nfrag_lanes) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nfrag_lanes) return;
+  const int lane = (int)(gid & 63);
+  long long f = gid >> 6;
+  const int ks = (int)(f % ksub);
+  f /= ksub;
+  const int tap = (int)(f % taps);
+  f /= taps;
+  const int chunk = (int)(f % nchunks);
+  const int nb = (int)(f / nchunks);
+  const int co = nb * 32 + (lane & 31);
+  const int ci0 = chunk * (16 * ksub) + ks * 16 + (lane >> 5) * 8;
+  typename Tr<T>::v8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = ci0 + j;
+    T x = (T)0.f;
+    if (co < Cout_src && ci < Cin_src) x = src[(long long)co * s_co + (long long)ci * s_ci + (long long)tap * s_tap];
+    v[j] = x;
+  }
+  *reinterpret_cast<typename Tr<T>::v8*>(dst + gid * 8) = v;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// GroupNorm statistics.  Stage 1: grid (nsplit, rows); each block reduces a slab of pixels for all channels
+// with Welford/Chan updates on 4-channel quads; stage 2 merges the slabs and emits the affine table.
+// ---------------------------------------------------------------------------------------------------------
+struct WStat {
+  float n, mean, m2;
+};
+__device__ __forceinline__ void chan_merge(WStat& a, const WStat& b) {
+  if (b.n == 0.f) return;
+  const float n = a.n + b.n;
+  const float d = b.mean - a.mean;
+  const float f = b.n / n;
+  a.mean += d * f;
+  a.m2 += b.m2 + d * d * a.n * f;
+  a.n = n;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x, long long S, int C, long long ps,
+                                                         int G, int nsplit, float* __restrict__ ws) {
+  const int split = blockIdx.x, row = blockIdx.y;
+  const int cv = C >> 3;         // 16-byte channel vectors per pixel
+  const int ppp = 256 / cv;      // pixels per pass
+  const int tid = threadIdx.x;
+  const int myv = tid % cv, mypl = tid / cv;
+  const long long per = (S + nsplit - 1) / nsplit;
+  const long long p0 = (long long)split * per;
+  long long p1 = p0 + per;
+  if (p1 > S) p1 = S;
+  WStat st[2] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  if (tid < cv * ppp) {
+    const T* base = x + ((long long)row * S) * ps + myv * 8;
+    for (long long px = p0 + mypl; px < p1; px += ppp) {
+      const uint4 u = *reinterpret_cast<const uint4*>(base + px * ps);
+      float f[8];
+      unpack8<T>(u, f);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float a = f[h * 4 + 0], b = f[h * 4 + 1], c = f[h * 4 + 2], d = f[h * 4 + 3];
+        const float mb = (a + b + c + d) * 0.25f;
+        const float m2b = (a - mb) * (a - mb) + (b - mb) * (b - mb) + (c - mb) * (c - mb) + (d - mb) * (d - mb);
+        WStat q = {4.f, mb, m2b};
+        chan_merge(st[h], q);
+      }
+    }
+  }
+  __shared__ WStat sh[256 * 2];
+  sh[tid * 2 + 0] = st[0];
+  sh[tid * 2 + 1] = st[1];
+  __syncthreads();
+  if (tid < G) {
+    const int cpg = C / G;        // channels per group (multiple of 4)
+    const int qpg = cpg >> 2;     // quads per group
+    WStat acc = {0.f, 0.f, 0.f};
+    const int q0 = tid * qpg;     // first quad index (over channels) of this group
+    for (int pl = 0; pl < ppp; ++pl)
+      for (int q = q0; q < q0 + qpg; ++q) {
+        const int v = q >> 1, h = q & 1;
+        chan_merge(acc, sh[(pl * cv + v) * 2 + h]);
+      }
+    float* o = ws + (((long long)row * nsplit + split) * G + tid) * 3;
+    o[0] = acc.n;
+    o[1] = acc.mean;
+    o[2] = acc.m2;
+  }
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ ws, int nsplit, int G, int C, float eps,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+  const int row = blockIdx.x, tid = threadIdx.x;
+  __shared__ float s_mean[64], s_rstd[64];
+  // 8 lanes per group (G <= 32)
+  const int g = tid >> 3, l8 = tid & 7;
+  WStat acc = {0.f, 0.f, 0.f};
+  if (g < G) {
+    for (int s = l8; s < nsplit; s += 8) {
+      const float* o = ws + (((long long)row * nsplit + s) * G + g) * 3;
+      WStat q = {o[0], o[1], o[2]};
+      chan_merge(acc, q);
+    }
+  }
+#pragma unroll
+  for (int off = 1; off < 8; off <<= 1) {
+    WStat q;
+    q.n = __shfl_xor(acc.n, off);
+    q.mean = __shfl_xor(acc.mean, off);
+    q.m2 = __shfl_xor(acc.m2, off);
+    chan_merge(acc, q);
+  }
+  if (g < G && l8 == 0) {
+    s_mean[g] = acc.mean;
+    s_rstd[g] = rsqrtf(acc.m2 / acc.n + eps);
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int c = tid; c < C; c += 256) {
+    const int gg = c / cpg;
+    const float sc = gamma[c] * s_rstd[gg];
+    scale[(long long)row * C + c] = sc;
+    shift[(long long)row * C + c] = beta[c] - s_mean[gg] * sc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm over C per pixel: one wave per pixel, C multiple of 8, C <= 64*8*4
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x, long long P, int C, float eps,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                        T* __restrict__ out) {
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= P) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C >> 3;
+  float sum = 0.f;
+  for (int v = lane; v < nv; v += 64) {
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(x + pix * C + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sum += f[j];
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) sum += __shfl_xor(sum, off);
+  const float mean = sum / (float)C;
+  float var = 0.f;
+  for (int v = lane; v < nv; v += 64) {
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(x + pix * C + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) var += (f[j] - mean) * (f[j] - mean);
+  }
+#pragma unroll
+  for (int off = 32; off; off >>= 1) var += __shfl_xor(var, off);
+  const float rstd = rsqrtf(var / (float)C + eps);
+  for (int v = lane; v < nv; v += 64) {
+    float f[8];
+    unpack8<T>(*reinterpret_cast<const uint4*>(x + pix * C + v * 8), f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gamma[v * 8 + j] + beta[v * 8 + j];
+    *reinterpret_cast<uint4*>(out + pix * C + v * 8) = pack8<T>(f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// row softmax: fp32 scores -> T probabilities; one block per row
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_reduce(float v, bool is_max, float* sh) {
+#pragma unroll
+  for (int off = 32; off; off >>= 1) {
+    const float o = __shfl_xor(v, off);
+    v = is_max ? fmaxf(v, o) : v + o;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = sh[0];
+  for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = is_max ? fmaxf(r, sh[i]) : r + sh[i];
+  return r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, int n_valid, long long ld_s,
+                                                           T* __restrict__ p, long long ld_p) {
+  __shared__ float sh[4];
+  const float* sr = s + (long long)blockIdx.x * ld_s;
+  T* pr = p + (long long)blockIdx.x * ld_p;
+  float mx = -3.0e38f;
+  for (int i = threadIdx.x; i < n_valid; i += 256) mx = fmaxf(mx, sr[i]);
+  mx = block_reduce(mx, true, sh);
+  float sum = 0.f;
+  for (int i = threadIdx.x; i < n_valid; i += 256) sum += __expf(sr[i] - mx);
+  sum = block_reduce(sum, false, sh);
+  const float inv = 1.0f / sum;
+  for (int i = threadIdx.x; i < (int)ld_p; i += 256) pr[i] = (T)(i < n_valid ? __expf(sr[i] - mx) * inv : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// transpose of 2-byte elements, 32x32 LDS tiles
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, int R, int C, long long ld_in,
+                                                          long long bs_in, uint16_t* __restrict__ out, long long ld_out,
+                                                          long long bs_out) {
+  __shared__ uint16_t t[32][33];
+  const uint16_t* ib = in + (long long)blockIdx.z * bs_in;
+  uint16_t* ob = out + (long long)blockIdx.z * bs_out;
+  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int r = r0 + ty + k * 8, c = c0 + tx;
+    t[ty + k * 8][tx] = (r < R && c < C) ? ib[(long long)r * ld_in + c] : (uint16_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = c0 + ty + k * 8, r = r0 + tx;
+    if (c < C && r < R) ob[(long long)c * ld_out + r] = t[tx][ty + k * 8];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// temporal attention over T <= 8 frames per pixel, directly on NDHWC: token (b, t, s) lives at
+// ((b*T + t)*S + s)*C.  One wave per pixel (b, s).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                            const T* __restrict__ v, long long P, int Tn, long long S,
+                                                            int C, float scale, T* __restrict__ out) {
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*S
+  if (pix >= P) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C >> 3;  // 16-byte vectors per token
+  const long long b = pix / S, s = pix - b * S;
+  const long long base = (b * Tn * S + s) * C;  // token 0 of this pixel
+  const long long tstride = S * C;
+  const T* qb = q + base;
+  const T* kb = k + base;
+  const T* vb = v + base;
+  float sc[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[i][j] = 0.f;
+  for (int vv = lane; vv < nv; vv += 64) {
+    float qf[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < Tn) unpack8<T>(*reinterpret_cast<const uint4*>(qb + i * tstride + vv * 8), qf[i]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < Tn) {
+        float kf[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(kb + j * tstride + vv * 8), kf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < Tn) {
+            float d = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d += qf[i][e] * kf[e];
+            sc[i][j] += d;
+          }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = sc[i][j];
+#pragma unroll
+      for (int off = 32; off; off >>= 1) x += __shfl_xor(x, off);
+      sc[i][j] = x * scale;
+    }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    if (i < Tn) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < Tn) mx = fmaxf(mx, sc[i][j]);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < Tn) {
+          sc[i][j] = __expf(sc[i][j] - mx);
+          sum += sc[i][j];
+        }
+      const float inv = 1.0f / sum;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) sc[i][j] = (j < Tn) ? sc[i][j] * inv : 0.f;
+    }
+  }
+  for (int vv = lane; vv < nv; vv += 64) {
+    float o[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (j < Tn) {
+        float vf[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(vb + j * tstride + vv * 8), vf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < Tn) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[i][e] += sc[i][j] * vf[e];
+          }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < Tn) *reinterpret_cast<uint4*>(out + base + i * tstride + vv * 8) = pack8<T>(o[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// layout at the boundary
+// ---------------------------------------------------------------------------------------------------------
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const TS* __restrict__ in, int C, long long THW, int Cpad,
+                                                             long long npix, TD* __restrict__ out) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*T*H*W
+  if (pix >= npix) return;
+  const long long b = pix / THW, s = pix - b * THW;
+  for (int c0 = 0; c0 < Cpad; c0 += 8) {
+    float f[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = c0 + j;
+      f[j] = (c < C) ? (float)in[(b * C + c) * THW + s] : 0.f;
+    }
+    *reinterpret_cast<uint4*>(out + pix * Cpad + c0) = pack8<TD>(f);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const T* __restrict__ in, int C, long long THW, long long ps,
+                                                             long long npix, T* __restrict__ out) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  const long long b = pix / THW, s = pix - b * THW;
+  for (int c = 0; c < C; ++c) out[(b * C + c) * THW + s] = in[pix * ps + c];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// tile blending (in place on b): b[.., :o] = (1-w)*a[.., -o:] + w*b[.., :o], w = i/o in fp32
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void blend_kernel(const T* __restrict__ a, int Ha, int Wa, T* __restrict__ b, int Hb,
+                                                    int Wb, long long rows, int o, int axis) {
+  const long long per_row = axis == 0 ? (long long)o * Wb : (long long)Hb * o;
+  const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= rows * per_row) return;
+  const long long r = gid / per_row, e = gid - r * per_row;
+  int y, x, i;
+  long long ai;
+  if (axis == 0) {  // blend_v: first o rows of b with last o rows of a
+    y = (int)(e / Wb);
+    x = (int)(e - (long long)y * Wb);
+    i = y;
+    ai = (r * Ha + (Ha - o + y)) * (long long)Wa + x;
+  } else {          // blend_h: first o columns of b with last o columns of a
+    y = (int)(e / o);
+    x = (int)(e - (long long)y * o);
+    i = x;
+    ai = (r * Ha + y) * (long long)Wa + (Wa - o + x);
+  }
+  const long long bi = (r * Hb + y) * (long long)Wb + x;
+  const float w = (float)i / (float)o;
+  b[bi] = (T)((1.0f - w) * (float)a[ai] + w * (float)b[bi]);
+}
+
+}  // namespace cvvae
+
+using namespace cvvae;
+
+#define CHECK_LAUNCH() return (int)hipGetLastError()
+
+extern "C" {
+
+size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps) {
+  const size_t co = (size_t)((Cout + 31) / 32) * 32;
+  return co * (size_t)Cin * (size_t)taps * 2 + 8 * 1024;  // + read-ahead tail for the prefetch ring
+}
+
+int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
+                       int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream) {
+  if (!src || !dst || Cout_src <= 0 || Cin_src <= 0 || taps <= 0 || kchunk <= 0 || kchunk % 16 || Cin_pad % kchunk ||
+      Cin_pad < Cin_src)
+    return CVVAE_EINVAL;
+  const int nb = (Cout_src + 31) / 32, nchunks = Cin_pad / kchunk, ksub = kchunk / 16;
+  const long long n = (long long)nb * nchunks * taps * ksub * 64;
+  const int grid = (int)((n + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, Cout_src, Cin_src, taps,
+                       (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (__bf16*)dst, n);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout_src, Cin_src,
+                       taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+static int gn_nsplit(int64_t S) {
+  int64_t n = (S + 2047) / 2048;
+  if (n < 1) n = 1;
+  if (n > 2048) n = 2048;
+  return (int)n;
+}
+
+size_t cvvae_gn_workspace_bytes(int32_t rows, int32_t groups, int64_t S) {
+  return (size_t)rows * (size_t)gn_nsplit(S) * (size_t)groups * 3 * sizeof(float);
+}
+
+int cvvae_gn_stats(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_t C, int64_t pix_stride, int32_t groups,
+                   float eps, const float* gamma, const float* beta, float* scale, float* shift, void* workspace,
+                   void* stream) {
+  if (!x || !gamma || !beta || !scale || !shift || !workspace || rows <= 0 || S <= 0) return CVVAE_EINVAL;
+  if (groups <= 0 || groups > 32 || C % groups || (C / groups) % 4 || C % 8 || C > 2048 || pix_stride % 8) return CVVAE_EUNSUPPORTED;
+  const int nsplit = gn_nsplit(S);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(gn_partial_kernel<__bf16>, dim3(nsplit, rows), dim3(256), 0, s, (const __bf16*)x, (long long)S, C,
+                       (long long)pix_stride, groups, nsplit, (float*)workspace);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(gn_partial_kernel<_Float16>, dim3(nsplit, rows), dim3(256), 0, s, (const _Float16*)x, (long long)S, C,
+                       (long long)pix_stride, groups, nsplit, (float*)workspace);
+  else
+    return CVVAE_EINVAL;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(rows), dim3(256), 0, s, (const float*)workspace, nsplit, groups, C, eps, gamma,
+                     beta, scale, shift);
+  CHECK_LAUNCH();
+}
+
+int cvvae_layernorm(int32_t dtype, const void* x, int64_t P, int32_t C, float eps, const float* gamma, const float* beta,
+                    void* out, void* stream) {
+  if (!x || !out || !gamma || !beta || P <= 0 || C <= 0 || C % 8) return CVVAE_EINVAL;
+  const int grid = (int)((P + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(layernorm_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)x, (long long)P, C, eps, gamma,
+                       beta, (__bf16*)out);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(layernorm_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, (long long)P, C, eps,
+                       gamma, beta, (_Float16*)out);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_softmax_rows(int32_t dtype, const float* sc, int64_t rows, int32_t n_valid, int64_t ld_s, void* p, int64_t ld_p,
+                       void* stream) {
+  if (!sc || !p || rows <= 0 || n_valid <= 0 || ld_s < n_valid || ld_p < n_valid) return CVVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<__bf16>, dim3((unsigned)rows), dim3(256), 0, s, sc, n_valid, (long long)ld_s,
+                       (__bf16*)p, (long long)ld_p);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3((unsigned)rows), dim3(256), 0, s, sc, n_valid, (long long)ld_s,
+                       (_Float16*)p, (long long)ld_p);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_transpose(int32_t dtype, const void* in, int32_t batch, int32_t R, int32_t C, int64_t ld_in, int64_t bs_in,
+                    void* out, int64_t ld_out, int64_t bs_out, void* stream) {
+  if (!in || !out || batch <= 0 || R <= 0 || C <= 0) return CVVAE_EINVAL;
+  if (dtype != CVVAE_BF16 && dtype != CVVAE_F16) return CVVAE_EINVAL;
+  hipLaunchKernelGGL(transpose16_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)in, R, C, (long long)ld_in, (long long)bs_in, (uint16_t*)out, (long long)ld_out,
+                     (long long)bs_out);
+  CHECK_LAUNCH();
+}
+
+int cvvae_temporal_attention(int32_t dtype, const void* q, const void* k, const void* v, int32_t B, int32_t T, int64_t S,
+                             int32_t C, void* out, void* stream) {
+  if (!q || !k || !v || !out || B <= 0 || S <= 0 || T <= 0 || C <= 0 || C % 8) return CVVAE_EINVAL;
+  if (T > 8) return CVVAE_EUNSUPPORTED;
+  const float scale = 1.0f / sqrtf((float)C);
+  const long long P = (long long)B * S;
+  const int grid = (int)((P + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(temporal_attn_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k,
+                       (const __bf16*)v, P, T, (long long)S, C, scale, (__bf16*)out);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(temporal_attn_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k,
+                       (const _Float16*)v, P, T, (long long)S, C, scale, (_Float16*)out);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_ncdhw_to_ndhwc(int32_t src_dtype, int32_t dst_dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H,
+                         int32_t W, int32_t Cpad, void* out, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || Cpad < C || Cpad % 8) return CVVAE_EINVAL;
+  const long long THW = (long long)T * H * W, npix = THW * B;
+  const int grid = (int)((npix + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+#define L(TS, TD) \
+  hipLaunchKernelGGL((ncdhw_to_ndhwc_kernel<TS, TD>), dim3(grid), dim3(256), 0, s, (const TS*)in, C, THW, Cpad, npix, (TD*)out)
+  if (dst_dtype == CVVAE_BF16) {
+    if (src_dtype == CVVAE_BF16) L(__bf16, __bf16);
+    else if (src_dtype == CVVAE_F16) L(_Float16, __bf16);
+    else if (src_dtype == 2) L(float, __bf16);
+    else return CVVAE_EINVAL;
+  } else if (dst_dtype == CVVAE_F16) {
+    if (src_dtype == CVVAE_BF16) L(__bf16, _Float16);
+    else if (src_dtype == CVVAE_F16) L(_Float16, _Float16);
+    else if (src_dtype == 2) L(float, _Float16);
+    else return CVVAE_EINVAL;
+  } else
+    return CVVAE_EINVAL;
+#undef L
+  CHECK_LAUNCH();
+}
+
+int cvvae_ndhwc_to_ncdhw(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                         int64_t pix_stride, void* out, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || pix_stride < C) return CVVAE_EINVAL;
+  const long long THW = (long long)T * H * W, npix = THW * B;
+  const int grid = (int)((npix + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)in, C, THW,
+                       (long long)pix_stride, npix, (__bf16*)out);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, C, THW,
+                       (long long)pix_stride, npix, (_Float16*)out);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_blend(int32_t dtype, const void* a, int32_t Ha, int32_t Wa, void* b, int32_t Hb, int32_t Wb, int64_t rows,
+                int32_t overlap, int32_t axis, void* stream) {
+  if (!a || !b || rows <= 0 || overlap <= 0 || (axis != 0 && axis != 1)) return CVVAE_EINVAL;
+  if (axis == 0 && (overlap > Ha || overlap > Hb || Wa != Wb)) return CVVAE_EINVAL;
+  if (axis == 1 && (overlap > Wa || overlap > Wb || Ha != Hb)) return CVVAE_EINVAL;
+  const long long n = rows * (axis == 0 ? (long long)overlap * Wb : (long long)Hb * overlap);
+  const int grid = (int)((n + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(blend_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)a, Ha, Wa, (__bf16*)b, Hb, Wb,
+                       (long long)rows, overlap, axis);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(blend_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)a, Ha, Wa, (_Float16*)b, Hb, Wb,
+                       (long long)rows, overlap, axis);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_abi_version(void) { return CVVAE_ABI_VERSION; }
+
+}  // extern "C"

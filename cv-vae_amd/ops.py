@@ -1,0 +1,245 @@
+"""Tensor-level wrappers over the C ABI: torch only owns the device memory and the stream.
+
+Activations are channels-last-3d tensors of shape [B, T, H, W, C] (contiguous; C may be a padded channel count),
+dtype torch.float16 or torch.bfloat16, on a ROCm device.  Nothing here computes with torch ops."""
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+_DT = {torch.float16: L.F16, torch.bfloat16: L.BF16, torch.float32: L.F32}
+
+
+def _dt(t: torch.dtype) -> int:
+    if t not in (torch.float16, torch.bfloat16):
+        raise TypeError(f"the MI355X path computes on fp16/bf16 MFMA; got {t}. Load the model with torch_dtype="
+                        "torch.float16 or torch.bfloat16 (as cvvae_inference_video.py does).")
+    return _DT[t]
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_gpu(t: torch.Tensor):
+    if not t.is_cuda:
+        raise RuntimeError("cv-vae_amd ops run on an MI355X (ROCm) device only; there is no CPU path. "
+                           f"Got a tensor on {t.device}.")
+
+
+def kchunk(k: Tuple[int, int, int]) -> int:
+    return {(3, 3, 3): 16, (1, 3, 3): 32, (1, 1, 1): 128}[tuple(k)]
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+@dataclass
+class PackedConv:
+    w: torch.Tensor          # packed, fragment order (opaque bytes)
+    bias: torch.Tensor       # fp32, padded to a multiple of 32
+    cout: int
+    cin: int                 # padded input channels the kernel consumes (multiple of kchunk)
+    k: Tuple[int, int, int]
+
+
+def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
+                strides: Optional[Tuple[int, int, int]] = None, cout: Optional[int] = None, cin: Optional[int] = None,
+                out: Optional[torch.Tensor] = None) -> PackedConv:
+    """Pack a conv / linear weight ([Cout, Cin, *k] contiguous, or any strided view described by `strides` =
+    (s_co, s_ci, s_tap) in elements) into MFMA fragment order for cvvae_conv_fwd."""
+    lib = L.load()
+    _need_gpu(w)
+    dt = _dt(w.dtype)
+    taps = k[0] * k[1] * k[2]
+    if strides is None:
+        w = w.contiguous()
+        cout_, cin_ = w.shape[0], w.shape[1]
+        strides = (cin_ * taps, taps, 1)
+    else:
+        cout_, cin_ = cout, cin
+    ck = kchunk(k)
+    cin_pad = round_up(cin_, ck) if cin_pad is None else cin_pad
+    nbytes = lib.cvvae_packed_weight_bytes(cout_, cin_pad, taps)
+    if out is None:
+        out = torch.zeros(nbytes, dtype=torch.uint8, device=w.device)
+    assert out.numel() * out.element_size() >= nbytes
+    L.check(lib.cvvae_pack_weights(dt, w.data_ptr(), cout_, cin_, taps, strides[0], strides[1], strides[2], cin_pad, ck,
+                                   out.data_ptr(), _stream()), "cvvae_pack_weights")
+    b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[:cout_] = bias.detach().to(torch.float32)
+    return PackedConv(out, b, cout_, cin_pad, tuple(k))
+
+
+def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
+         pad_mode_hw=L.PAD_ZERO, prologue=L.PRO_NONE, gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+         gn_per_frame=False, residual: Optional[torch.Tensor] = None, upsample2x=False, out_mode=L.OUT_NDHWC,
+         out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None) -> torch.Tensor:
+    """x: [B,T,H,W,Cs] with Cs >= pw.cin.  pad = ((t_front,t_back),(h_front,h_back),(w_front,w_back)).
+    Returns [B,To,Ho,Wo,Cout(_pad)] (NDHWC), [B,2To-1,Ho,Wo,Cout/2] (TIME_SHUFFLE) or [B,Cout,To,Ho,Wo] (NCDHW)."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous()
+    dt = _dt(x.dtype)
+    B, Ti, Hi, Wi, Cs = x.shape
+    assert Cs >= pw.cin, f"input has {Cs} channels, packed weights consume {pw.cin}"
+    kT, kH, kW = pw.k
+    Hl, Wl = (2 * Hi, 2 * Wi) if upsample2x else (Hi, Wi)
+    To = (Ti + pad[0][0] + pad[0][1] - kT) // stride[0] + 1
+    Ho = (Hl + pad[1][0] + pad[1][1] - kH) // stride[1] + 1
+    Wo = (Wl + pad[2][0] + pad[2][1] - kW) // stride[2] + 1
+    cout = pw.cout
+    d = L.ConvDesc()
+    d.dtype = dt
+    d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, pw.cin
+    d.in_pix_stride = Cs
+    d.upsample2x = 1 if upsample2x else 0
+    d.kT, d.kH, d.kW = kT, kH, kW
+    d.sT, d.sH, d.sW = stride
+    d.pad_t, d.pad_h, d.pad_w = pad[0][0], pad[1][0], pad[2][0]
+    d.pad_mode_t, d.pad_mode_hw = pad_mode_t, pad_mode_hw
+    d.prologue = prologue
+    d.gn_rows_per_batch = Ti if gn_per_frame else 1
+    d.To, d.Ho, d.Wo, d.Cout = To, Ho, Wo, cout
+    d.out_mode = out_mode
+    d.out_f32 = 1 if out_f32 else 0
+    d.alpha = alpha
+    odt = torch.float32 if out_f32 else x.dtype
+    if out_mode == L.OUT_NCDHW:
+        shape = (B, cout, To, Ho, Wo)
+        d.out_pix_stride = 0
+    elif out_mode == L.OUT_TIME_SHUFFLE:
+        shape = (B, 2 * To - 1, Ho, Wo, cout // 2)
+        d.out_pix_stride = cout // 2
+    else:
+        cp = cout if cout_pad is None else cout_pad
+        shape = (B, To, Ho, Wo, cp)
+        d.out_pix_stride = cp
+    if out is None:
+        # padded output channels (cout_pad > cout) must read as zero for the consumer
+        out = (torch.zeros if (out_mode == L.OUT_NDHWC and shape[-1] != cout) else torch.empty)(shape, dtype=odt, device=x.device)
+    else:
+        assert tuple(out.shape) == shape and out.dtype == odt and out.is_contiguous()
+    if residual is not None:
+        assert residual.shape == out.shape and residual.dtype == x.dtype and residual.is_contiguous()
+    gsc = gsh = None
+    if prologue != L.PRO_NONE:
+        gsc, gsh = gn
+        assert gsc.dtype == torch.float32 and gsc.shape[-1] == pw.cin and gsc.is_contiguous() and gsh.is_contiguous()
+    L.check(lib.cvvae_conv_fwd(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),
+                               residual.data_ptr() if residual is not None else None,
+                               gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
+                               out.data_ptr(), _stream()), "cvvae_conv_fwd")
+    return out
+
+
+def conv_kernel_name(d: "L.ConvDesc") -> Optional[str]:
+    n = L.load().cvvae_conv_kernel_name(d)
+    return n.decode() if n else None
+
+
+def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float, groups: int = 32,
+             per_frame: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """GroupNorm statistics of x [B,T,H,W,C] -> (scale, shift) fp32 tables [rows, C]; rows = B (5-D GroupNorm,
+    stats over T,H,W) or B*T (per-frame).  gamma/beta: fp32 [C]."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous()
+    B, T, H, W, C = x.shape
+    rows, S = (B * T, H * W) if per_frame else (B, T * H * W)
+    assert gamma.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+    scale = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    shift = torch.empty((rows, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib.cvvae_gn_workspace_bytes(rows, groups, S), dtype=torch.uint8, device=x.device)
+    L.check(lib.cvvae_gn_stats(_dt(x.dtype), x.data_ptr(), rows, S, C, C, groups, eps, gamma.data_ptr(), beta.data_ptr(),
+                               scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream()), "cvvae_gn_stats")
+    return scale, shift
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:
+    lib = L.load()
+    _need_gpu(x)
+    assert x.is_contiguous()
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    L.check(lib.cvvae_layernorm(_dt(x.dtype), x.data_ptr(), x.numel() // C, C, eps, gamma.data_ptr(), beta.data_ptr(),
+                                out.data_ptr(), _stream()), "cvvae_layernorm")
+    return out
+
+
+def softmax_rows(s: torch.Tensor, n_valid: int, dtype: torch.dtype, ld_p: Optional[int] = None) -> torch.Tensor:
+    """s: [rows, ld_s] fp32 -> [rows, ld_p] dtype; columns >= n_valid are written as 0."""
+    lib = L.load()
+    _need_gpu(s)
+    assert s.dim() == 2 and s.is_contiguous() and s.dtype == torch.float32
+    rows, ld_s = s.shape
+    ld_p = ld_s if ld_p is None else ld_p
+    p = torch.empty((rows, ld_p), dtype=dtype, device=s.device)
+    L.check(lib.cvvae_softmax_rows(_dt(dtype), s.data_ptr(), rows, n_valid, ld_s, p.data_ptr(), ld_p, _stream()),
+            "cvvae_softmax_rows")
+    return p
+
+
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    """x: [batch, R, C] contiguous -> [batch, C, R]."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 3 and x.is_contiguous()
+    b, R, C = x.shape
+    out = torch.empty((b, C, R), dtype=x.dtype, device=x.device)
+    L.check(lib.cvvae_transpose(_dt(x.dtype), x.data_ptr(), b, R, C, C, R * C, out.data_ptr(), R, R * C, _stream()),
+            "cvvae_transpose")
+    return out
+
+
+def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+    """q,k,v: NDHWC [B,T,H,W,C] -> softmax(q k^T / sqrt(C)) v over the T frames of every pixel (T <= 8)."""
+    lib = L.load()
+    _need_gpu(q)
+    assert q.dim() == 5 and q.is_contiguous() and k.is_contiguous() and v.is_contiguous() and q.shape == k.shape == v.shape
+    B, T, H, W, C = q.shape
+    out = torch.empty_like(q)
+    L.check(lib.cvvae_temporal_attention(_dt(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, T, H * W, C,
+                                         out.data_ptr(), _stream()), "cvvae_temporal_attention")
+    return out
+
+
+def ncdhw_to_ndhwc(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """x: [B,C,T,H,W] (fp16/bf16/fp32) -> [B,T,H,W,cpad] `dtype`, pad channels zero."""
+    lib = L.load()
+    _need_gpu(x)
+    x = x.contiguous()
+    B, C, T, H, W = x.shape
+    if x.dtype not in _DT:
+        raise TypeError(f"unsupported input dtype {x.dtype}")
+    out = torch.empty((B, T, H, W, cpad), dtype=dtype, device=x.device)
+    L.check(lib.cvvae_ncdhw_to_ndhwc(_DT[x.dtype], _dt(dtype), x.data_ptr(), B, C, T, H, W, cpad, out.data_ptr(), _stream()),
+            "cvvae_ncdhw_to_ndhwc")
+    return out
+
+
+def ndhwc_to_ncdhw(x: torch.Tensor, c: int) -> torch.Tensor:
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous()
+    B, T, H, W, Cs = x.shape
+    out = torch.empty((B, c, T, H, W), dtype=x.dtype, device=x.device)
+    L.check(lib.cvvae_ndhwc_to_ncdhw(_dt(x.dtype), x.data_ptr(), B, c, T, H, W, Cs, out.data_ptr(), _stream()),
+            "cvvae_ndhwc_to_ncdhw")
+    return out
+
+
+def blend_(a: torch.Tensor, b: torch.Tensor, overlap: int, axis: int) -> torch.Tensor:
+    """in place on b (NCDHW tensors): axis 0 = blend_v (H), 1 = blend_h (W).  modeling_vae.py:321-341."""
+    lib = L.load()
+    _need_gpu(b)
+    assert a.dim() == 5 and b.dim() == 5 and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype
+    rows = b.shape[0] * b.shape[1] * b.shape[2]
+    assert a.shape[:3] == b.shape[:3]
+    L.check(lib.cvvae_blend(_dt(b.dtype), a.data_ptr(), a.shape[3], a.shape[4], b.data_ptr(), b.shape[3], b.shape[4], rows,
+                            overlap, axis, _stream()), "cvvae_blend")
+    return b

@@ -1,0 +1,11 @@
+"""Import alias: `import cvvae_amd` loads the package that lives in the directory `cv-vae_amd/`."""
+import importlib.util
+import os
+import sys
+
+_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cv-vae_amd")
+_spec = importlib.util.spec_from_file_location("cvvae_amd", os.path.join(_dir, "__init__.py"),
+                                               submodule_search_locations=[_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["cvvae_amd"] = _mod
+_spec.loader.exec_module(_mod)

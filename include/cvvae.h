@@ -1,0 +1,150 @@
+/*
+ * cvvae.h -- C ABI of libcvvae_hip.so: the MI355X (gfx950) kernels under the CV-VAE encode/decode path.
+ *
+ * The reference (AILab-CVC/CV-VAE) is pure PyTorch: it has no FFI / operator registry.  Its hot path
+ * dispatches to ATen ops from Python.  Each entry point below replaces one ATen op family
+ * at the call sites cited next to it; the Python host (cv-vae_amd/) binds them with ctypes and mirrors the
+ * reference's module API (models/modeling_vae.py) above them.  INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 for a bad argument / unsupported shape (CVVAE_E*),
+ *     >0 for a hipError_t raised by the launch.  Nothing throws, allocates or synchronises.
+ *   - pointers are raw DEVICE pointers owned by the caller; `stream` is a hipStream_t (NULL = default).
+ *   - activations are NDHWC ("channels last 3d"): element (b,t,y,x,c) at ((b*T+t)*H+y)*W+x)*pix_stride + c.
+ *   - dtype is the storage/MFMA operand type; accumulation and GroupNorm statistics are always fp32.
+ */
+#ifndef CVVAE_H_
+#define CVVAE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CVVAE_ABI_VERSION 1
+
+enum { CVVAE_F16 = 0, CVVAE_BF16 = 1 };                       /* cvvae dtype */
+enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
+enum { CVVAE_PRO_NONE = 0, CVVAE_PRO_GN_SILU = 1, CVVAE_PRO_GN = 2 };   /* fused prologue on the input */
+enum { CVVAE_OUT_NDHWC = 0, CVVAE_OUT_NCDHW = 1, CVVAE_OUT_TIME_SHUFFLE = 2 };
+
+enum {
+  CVVAE_OK = 0,
+  CVVAE_EINVAL = -1,      /* NULL / negative / inconsistent argument */
+  CVVAE_EUNSUPPORTED = -2 /* shape or option combination with no kernel instance */
+};
+
+/* Kernel families of cvvae_conv_fwd.  The packed-weight layout depends on the family's K-chunk
+ * (channels staged per LDS pass): 16 for 3x3x3, 32 for 1x3x3, 128 for 1x1x1. */
+static inline int cvvae_conv_kchunk(int kT, int kH, int kW) {
+  return (kT == 3 && kH == 3 && kW == 3) ? 16 : (kT == 1 && kH == 3 && kW == 3) ? 32 : (kT == 1 && kH == 1 && kW == 1) ? 128 : 0;
+}
+
+/*
+ * One convolution = one implicit GEMM on MFMA (v_mfma_f32_32x32x16_{bf16,f16}).
+ * Replaces, in the reference: aten::convolution + the F.pad / F.interpolate / GroupNorm / SiLU / add that
+ * surround it --
+ *   CausalConv3d.forward   models/vae_blocks3d_sd3.py:81-104, models/vae_models.py:298-328
+ *   Conv3d (replicate)     models/vae_blocks3d_sd3.py:16-46;  nn.Conv3d(padding=1) models/vae_models.py:361-362
+ *   Conv2dWithExtraDim     models/vae_blocks3d_sd3.py:107-116, models/vae_models.py:331-340   (kT = 1)
+ *   Downsample3D           models/vae_blocks3d_sd3.py:224-239, models/vae_models.py:251-263   (stride 2 / (1,2,2))
+ *   Upsample3D             models/vae_blocks3d_sd3.py:314-364, models/vae_models.py:214-235   (upsample2x + TIME_SHUFFLE)
+ *   GroupNorm+SiLU feeding a conv: ResnetBlock3D.forward models/vae_blocks3d_sd3.py:523-524,547-559 (prologue)
+ *   residual add           models/vae_blocks3d_sd3.py:567, models/vae_models.py:410            (epilogue)
+ *   nn.Linear / 1x1 Conv2d of the attention blocks (kT=kH=kW=1)
+ */
+typedef struct cvvae_conv_desc {
+  int32_t dtype;              /* CVVAE_F16 | CVVAE_BF16: input, weights, residual, (non-f32) output */
+  /* input, NDHWC, as stored */
+  int32_t B, Ti, Hi, Wi;
+  int32_t Cin;                /* channels consumed; multiple of cvvae_conv_kchunk(); extra channels must have zero weights */
+  int64_t in_pix_stride;      /* elements between consecutive pixels (>= Cin, multiple of 8) */
+  int32_t upsample2x;         /* 1: the conv sees nearest x(1,2,2) of the stored input (never materialised) */
+  /* kernel */
+  int32_t kT, kH, kW;         /* (3,3,3) | (1,3,3) | (1,1,1) */
+  int32_t sT, sH, sW;         /* 1 or 2 each; stride > 1 only with (3,3,3) */
+  int32_t pad_t, pad_h, pad_w;            /* FRONT padding per axis (back padding is implied by To/Ho/Wo) */
+  int32_t pad_mode_t, pad_mode_hw;        /* CVVAE_PAD_* for taps that fall outside the (upsampled) input */
+  /* prologue: y = x*scale[row,c] + shift[row,c] (then SiLU); zero-padded taps stay 0 */
+  int32_t prologue;           /* CVVAE_PRO_* */
+  int32_t gn_rows_per_batch;  /* 1: row = b (5-D GroupNorm); Ti: row = b*Ti + t (per-frame GroupNorm, kT must be 1) */
+  /* output */
+  int32_t To, Ho, Wo, Cout;   /* Cout = real output channels (weights are packed to a multiple of 32) */
+  int32_t out_mode;           /* CVVAE_OUT_*; TIME_SHUFFLE: channel n*C+c of frame t -> frame 2t+n-1, channel c
+                                 (C = Cout/2, frame -1 dropped): 'b (n c) t h w -> b c (t n) h w' then [:, :, 1:] */
+  int32_t out_f32;            /* 1: store fp32 (NDHWC only), else dtype */
+  int64_t out_pix_stride;     /* NDHWC modes: elements between pixels of `out` and of `residual` */
+  float alpha;                /* out = alpha*acc + bias (+ residual) */
+} cvvae_conv_desc;
+
+/* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */
+size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps);
+
+/*
+ * Pack weights into MFMA-fragment order: [Cout/32][Cin/kchunk][tap][kchunk/16][64 lanes][8].
+ * src element (co, ci, tap) is read at src[co*s_co + ci*s_ci + tap*s_tap] (dtype elements), so the same entry
+ * packs torch conv weights [Cout][Cin][kT*kH*kW] (s_co=Cin_src*taps, s_ci=taps, s_tap=1), nn.Linear weights, and
+ * per-frame attention K / V^T matrices produced on the device.  co >= Cout_src or ci >= Cin_src pack as 0.
+ */
+int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps,
+                       int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst,
+                       void* stream);
+
+int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
+                   const void* residual, const float* gn_scale, const float* gn_shift, void* out, void* stream);
+
+/*
+ * GroupNorm statistics -> per-(row, channel) affine table consumed by the conv prologue.
+ * Replaces aten::native_group_norm: torch.nn.GroupNorm at models/vae_blocks3d_sd3.py:449,472 (5-D, row = b),
+ * models/vae_models3d_sd3.py:150,315, models/vae_models.py:192-195, and the per-frame group_norm of the attention
+ * blocks (rows = B*T, S = H*W).  x is [rows][S][C] (pix_stride elements per pixel); biased variance; fp32 Chan merge.
+ *   scale[row,c] = gamma[c]*rstd(row,g(c)),  shift[row,c] = beta[c] - mean(row,g(c))*scale[row,c]
+ * workspace: cvvae_gn_workspace_bytes(rows, groups, S) bytes.
+ */
+size_t cvvae_gn_workspace_bytes(int32_t rows, int32_t groups, int64_t S);
+int cvvae_gn_stats(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_t C, int64_t pix_stride, int32_t groups,
+                   float eps, const float* gamma, const float* beta, float* scale, float* shift, void* workspace,
+                   void* stream);
+
+/* LayerNorm over C for every pixel (vae3d temporal attention, models/vae_models.py:571,575). in/out [P][C]. */
+int cvvae_layernorm(int32_t dtype, const void* x, int64_t P, int32_t C, float eps, const float* gamma, const float* beta,
+                    void* out, void* stream);
+
+/* Row softmax of fp32 scores -> dtype probabilities (F.scaled_dot_product_attention's softmax).
+ * s: [rows][ld_s] fp32, first n_valid columns are real; p: [rows][ld_p], columns >= n_valid written as 0. */
+int cvvae_softmax_rows(int32_t dtype, const float* s, int64_t rows, int32_t n_valid, int64_t ld_s, void* p, int64_t ld_p,
+                       void* stream);
+
+/* 2-D transpose of dtype elements: out[c][r] = in[r][c], in [R][C] (ld_in), out [C][R] (ld_out). batched. */
+int cvvae_transpose(int32_t dtype, const void* in, int32_t batch, int32_t R, int32_t C, int64_t ld_in, int64_t batch_stride_in,
+                    void* out, int64_t ld_out, int64_t batch_stride_out, void* stream);
+
+/* Temporal attention over the T frames of every pixel (vae3d MemoryEfficientAttnVideoBlock.attention_t,
+ * models/vae_models.py:581-583), directly on NDHWC: q,k,v,out are [B][T][S][C] (S = H*W pixels, T <= 8),
+ * softmax(q k^T * C^-0.5) v over t for each (b, s).  The reference's '(b h w) t c' rearrange is never materialised. */
+int cvvae_temporal_attention(int32_t dtype, const void* q, const void* k, const void* v, int32_t B, int32_t T, int64_t S,
+                             int32_t C, void* out, void* stream);
+
+/* Layout at the drop-in boundary (the reference's tensors are NCDHW, models/modeling_vae.py):
+ * in [B][C][T][H][W] (src_dtype: CVVAE_F16/BF16, or 2 = fp32) -> out NDHWC with Cpad >= C channels, pad = 0. */
+int cvvae_ncdhw_to_ndhwc(int32_t src_dtype, int32_t dst_dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H,
+                         int32_t W, int32_t Cpad, void* out, void* stream);
+int cvvae_ndhwc_to_ncdhw(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
+                         int64_t pix_stride, void* out, void* stream);
+
+/* Tile blending, in place on b (blend_h / blend_v, models/modeling_vae.py:321-341,647-667): NCDHW tensors,
+ * b[..., :o] = (1-w)*a[..., -o:] + w*b[..., :o], w = arange(o)/o in fp32.  axis: 0 = H (blend_v), 1 = W (blend_h).
+ * rows = B*C*T.  a is [rows][Ha][Wa], b is [rows][Hb][Wb]. */
+int cvvae_blend(int32_t dtype, const void* a, int32_t Ha, int32_t Wa, void* b, int32_t Hb, int32_t Wb, int64_t rows,
+                int32_t overlap, int32_t axis, void* stream);
+
+int cvvae_abi_version(void);
+/* name of the kernel instance cvvae_conv_fwd would launch for d (for profiling reports); NULL if unsupported */
+const char* cvvae_conv_kernel_name(const cvvae_conv_desc* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CVVAE_H_ */

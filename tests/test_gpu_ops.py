@@ -1,0 +1,260 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry against a plain PyTorch fp32 CPU evaluation of the same
+op on the same (16-bit-rounded) inputs.  Tolerances are stated per test."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def _ops():
+    import cvvae_amd
+    from cvvae_amd import ops, _lib
+    return ops, _lib
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype)
+
+
+def to_ndhwc(x):  # [B,C,T,H,W] -> [B,T,H,W,C]
+    return x.permute(0, 2, 3, 4, 1).contiguous()
+
+
+def to_ncdhw(x):
+    return x.permute(0, 4, 1, 2, 3).contiguous()
+
+
+def ref_pad(x, pad, mode_t, mode_hw):
+    (tf, tb), (hf, hb), (wf, wb) = pad
+    if hf or hb or wf or wb:
+        x = F.pad(x, (wf, wb, hf, hb, 0, 0), mode="replicate" if mode_hw else "constant")
+    if tf or tb:
+        x = F.pad(x, (0, 0, 0, 0, tf, tb), mode="replicate" if mode_t else "constant")
+    return x
+
+
+def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prologue=0, ups=False, out_mode=0,
+                  residual=False, seed=0, tol=None):
+    ops, L = _ops()
+    B, T, H, W = shape
+    x = rnd((B, Cin, T, H, W), dtype, seed, 1.0)
+    w = rnd((Cout, Cin) + tuple(k), dtype, seed + 1, 1.0 / (Cin * k[0] * k[1] * k[2]) ** 0.5)
+    bias = rnd((Cout,), torch.float32, seed + 2, 0.1)
+    gamma = 1.0 + rnd((Cin,), torch.float32, seed + 3, 0.1)
+    beta = rnd((Cin,), torch.float32, seed + 4, 0.1)
+    # ---- fp32 CPU reference on the same rounded inputs
+    xr = x.float()
+    if prologue:
+        xr = F.group_norm(xr, 32, gamma, beta, 1e-6)
+        if prologue == 1:
+            xr = xr * torch.sigmoid(xr)
+    if ups:
+        xr = F.interpolate(xr, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+    xr = ref_pad(xr, pad, mode_t, mode_hw)
+    ref = F.conv3d(xr, w.float(), bias, stride=stride)
+    res = None
+    if residual:
+        res = rnd(tuple(ref.shape), dtype, seed + 5, 1.0)
+        ref = ref + res.float()
+    if out_mode == L.OUT_TIME_SHUFFLE:
+        b_, nc, t_, h_, w_ = ref.shape
+        c = nc // 2
+        ref = ref.reshape(b_, 2, c, t_, h_, w_).permute(0, 2, 3, 1, 4, 5).reshape(b_, c, 2 * t_, h_, w_)[:, :, 1:]
+    # ---- HIP
+    xd = to_ndhwc(x).to(DEV)
+    ck = ops.kchunk(k)
+    cin_pad = ops.round_up(Cin, ck)
+    if cin_pad != Cin:
+        xp = torch.zeros(xd.shape[:-1] + (cin_pad,), dtype=dtype, device=DEV)
+        xp[..., :Cin] = xd
+        xd = xp
+    pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k, cin_pad=cin_pad)
+    gn = None
+    if prologue:
+        g = torch.zeros(cin_pad); g[:Cin] = gamma
+        bb = torch.zeros(cin_pad); bb[:Cin] = beta
+        assert cin_pad == Cin, "prologue cases use channel counts that need no padding"
+        gn = ops.gn_stats(xd, g.to(DEV), bb.to(DEV), 1e-6)
+    out = ops.conv(xd, pw, stride=stride, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=prologue, gn=gn,
+                   residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    if out_mode != L.OUT_NCDHW:
+        got = to_ncdhw(got)
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    err = (got - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    if tol is None:
+        # inputs are exact in 16 bit; remaining error = fp32 accumulation order + one output rounding
+        # (+ one rounding of the GN/SiLU operand when the prologue is fused)
+        base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        tol = base * (3.0 if prologue else 1.0)
+    assert err <= tol * scale + 1e-6, f"max err {err:.4g} vs scale {scale:.4g} (tol {tol * scale:.4g})"
+    return err / scale
+
+
+DT = [torch.bfloat16, torch.float16]
+REP, ZERO = 1, 0
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Cout", [128, 256, 32, 3])
+def test_conv333_sd3_causal(dtype, Cout):
+    # sd3 CausalConv3d: replicate W,H (1,1), replicate T front 2 (vae_blocks3d_sd3.py:87-98)
+    L = _ops()[1]
+    run_conv_case(dtype, 128, Cout, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 24, 40),
+                  out_mode=L.OUT_NCDHW if Cout <= 32 else L.OUT_NDHWC)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv333_prologue_gn_silu_zero_pad(dtype):
+    # vae3d decoder conv: zero pad all faces, fused GroupNorm+SiLU prologue, 256 -> 256
+    run_conv_case(dtype, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), ZERO, ZERO, (2, 3, 16, 32), prologue=1)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv333_prologue_cout128_replicate(dtype):
+    run_conv_case(dtype, 128, 128, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (1, 4, 17, 33), prologue=1)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv333_vae3d_causal_mixed_pad(dtype):
+    # vae3d CausalConv3d: zero pad W,H, replicate T front 2 (vae_models.py:301-326)
+    run_conv_case(dtype, 128, 256, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, ZERO, (1, 5, 16, 32))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("stride", [(2, 2, 2), (1, 2, 2)])
+def test_conv333_downsample_sd3(dtype, stride):
+    # sd3 Downsample3D: CausalConv3d stride 2 / (1,2,2), replicate pad (1,1,1,1,2,0)  (vae_blocks3d_sd3.py:203-210)
+    run_conv_case(dtype, 128, 128, (3, 3, 3), stride, ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 24, 40))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("stride", [(2, 2, 2), (1, 2, 2)])
+def test_conv333_downsample_vae3d(dtype, stride):
+    # vae3d Downsample3D: zero pad right/bottom only, replicate T front 2 (vae_models.py:253-260)
+    run_conv_case(dtype, 256, 256, (3, 3, 3), stride, ((2, 0), (0, 1), (0, 1)), REP, ZERO, (1, 5, 16, 32))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv333_upsample_time_shuffle(dtype):
+    # sd3 Upsample3D with up_time: nearest x2, replicate conv to 2C, shuffle + drop (vae_blocks3d_sd3.py:342-362)
+    L = _ops()[1]
+    run_conv_case(dtype, 256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (1, 3, 8, 16), ups=True,
+                  out_mode=L.OUT_TIME_SHUFFLE)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv333_upsample_vae3d_pad(dtype):
+    # vae3d Upsample3D: nearest x2, zero pad W,H, replicate T (1,1), no time upsampling (vae_models.py:218-229)
+    run_conv_case(dtype, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, ZERO, (1, 3, 8, 16), ups=True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Cout", [128, 256])
+def test_conv133_prologue_residual(dtype, Cout):
+    # ResnetBlock conv2: per-frame 3x3, zero pad 1, GN+SiLU prologue, residual add in the epilogue
+    run_conv_case(dtype, Cout, Cout, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, (1, 3, 24, 40), prologue=1,
+                  residual=True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Cout", [256, 128])
+def test_conv111_shortcut(dtype, Cout):
+    run_conv_case(dtype, 128, Cout, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), ZERO, ZERO, (1, 3, 10, 52))
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv111_gn_only_prologue(dtype):
+    run_conv_case(dtype, 512, 512, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), ZERO, ZERO, (1, 1, 1, 300), prologue=2)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_small_cin_padded(dtype):
+    # conv_in: 3 input channels padded to the 16-channel chunk with zero weights
+    run_conv_case(dtype, 3, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 16, 40))
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("per_frame", [False, True])
+def test_gn_stats(dtype, per_frame):
+    ops, L = _ops()
+    B, C, T, H, W = 2, 256, 3, 12, 20
+    x = rnd((B, C, T, H, W), dtype, 0, 2.0) + 3.0  # offset mean stresses the variance algorithm
+    x = x.to(dtype)
+    gamma = 1.0 + rnd((C,), torch.float32, 1, 0.1)
+    beta = rnd((C,), torch.float32, 2, 0.1)
+    sc, sh = ops.gn_stats(to_ndhwc(x).to(DEV), gamma.to(DEV), beta.to(DEV), 1e-6, per_frame=per_frame)
+    xf = x.float()
+    if per_frame:
+        xf = xf.permute(0, 2, 1, 3, 4).reshape(B * T, C, H * W)
+    else:
+        xf = xf.reshape(B, C, T * H * W)
+    rows = xf.shape[0]
+    g = xf.reshape(rows, 32, -1).double()
+    mean = g.mean(-1)
+    var = g.var(-1, unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    sc_ref = (gamma.double().view(1, 32, -1) * rstd.unsqueeze(-1)).reshape(rows, C)
+    sh_ref = beta.double().view(1, C) - (mean.unsqueeze(-1).expand(rows, 32, C // 32).reshape(rows, C)) * sc_ref
+    assert (sc.cpu().double() - sc_ref).abs().max() <= 1e-5 * sc_ref.abs().max()
+    assert (sh.cpu().double() - sh_ref).abs().max() <= 2e-5 * max(1.0, sh_ref.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_softmax_transpose_layernorm_tattn(dtype):
+    ops, L = _ops()
+    s = rnd((37, 200), torch.float32, 0, 3.0)
+    sp = torch.zeros(37, 256); sp[:, :200] = s; sp[:, 200:] = 99.0  # garbage in the padding must be ignored
+    p = ops.softmax_rows(sp.to(DEV), 200, dtype)
+    ref = torch.softmax(s, -1)
+    tol = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (p[:, :200].float().cpu() - ref).abs().max() <= tol * ref.max() + 1e-6
+    assert p[:, 200:].float().abs().max().item() == 0.0
+    x = rnd((3, 70, 45), dtype, 1)
+    assert torch.equal(ops.transpose(x.to(DEV)).cpu(), x.transpose(1, 2).contiguous())
+    y = rnd((50, 512), dtype, 2, 2.0)
+    gam = 1.0 + rnd((512,), torch.float32, 3, 0.1)
+    bet = rnd((512,), torch.float32, 4, 0.1)
+    ln = ops.layernorm(y.to(DEV), gam.to(DEV), bet.to(DEV), 1e-5).float().cpu()
+    lref = F.layer_norm(y.float(), (512,), gam, bet, 1e-5)
+    assert (ln - lref).abs().max() <= tol * lref.abs().max() * 1.5
+    # temporal attention straight on NDHWC [B,T,H,W,C]; reference = '(b h w) t c' attention (vae_models.py:626-628)
+    q, k, v = rnd((2, 5, 3, 11, 512), dtype, 5), rnd((2, 5, 3, 11, 512), dtype, 6), rnd((2, 5, 3, 11, 512), dtype, 7)
+    o = ops.temporal_attention(q.to(DEV), k.to(DEV), v.to(DEV)).float().cpu()
+    tok = lambda t: t.float().permute(0, 2, 3, 1, 4).reshape(-1, 5, 512)  # noqa: E731
+    sc = torch.softmax(tok(q) @ tok(k).transpose(1, 2) * 512 ** -0.5, -1)
+    oref = (sc @ tok(v)).reshape(2, 3, 11, 5, 512).permute(0, 3, 1, 2, 4)
+    assert (o - oref).abs().max() <= tol * oref.abs().max() * 1.5
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_layout_and_blend(dtype):
+    ops, L = _ops()
+    x = rnd((2, 3, 4, 9, 11), torch.float32, 0)
+    nd = ops.ncdhw_to_ndhwc(x.to(DEV), 16, dtype)
+    assert nd.shape == (2, 4, 9, 11, 16)
+    assert torch.equal(nd[..., :3].cpu(), to_ndhwc(x.to(dtype)))
+    assert nd[..., 3:].float().abs().max().item() == 0.0
+    back = ops.ndhwc_to_ncdhw(nd, 3)
+    assert torch.equal(back.cpu(), x.to(dtype))
+    for axis in (0, 1):
+        a = rnd((1, 4, 3, 20, 24), dtype, 1)
+        b = rnd((1, 4, 3, 20, 24), dtype, 2)
+        o = 6
+        wgt = torch.arange(o) / o
+        ref = b.clone()
+        if axis == 0:
+            w5 = wgt.view(1, 1, 1, -1, 1)
+            ref[:, :, :, :o, :] = ((1 - w5) * a[:, :, :, -o:, :] + w5 * b[:, :, :, :o, :]).to(dtype)
+        else:
+            w5 = wgt.view(1, 1, 1, 1, -1)
+            ref[:, :, :, :, :o] = ((1 - w5) * a[:, :, :, :, -o:] + w5 * b[:, :, :, :, :o]).to(dtype)
+        got = ops.blend_(a.to(DEV), b.to(DEV).clone(), o, axis).cpu()
+        # same fp32 formula; an FMA contraction can move one value by one 16-bit ulp
+        assert (got.float() - ref.float()).abs().max() <= (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * 4
