@@ -1,0 +1,203 @@
+#!/usr/bin/env python
+"""bench.py -- BASELINE.json's metric on MI355X: encode+decode frames/sec of the CV-VAE codec at T=17, 512x512.
+
+One "step" = one pass of the hot path over one clip: `vae.encode(x).latent_dist.mode()` then `vae.decode(z).sample`
+for a synthetic [1,3,17,512,512] clip (config.workload = BASELINE cfg 3: vae3d_sd3, bf16).  Inputs are resident in
+HBM before the timed region.  N>1 (launched by torch.distributed.run): one process per GPU, every rank codes its own
+clip (the path partitions into independent 17-frame windows -- SURVEY.md 8e -- so there is no data-path collective;
+weak scaling); value = clips of all ranks * 17 frames / max-over-ranks time.
+
+Besides the contract line, the JSON carries
+  roofline     -- the dominant kernel's algorithmic FLOPs / its HIP-event time, measured live in a separate pass
+  cpu_baseline -- the CPU oracle (oracle/cvvae_oracle.py, a PyTorch-CPU restatement of the reference: "port") on a
+                  bounded sample of the same workload, on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # name: (family, B, T, H, W)
+    "cfg3_sd3_T17_512": ("sd3", 1, 17, 512, 512),
+    "cfg2_vae3d_T17_256": ("vae3d", 1, 17, 256, 256),
+}
+# algorithmic FLOPs per clip (2*M*N*K of every conv/linear + attention)
+ALG_TFLOP = {"cfg3_sd3_T17_512": 91.41, "cfg2_vae3d_T17_256": 22.79}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg3_sd3_T17_512", choices=sorted(WORKLOADS))
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    return ap.parse_args()
+
+
+def conv_flops(d, pw):
+    taps = d.kT * d.kH * d.kW
+    return 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * pw.cin_real * taps
+
+
+def roofline_pass(step_fn):
+    """Re-run one step with a HIP event pair around every conv launch (on the stream it is launched on) and
+    aggregate per kernel instance."""
+    from cvvae_amd import ops
+
+    rec = []
+
+    def observer(d, pw, launch):
+        name = ops.conv_kernel_name(d)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        launch()
+        e1.record()
+        rec.append((name, conv_flops(d, pw), e0, e1))
+
+    ops.PROFILE = observer
+    try:
+        step_fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILE = None
+    agg = {}
+    for name, fl, e0, e1 in rec:
+        a = agg.setdefault(name, [0.0, 0.0, 0])
+        a[0] += fl
+        a[1] += e0.elapsed_time(e1) * 1e-3
+        a[2] += 1
+    return agg
+
+
+def cpu_baseline(family):
+    """CPU oracle on a bounded sample: the same network on a 17-frame window at 128x128 (1/16 of the 512x512 frame
+    area; one temporal window, no spatial tiling -- like the workload), scaled to 512x512-equivalent frames/s."""
+    from oracle import cvvae_oracle as O
+    from oracle.seeded import seeded_input, seeded_state_dict
+    from oracle.shapes import state_dict_shapes
+
+    cores = min(os.cpu_count() or 1, 32)  # oneDNN conv at this size stops scaling (and regresses) beyond ~32 threads
+    torch.set_num_threads(cores)
+    sd = seeded_state_dict(state_dict_shapes(family), 0)
+    hw = 128
+    x = seeded_input((1, 3, 17, hw, hw), 0)
+    with torch.no_grad():
+        t0 = time.time()
+        mom = O.encode_moments(x, sd, {}, family)
+        rec = O.decode_sample(O.posterior_mode(mom), sd, {}, family)
+        dt = time.time() - t0
+    assert rec.shape == x.shape
+    area_scale = (512 * 512) / float(hw * hw)
+    return {
+        "value": round(17.0 / (dt * area_scale), 5),
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"oracle (PyTorch-CPU fp32 restatement) encode+decode of 1x3x17x{hw}x{hw} in {dt:.1f}s; value = 17 frames "
+                  f"/ (t * {area_scale:.0f}) i.e. scaled by pixel count to the 512x512 workload",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+
+        dist = dist_
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    import cvvae_amd
+
+    family, B, T, H, W = WORKLOADS[args.workload]
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
+    torch.manual_seed(0)
+    cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
+    vae = cls().to(dtype).cuda().eval()  # random-init weights of the named architecture (no checkpoint access)
+    g = torch.Generator().manual_seed(1000 + rank)
+    x = (torch.rand((B, 3, T, H, W), generator=g) * 2 - 1).to(dtype).cuda()
+
+    def step():
+        z = vae.encode(x).latent_dist.mode()
+        return vae.decode(z).sample
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        y = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert y.shape == x.shape
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    frames = world * B * T * args.steps
+    out = {
+        "metric": "encode+decode frames/sec (T=17, 512x512)" if args.workload.startswith("cfg3") else "encode+decode frames/sec",
+        "value": round(frames / elapsed, 3),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic uniform[-1,1) clip, random-init weights (seed 0) of the named architecture",
+        "config": {"workload": f"{args.workload}: {family} encode(x).mode() + decode(z), x=[{B},3,{T},{H},{W}] per GPU",
+                   "clips_per_gpu": B, "parallelism": f"window-sharded x{world} (no collective)"},
+        "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * world * args.steps / elapsed, 1),
+    }
+
+    if rank == 0 and not args.no_roofline:
+        agg = roofline_pass(step)
+        name, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
+        ach = fl / sec / 1e12
+        out["roofline"] = {
+            "bound": "mfma", "kernel": name, "launches_per_step": n,
+            "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": None,
+        }
+        out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3), "launches": v[2]}
+                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(family)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -4,5 +4,6 @@ Host side = Python on PyTorch-ROCm (memory, streams, torch.distributed); compute
 libcvvae_hip.so behind the C ABI of include/cvvae.h.  Import this package as `cvvae_amd` (see /cvvae_amd.py; the
 directory name `cv-vae_amd` is not a Python identifier)."""
 from . import _lib, ops  # noqa: F401
+from .modeling import AutoencoderKLCVVAE, CVVAEModel, CVVAESD3Model  # noqa: F401
 
-__all__ = ["_lib", "ops"]
+__all__ = ["_lib", "ops", "CVVAEModel", "CVVAESD3Model", "AutoencoderKLCVVAE"]

@@ -1,0 +1,248 @@
+"""Layer programs of the two CV-VAE families, expressed as sequences of C-ABI kernel launches on NDHWC tensors.
+
+This is the host-side mirror of the reference's L1/L2 modules: every function names
+the reference forward it reproduces.  What the reference does as separate ATen ops (F.pad, F.interpolate,
+GroupNorm, SiLU, add, rearrange) is folded into the conv launches -- see include/cvvae.h.
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+REP, ZERO = L.PAD_REPLICATE, L.PAD_ZERO
+P1 = ((1, 1), (1, 1), (1, 1))          # symmetric pad 1 on T,H,W
+PC = ((2, 0), (1, 1), (1, 1))          # causal: T front 2
+P2D = ((0, 0), (1, 1), (1, 1))         # per-frame 3x3
+P0 = ((0, 0), (0, 0), (0, 0))
+
+
+class WeightCache:
+    """Packed (MFMA fragment order) weights and fp32 norm parameters of one nn.Module tree, rebuilt lazily whenever
+    a parameter was replaced, moved (.cuda()/.to()) or modified in place (load_state_dict)."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.m = module
+        self._c: Dict[str, tuple] = {}
+
+    def _key(self, *ps):
+        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps if p is not None)
+
+    def conv(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None) -> ops.PackedConv:
+        w = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(w, b)
+        hit = self._c.get(pre)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        taps = k[0] * k[1] * k[2]
+        co, ci = w.shape[0], w.shape[1]
+        assert w.numel() == co * ci * taps, f"{pre}: weight {tuple(w.shape)} is not a {k} kernel"
+        pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad)
+        self._c[pre] = (key, pw)
+        return pw
+
+    def norm(self, pre: str) -> Tuple[torch.Tensor, torch.Tensor]:
+        g = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(g, b)
+        hit = self._c.get(pre)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        val = (g.detach().float().contiguous(), b.detach().float().contiguous())
+        self._c[pre] = (key, val)
+        return val
+
+    def has(self, name: str) -> bool:
+        try:
+            self.m.get_parameter(name)
+            return True
+        except AttributeError:
+            return False
+
+
+def _flat(x: torch.Tensor) -> torch.Tensor:
+    """[B,T,H,W,C] -> [1,1,1,B*T*H*W,C] view for the 1-D pixel tiles of the 1x1x1 conv."""
+    return x.view(1, 1, 1, -1, x.shape[-1])
+
+
+def conv1x1(wc: WeightCache, x: torch.Tensor, pre: str, residual: Optional[torch.Tensor] = None, prologue=L.PRO_NONE,
+            gn=None) -> torch.Tensor:
+    pw = wc.conv(pre, (1, 1, 1))
+    y = ops.conv(_flat(x), pw, prologue=prologue, gn=gn, residual=_flat(residual) if residual is not None else None)
+    return y.view(*x.shape[:-1], pw.cout)
+
+
+# --------------------------------------------------------------------------------------------------------
+# single-head spatial self-attention per frame (both families)
+# --------------------------------------------------------------------------------------------------------
+def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: str, v: str, proj: str, eps: float,
+                      residual: bool) -> torch.Tensor:
+    """sd3: AttentionWithExtraDim (vae_blocks3d_sd3.py:119-147) over diffusers Attention.
+    vae3d: MemoryEfficientAttnBlock.attention + proj_out (vae_models.py:500-537).
+    Per frame: GN(32) over (C/32, H*W) -> q,k,v (1x1) -> softmax(q k^T / sqrt(C)) v -> proj (+ x)."""
+    B, T, H, W, C = x.shape
+    N = H * W
+    gamma, beta = wc.norm(norm)
+    gn = ops.gn_stats(x, gamma, beta, eps, per_frame=True)           # rows = B*T
+    xf = x.view(B * T, 1, 1, N, C)                                    # frames as batch: GN row = frame
+    qq = ops.conv(xf, wc.conv(q, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
+    kk = ops.conv(xf, wc.conv(k, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
+    vv = ops.conv(xf, wc.conv(v, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
+    npad = ops.round_up(N, 128)
+    vt = ops.transpose(vv.view(B * T, N, C))                          # [BT, C, N]
+    o = torch.empty((B * T, 1, 1, N, C), dtype=x.dtype, device=x.device)
+    scale = float(C) ** -0.5
+    for f in range(B * T):
+        kp = ops.pack_weight(kk[f], None, (1, 1, 1), cin_pad=C, strides=(C, 1, 0), cout=N, cin=C)
+        s = ops.conv(qq[f].view(1, 1, 1, N, C), kp, out_f32=True, alpha=scale, cout_pad=npad)   # [1,1,1,N,npad] fp32
+        p = ops.softmax_rows(s.view(N, npad), N, x.dtype)                                      # [N, npad]
+        vp = ops.pack_weight(vt[f], None, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
+        ops.conv(p.view(1, 1, 1, N, npad), vp, out=o[f].view(1, 1, 1, N, C))
+    return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None)
+
+
+# --------------------------------------------------------------------------------------------------------
+# vae3d_sd3 family
+# --------------------------------------------------------------------------------------------------------
+def sd3_resnet(wc: WeightCache, x: torch.Tensor, pre: str, causal: bool) -> torch.Tensor:
+    """ResnetBlock3D.forward, vae_blocks3d_sd3.py:517-569: GN(eps 1e-6)+SiLU fused into conv1 (replicate pad, causal
+    T(2,0) or (1,1)) and into conv2 (per-frame 3x3, zero pad); 1x1 shortcut; residual add in conv2's epilogue."""
+    g1 = ops.gn_stats(x, *wc.norm(pre + ".norm1"), 1e-6)
+    h = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+                 prologue=L.PRO_GN_SILU, gn=g1)
+    g2 = ops.gn_stats(h, *wc.norm(pre + ".norm2"), 1e-6)
+    sc = conv1x1(wc, x, pre + ".conv_shortcut") if wc.has(pre + ".conv_shortcut.weight") else x
+    return ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
+                    residual=sc)
+
+
+def sd3_mid(wc: WeightCache, x: torch.Tensor, pre: str, causal: bool, attention: bool) -> torch.Tensor:
+    """UNetMidBlock3D.forward, vae_blocks3d_sd3.py:847-856."""
+    x = sd3_resnet(wc, x, pre + ".resnets.0", causal)
+    if attention:
+        a = pre + ".attentions.0"
+        x = spatial_attention(wc, x, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True)
+    return sd3_resnet(wc, x, pre + ".resnets.1", causal)
+
+
+def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """Encoder3D.forward, vae_models3d_sd3.py:162-208.  x: NCDHW (any float dtype) -> moments NCDHW."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    causal = cfg["causal"]
+    boc = cfg["block_out_channels"]
+    h = ops.ncdhw_to_ndhwc(x, 16, dtype)
+    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP)
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"]):
+            h = sd3_resnet(wc, h, f"down_blocks.{i}.resnets.{j}", causal)
+        if i != len(boc) - 1:  # Downsample3D vae_blocks3d_sd3.py:224-239; time stride on even blocks (:115)
+            st = (2, 2, 2) if i % 2 == 0 else (1, 2, 2)
+            h = ops.conv(h, wc.conv(f"down_blocks.{i}.downsamplers.0.conv", (3, 3, 3)), stride=st,
+                         pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP)
+    h = sd3_mid(wc, h, "mid_block", causal, cfg["mid_block_add_attention"])
+    g = ops.gn_stats(h, *wc.norm("conv_norm_out"), 1e-6)
+    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+                    prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
+
+
+def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """Decoder3D.forward, vae_models3d_sd3.py:323-388.  z: NCDHW latents -> pixels NCDHW."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    causal = cfg["causal"]
+    boc = cfg["block_out_channels"]
+    pad = PC if causal else P1
+    zin = z.shape[1]
+    h = ops.ncdhw_to_ndhwc(z, ops.round_up(zin, 16), dtype)
+    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP)
+    h = sd3_mid(wc, h, "mid_block", causal, cfg["mid_block_add_attention"])
+    for i in range(len(boc)):
+        for j in range(cfg["layers_per_block"] + 1):
+            h = sd3_resnet(wc, h, f"up_blocks.{i}.resnets.{j}", causal)
+        if i != len(boc) - 1:  # Upsample3D vae_blocks3d_sd3.py:314-364; up_time on even blocks (vae_models3d_sd3.py:289)
+            up_time = i % 2 == 0
+            h = ops.conv(h, wc.conv(f"up_blocks.{i}.upsamplers.0.conv", (3, 3, 3)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
+                         upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC)
+    g = ops.gn_stats(h, *wc.norm("conv_norm_out"), 1e-6)
+    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
+                    out_mode=L.OUT_NCDHW)
+
+
+# --------------------------------------------------------------------------------------------------------
+# vae3d family
+# --------------------------------------------------------------------------------------------------------
+def _v3_pad(causal: bool):
+    # CausalConv3d (vae_models.py:298-328): zero pad W,H; replicate T front 2.  nn.Conv3d(padding=1): zero everywhere.
+    return (PC, REP, ZERO) if causal else (P1, ZERO, ZERO)
+
+
+def v3_resnet(wc: WeightCache, x: torch.Tensor, pre: str, causal: bool) -> torch.Tensor:
+    """ResnetBlock3D.forward, vae_models.py:390-410 (GN eps 1e-5, swish, nin_shortcut 1x1x1)."""
+    pad, mt, mhw = _v3_pad(causal)
+    g1 = ops.gn_stats(x, *wc.norm(pre + ".norm1"), 1e-5)
+    h = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g1)
+    g2 = ops.gn_stats(h, *wc.norm(pre + ".norm2"), 1e-5)
+    sc = conv1x1(wc, x, pre + ".nin_shortcut") if wc.has(pre + ".nin_shortcut.weight") else x
+    return ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
+                    residual=sc)
+
+
+def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """Encoder.forward, vae_models.py:790-823."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    causal = cfg["causal"]
+    pad, mt, mhw = _v3_pad(causal)
+    nlev = len(cfg["ch_mult"])
+    h = ops.ncdhw_to_ndhwc(x, 16, dtype)
+    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
+    for lvl in range(nlev):
+        for j in range(cfg["num_res_blocks"]):
+            h = v3_resnet(wc, h, f"down.{lvl}.block.{j}", causal)
+        if lvl != nlev - 1:  # Downsample3D vae_models.py:251-263: zero pad right/bottom, replicate T front 2
+            st = (2, 2, 2) if lvl % 2 == 0 else (1, 2, 2)
+            h = ops.conv(h, wc.conv(f"down.{lvl}.downsample.conv", (3, 3, 3)), stride=st, pad=((2, 0), (0, 1), (0, 1)),
+                         pad_mode_t=REP, pad_mode_hw=ZERO)
+    h = v3_resnet(wc, h, "mid.block_1", causal)
+    a = "mid.attn_1"
+    h = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True)
+    h = v3_resnet(wc, h, "mid.block_2", causal)
+    g = ops.gn_stats(h, *wc.norm("norm_out"), 1e-5)
+    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
+                    out_mode=L.OUT_NCDHW)
+
+
+def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str) -> torch.Tensor:
+    """MemoryEfficientAttnVideoBlock.forward, vae_models.py:619-629: spatial attention without residual, then over T
+    per pixel: LayerNorm -> q_t,k_t,v_t -> attention -> proj_out_t; one residual.  Stays NDHWC throughout."""
+    h = spatial_attention(wc, x, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, False)
+    n = ops.layernorm(h, *wc.norm(a + ".norm_t"), 1e-5)
+    q = conv1x1(wc, n, a + ".q_t")
+    k = conv1x1(wc, n, a + ".k_t")
+    v = conv1x1(wc, n, a + ".v_t")
+    o = ops.temporal_attention(q, k, v)
+    return conv1x1(wc, o, a + ".proj_out_t", residual=x)
+
+
+def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """Decoder.forward, vae_models.py:960-1002."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    causal = cfg["causal"]
+    pad, mt, mhw = _v3_pad(causal)
+    nlev = len(cfg["ch_mult"])
+    zin = z.shape[1]
+    h = ops.ncdhw_to_ndhwc(z, ops.round_up(zin, 16), dtype)
+    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
+    h = v3_resnet(wc, h, "mid.block_1", causal)
+    h = v3_attn_spatial_temporal(wc, h, "mid.attn_1")
+    h = v3_resnet(wc, h, "mid.block_2", causal)
+    for lvl in reversed(range(nlev)):
+        for j in range(cfg["num_res_blocks"] + 1):
+            h = v3_resnet(wc, h, f"up.{lvl}.block.{j}", causal)
+        if lvl != 0:  # Upsample3D vae_models.py:214-235 (built non-causal, :936): zero pad W,H, replicate T (1,1)
+            up_time = lvl % 2 == 1
+            h = ops.conv(h, wc.conv(f"up.{lvl}.upsample.conv", (3, 3, 3)), pad=P1, pad_mode_t=REP, pad_mode_hw=ZERO,
+                         upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC)
+    g = ops.gn_stats(h, *wc.norm("norm_out"), 1e-5)
+    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
+                    out_mode=L.OUT_NCDHW)

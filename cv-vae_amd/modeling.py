@@ -1,0 +1,585 @@
+"""Drop-in boundary: `CVVAEModel` / `CVVAESD3Model` with the reference's public API
+(/root/reference/models/modeling_vae.py:20-341 and :344-667) over the MI355X HIP engine.
+
+Same class names, constructor/config keys, `from_pretrained(path, subfolder=, torch_dtype=)`, `.encode(x).latent_dist`,
+`.decode(z, num_frames=).sample`, `.forward`, `.encoder` / `.decoder` callables on NCDHW tensors, the same temporal
+windows / spatial tiles / in-place blending, and the same state-dict key names and shapes, so
+cvvae_inference_video.py and cvvae_sd3_inference_video.py run unchanged on top of `models/modeling_vae.py`.
+diffusers is not a dependency: config / weight loading and the two small output types are implemented here.
+"""
+import json
+import math
+import os
+from types import SimpleNamespace
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn as nn
+
+from . import engine, ops
+
+
+# ------------------------------------------------------------------------------------------------------
+# parameter holders: they only own tensors under the reference's names; compute happens in engine.py
+# ------------------------------------------------------------------------------------------------------
+class ConvP(nn.Module):
+    def __init__(self, cin: int, cout: int, ksize: Tuple[int, ...]):
+        super().__init__()
+        self.weight = nn.Parameter(torch.empty((cout, cin) + tuple(ksize)))
+        self.bias = nn.Parameter(torch.empty(cout))
+        fan_in = cin * int(math.prod(ksize)) if ksize else cin
+        bound = 1.0 / math.sqrt(fan_in)  # torch's default conv/linear init (kaiming_uniform(a=sqrt(5)))
+        with torch.no_grad():
+            self.weight.uniform_(-bound, bound)
+            self.bias.uniform_(-bound, bound)
+
+
+class NormP(nn.Module):
+    def __init__(self, c: int):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(c))
+        self.bias = nn.Parameter(torch.zeros(c))
+
+
+def _holder(**children) -> nn.Module:
+    m = nn.Module()
+    for k, v in children.items():
+        m.add_module(k, v)
+    return m
+
+
+def _resnet(cin: int, cout: int, shortcut_name: str, shortcut_k: Tuple[int, ...]) -> nn.Module:
+    m = _holder(norm1=NormP(cin), conv1=ConvP(cin, cout, (3, 3, 3)), norm2=NormP(cout), conv2=ConvP(cout, cout, (3, 3)))
+    if cin != cout:
+        m.add_module(shortcut_name, ConvP(cin, cout, shortcut_k))
+    return m
+
+
+class _Net(nn.Module):
+    """Base of the four encoder/decoder modules: parameters + a WeightCache + `forward` on NCDHW tensors."""
+
+    _program = None
+
+    def __init__(self):
+        super().__init__()
+        self._wc = None
+        self._cfg = {}
+
+    def _cache(self) -> engine.WeightCache:
+        if self._wc is None:
+            object.__setattr__(self, "_wc", engine.WeightCache(self))
+        return self._wc
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        if x.dim() != 5:
+            raise ValueError(f"expected a [B,C,T,H,W] tensor, got shape {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("cv-vae_amd runs on an MI355X (ROCm) device only; move the model and the input to 'cuda'. "
+                               "There is no CPU fallback.")
+        out = type(self)._program(self._cache(), x, self._cfg)
+        return out
+
+    def get_last_layer(self, **kwargs):
+        return self.conv_out.weight
+
+
+# ------------------------------------------------------------------------------------------------------
+# vae3d_sd3 graphs (vae_models3d_sd3.py:55-391)
+# ------------------------------------------------------------------------------------------------------
+def _sd3_mid(c: int, attention: bool) -> nn.Module:
+    resnets = nn.ModuleList([_resnet(c, c, "conv_shortcut", (1, 1)), _resnet(c, c, "conv_shortcut", (1, 1))])
+    atts = nn.ModuleList()
+    if attention:
+        a = _holder(group_norm=NormP(c), to_q=ConvP(c, c, ()), to_k=ConvP(c, c, ()), to_v=ConvP(c, c, ()))
+        a.add_module("to_out", nn.ModuleList([ConvP(c, c, ()), nn.Identity()]))
+        atts.append(a)
+    return _holder(resnets=resnets, attentions=atts)
+
+
+class Encoder3D(_Net):
+    _program = staticmethod(engine.sd3_encoder)
+
+    def __init__(self, in_channels=3, out_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 double_z=True, mid_block_add_attention=True, causal=True, **_):
+        super().__init__()
+        boc = list(block_out_channels)
+        self.conv_in = ConvP(in_channels, boc[0], (3, 3, 3))
+        self.down_blocks = nn.ModuleList()
+        ch = boc[0]
+        for i, co in enumerate(boc):
+            blk = _holder(resnets=nn.ModuleList(
+                [_resnet(ch if j == 0 else co, co, "conv_shortcut", (1, 1)) for j in range(layers_per_block)]))
+            ch = co
+            if i != len(boc) - 1:
+                blk.add_module("downsamplers", nn.ModuleList([_holder(conv=ConvP(co, co, (3, 3, 3)))]))
+            self.down_blocks.append(blk)
+        self.mid_block = _sd3_mid(boc[-1], mid_block_add_attention)
+        self.conv_norm_out = NormP(boc[-1])
+        self.conv_out = ConvP(boc[-1], 2 * out_channels if double_z else out_channels, (3, 3, 3))
+        self._cfg = dict(causal=causal, block_out_channels=boc, layers_per_block=layers_per_block,
+                         mid_block_add_attention=mid_block_add_attention)
+
+
+class Decoder3D(_Net):
+    _program = staticmethod(engine.sd3_decoder)
+
+    def __init__(self, in_channels=16, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
+                 mid_block_add_attention=True, causal=False, **_):
+        super().__init__()
+        boc = list(block_out_channels)
+        rev = list(reversed(boc))
+        self.conv_in = ConvP(in_channels, rev[0], (3, 3, 3))
+        self.mid_block = _sd3_mid(rev[0], mid_block_add_attention)
+        self.up_blocks = nn.ModuleList()
+        ch = rev[0]
+        for i, co in enumerate(rev):
+            blk = _holder(resnets=nn.ModuleList(
+                [_resnet(ch if j == 0 else co, co, "conv_shortcut", (1, 1)) for j in range(layers_per_block + 1)]))
+            ch = co
+            if i != len(rev) - 1:
+                up_time = 2 if i % 2 == 0 else 1
+                blk.add_module("upsamplers", nn.ModuleList([_holder(conv=ConvP(co, co * up_time, (3, 3, 3)))]))
+            self.up_blocks.append(blk)
+        self.conv_norm_out = NormP(boc[0])
+        self.conv_out = ConvP(boc[0], out_channels, (3, 3, 3))
+        self._cfg = dict(causal=causal, block_out_channels=boc, layers_per_block=layers_per_block,
+                         mid_block_add_attention=mid_block_add_attention)
+
+
+# ------------------------------------------------------------------------------------------------------
+# vae3d graphs (vae_models.py:679-1002), LDM key naming
+# ------------------------------------------------------------------------------------------------------
+def _v3_attn(c: int, temporal: bool) -> nn.Module:
+    a = _holder(norm=NormP(c), q=ConvP(c, c, (1, 1)), k=ConvP(c, c, (1, 1)), v=ConvP(c, c, (1, 1)),
+                proj_out=ConvP(c, c, (1, 1)))
+    if temporal:
+        for n in ("q_t", "k_t", "v_t", "proj_out_t"):
+            a.add_module(n, ConvP(c, c, ()))
+        a.add_module("norm_t", NormP(c))
+    return a
+
+
+class Encoder(_Net):
+    _program = staticmethod(engine.v3_encoder)
+
+    def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4, double_z=True,
+                 causal=True, **_):
+        super().__init__()
+        mult = list(ch_mult)
+        in_mult = [1] + mult
+        self.conv_in = ConvP(in_channels, ch, (3, 3, 3))
+        self.down = nn.ModuleList()
+        bi = ch
+        for lvl in range(len(mult)):
+            bi, bo = ch * in_mult[lvl], ch * mult[lvl]
+            blocks = nn.ModuleList()
+            for _j in range(num_res_blocks):
+                blocks.append(_resnet(bi, bo, "nin_shortcut", (1, 1, 1)))
+                bi = bo
+            lv = _holder(block=blocks, attn=nn.ModuleList())
+            if lvl != len(mult) - 1:
+                lv.add_module("downsample", _holder(conv=ConvP(bi, bi, (3, 3, 3))))
+            self.down.append(lv)
+        self.mid = _holder(block_1=_resnet(bi, bi, "nin_shortcut", (1, 1, 1)), attn_1=_v3_attn(bi, False),
+                           block_2=_resnet(bi, bi, "nin_shortcut", (1, 1, 1)))
+        self.norm_out = NormP(bi)
+        self.conv_out = ConvP(bi, 2 * z_channels if double_z else z_channels, (3, 3, 3))
+        self._cfg = dict(causal=causal, ch_mult=mult, num_res_blocks=num_res_blocks)
+
+
+class Decoder(_Net):
+    _program = staticmethod(engine.v3_decoder)
+
+    def __init__(self, ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, causal=False, **_):
+        super().__init__()
+        mult = list(ch_mult)
+        bi = ch * mult[-1]
+        self.conv_in = ConvP(z_channels, bi, (3, 3, 3))
+        self.mid = _holder(block_1=_resnet(bi, bi, "nin_shortcut", (1, 1, 1)), attn_1=_v3_attn(bi, True),
+                           block_2=_resnet(bi, bi, "nin_shortcut", (1, 1, 1)))
+        ups = [None] * len(mult)
+        for lvl in reversed(range(len(mult))):
+            bo = ch * mult[lvl]
+            blocks = nn.ModuleList()
+            for _j in range(num_res_blocks + 1):
+                blocks.append(_resnet(bi, bo, "nin_shortcut", (1, 1, 1)))
+                bi = bo
+            lv = _holder(block=blocks, attn=nn.ModuleList())
+            if lvl != 0:
+                up_time = 2 if lvl % 2 == 1 else 1
+                lv.add_module("upsample", _holder(conv=ConvP(bi, bi * up_time, (3, 3, 3))))
+            ups[lvl] = lv
+        self.up = nn.ModuleList(ups)
+        self.norm_out = NormP(bi)
+        self.conv_out = ConvP(bi, out_ch, (3, 3, 3))
+        self._cfg = dict(causal=causal, ch_mult=mult, num_res_blocks=num_res_blocks)
+        self.last_z_shape = None
+
+    def forward(self, z, **kwargs):
+        self.last_z_shape = z.shape  # vae_models.py:962
+        return super().forward(z)
+
+
+# ------------------------------------------------------------------------------------------------------
+# output types (diffusers' AutoencoderKLOutput / DecoderOutput / DiagonalGaussianDistribution contracts)
+# ------------------------------------------------------------------------------------------------------
+class AutoencoderKLOutput(dict):
+    def __init__(self, latent_dist):
+        super().__init__(latent_dist=latent_dist)
+        self.latent_dist = latent_dist
+
+    def to_tuple(self):
+        return (self.latent_dist,)
+
+
+class DecoderOutput(dict):
+    def __init__(self, sample):
+        super().__init__(sample=sample)
+        self.sample = sample
+
+    def to_tuple(self):
+        return (self.sample,)
+
+
+class DiagonalGaussianDistribution:
+    """Posterior over latents; maths of /root/reference/lvdm/modules/distributions/distributions.py:24-73 (the in-tree
+    twin of diffusers' class) plus diffusers' `sample(generator=)` signature."""
+
+    def __init__(self, parameters: torch.Tensor, deterministic: bool = False):
+        self.parameters = parameters
+        self.mean, self.logvar = torch.chunk(parameters, 2, dim=1)
+        self.logvar = torch.clamp(self.logvar, -30.0, 20.0)
+        self.deterministic = deterministic
+        self.std = torch.exp(0.5 * self.logvar)
+        self.var = torch.exp(self.logvar)
+        if self.deterministic:
+            self.var = self.std = torch.zeros_like(self.mean)
+
+    def sample(self, generator: Optional[torch.Generator] = None) -> torch.Tensor:
+        dev = self.parameters.device
+        rand_dev = dev
+        if generator is not None and generator.device.type == "cpu" and dev.type != "cpu":
+            rand_dev = torch.device("cpu")  # diffusers randn_tensor: draw on the generator's device, then move
+        noise = torch.randn(self.mean.shape, generator=generator, device=rand_dev, dtype=self.parameters.dtype).to(dev)
+        return self.mean + self.std * noise
+
+    def mode(self) -> torch.Tensor:
+        return self.mean
+
+    def kl(self, other=None):
+        dims = list(range(1, self.mean.dim()))
+        if self.deterministic:
+            return torch.Tensor([0.0])
+        if other is None:
+            return 0.5 * torch.sum(torch.pow(self.mean, 2) + self.var - 1.0 - self.logvar, dim=dims)
+        return 0.5 * torch.sum(torch.pow(self.mean - other.mean, 2) / other.var + self.var / other.var - 1.0
+                               - self.logvar + other.logvar, dim=dims)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the wrapper (modeling_vae.py): config, from_pretrained, temporal windows, spatial tiles, blending
+# ------------------------------------------------------------------------------------------------------
+class _Config(SimpleNamespace):
+    def __getitem__(self, k):
+        return getattr(self, k)
+
+    def get(self, k, default=None):
+        return getattr(self, k, default)
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+
+class _CVVAEBase(nn.Module):
+    config_name = "config.json"
+    _defaults: dict = {}
+    _class_name = ""
+
+    # ---- construction -------------------------------------------------------------------------------
+    def _init_common(self, kw: dict):
+        cfg = dict(self._defaults)
+        unknown = [k for k in kw if k not in cfg and not k.startswith("_")]
+        if unknown:
+            raise TypeError(f"{type(self).__name__}: unexpected config keys {unknown}")
+        cfg.update({k: v for k, v in kw.items() if not k.startswith("_")})
+        self.config = _Config(**cfg)
+        n, tnc = cfg["en_de_n_frames_a_time"], cfg["time_n_compress"]
+        if n is not None:  # modeling_vae.py:84-91
+            assert tnc is not None
+            assert n % tnc == 0
+            self.encode_n_frames_a_time, self.decode_n_frames_a_time = n, n // tnc
+        else:
+            self.encode_n_frames_a_time = self.decode_n_frames_a_time = None
+        nvf = cfg["num_video_frames"]
+        if nvf is not None:  # :93-99
+            assert tnc is not None
+            self.num_video_frames, self.num_latent_frames = nvf, 1 + (nvf - 1) // tnc
+        else:
+            self.num_video_frames = self.num_latent_frames = None
+        ts = cfg["tile_spatial_size"]
+        if ts is not None:  # :101-109
+            assert cfg["spatial_n_compress"] is not None and cfg["tile_overlap_ratio"] is not None
+            self.pixel_tile_size, self.latent_tile_size = ts, ts // cfg["spatial_n_compress"]
+            self.tile_overlap_ratio = cfg["tile_overlap_ratio"]
+        else:
+            self.pixel_tile_size = self.latent_tile_size = self.tile_overlap_ratio = None
+        self.reshape_z_dim_to_4 = cfg["reshape_z_dim_to_4"]  # stored, never applied in encode (Appendix A.1)
+        self.reshape_x_dim_to_4 = cfg["reshape_x_dim_to_4"]
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None,
+                        torch_dtype: Optional[torch.dtype] = None, **kwargs):
+        """diffusers ModelMixin.from_pretrained semantics for a local directory: <path>/<subfolder>/config.json +
+        diffusion_pytorch_model.safetensors (or .bin), strict load, cast, eval  (cvvae_inference_video.py:11)."""
+        root = os.fspath(pretrained_model_name_or_path)
+        if subfolder:
+            root = os.path.join(root, subfolder)
+        cfg_path = os.path.join(root, cls.config_name)
+        if not os.path.isfile(cfg_path):
+            raise OSError(f"{cfg_path} not found (only local directories are supported: there is no hub access)")
+        with open(cfg_path) as f:
+            cfg = json.load(f)
+        cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        model = cls(**cfg)
+        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
+        if os.path.isfile(st):
+            from safetensors.torch import load_file
+            sd = load_file(st)
+        else:
+            binp = os.path.join(root, "diffusion_pytorch_model.bin")
+            if not os.path.isfile(binp):
+                raise OSError(f"no diffusion_pytorch_model.safetensors/.bin under {root}")
+            sd = torch.load(binp, map_location="cpu", weights_only=True)
+        model.load_state_dict(sd, strict=True)
+        if torch_dtype is not None:
+            model = model.to(torch_dtype)
+        model.eval()
+        return model
+
+    def save_pretrained(self, save_directory, safe_serialization: bool = True):
+        os.makedirs(save_directory, exist_ok=True)
+        cfg = self.config.to_dict()
+        cfg["_class_name"] = self._class_name or type(self).__name__
+        with open(os.path.join(save_directory, self.config_name), "w") as f:
+            json.dump(cfg, f, indent=2)
+        sd = {k: v.detach().cpu().contiguous() for k, v in self.state_dict().items()}
+        if safe_serialization:
+            from safetensors.torch import save_file
+            save_file(sd, os.path.join(save_directory, "diffusion_pytorch_model.safetensors"))
+        else:
+            torch.save(sd, os.path.join(save_directory, "diffusion_pytorch_model.bin"))
+
+    @property
+    def dtype(self) -> torch.dtype:
+        return next(self.parameters()).dtype
+
+    @property
+    def device(self) -> torch.device:
+        return next(self.parameters()).device
+
+    # diffusers no-op toggles some pipelines call
+    def enable_slicing(self): pass
+    def disable_slicing(self): pass
+    def enable_tiling(self, *a, **k): pass
+    def disable_tiling(self): pass
+
+    # ---- blending (modeling_vae.py:321-341 / 647-667): in place on b, fp32 ramp ----------------------
+    def blend_v(self, a: torch.Tensor, b: torch.Tensor, overlap_size: int) -> torch.Tensor:
+        return self._blend(a, b, overlap_size, 0)
+
+    def blend_h(self, a: torch.Tensor, b: torch.Tensor, overlap_size: int) -> torch.Tensor:
+        return self._blend(a, b, overlap_size, 1)
+
+    @staticmethod
+    def _blend(a, b, o, axis):
+        if not b.is_cuda:
+            raise RuntimeError("cv-vae_amd blends on the MI355X only (no CPU path)")
+        if a.is_contiguous() and b.is_contiguous():
+            return ops.blend_(a, b, o, axis)
+        ac, bc = a.contiguous(), b.contiguous()
+        ops.blend_(ac, bc, o, axis)
+        b.copy_(bc)
+        return b
+
+    # ---- spatial tiles (modeling_vae.py:144-191, 230-277) ---------------------------------------------
+    def _spatial_tiled(self, x, net, tile, stride, overlap_out, stride_out, **kwargs):
+        rows = []
+        for i in range(0, x.shape[3], stride):
+            cols = []
+            for j in range(0, x.shape[4], stride):
+                cols.append(net(x[:, :, :, i:i + tile, j:j + tile]))
+                if j + tile >= x.shape[4]:
+                    break
+            rows.append(cols)
+            if i + tile >= x.shape[3]:
+                break
+        res = []
+        for i, cols in enumerate(rows):
+            rc = []
+            for j, t in enumerate(cols):
+                if i > 0:
+                    t = self.blend_v(rows[i - 1][j], t, overlap_out)
+                if j > 0:
+                    t = self.blend_h(cols[j - 1], t, overlap_out)
+                rc.append(t)
+            res.append(rc)
+        out_rows = []
+        for i, cols in enumerate(res):
+            for j, t in enumerate(cols):
+                if i < len(res) - 1:
+                    t = t[:, :, :, :stride_out, :]
+                if j < len(cols) - 1:
+                    t = t[:, :, :, :, :stride_out]
+                cols[j] = t
+            out_rows.append(torch.cat(cols, dim=4))
+        return torch.cat(out_rows, dim=3)
+
+    def spatial_tiled_encode(self, x):
+        if self.pixel_tile_size is None:
+            return self.encoder(x)
+        pixel_stride = round(self.pixel_tile_size * (1 - self.tile_overlap_ratio))
+        latent_overlap = round(self.latent_tile_size * self.tile_overlap_ratio)
+        return self._spatial_tiled(x, self.encoder, self.pixel_tile_size, pixel_stride, latent_overlap,
+                                   self.latent_tile_size - latent_overlap)
+
+    def spatial_tiled_decode(self, z, **kwargs):
+        if self.latent_tile_size is None:
+            return self.decoder(z, **kwargs)
+        latent_stride = round(self.latent_tile_size * (1 - self.tile_overlap_ratio))
+        pixel_overlap = round(self.pixel_tile_size * self.tile_overlap_ratio)
+        return self._spatial_tiled(z, self.decoder, self.latent_tile_size, latent_stride, pixel_overlap,
+                                   self.pixel_tile_size - pixel_overlap)
+
+    # ---- temporal windows (modeling_vae.py:193-210, 279-296) -------------------------------------------
+    @staticmethod
+    def _windows(T: int, stride: int):
+        n_rounds = math.ceil((T - 1) / stride)
+        n_rounds = 1 if n_rounds == 0 else n_rounds
+        return [(n * stride, (n + 1) * stride + 1) for n in range(n_rounds)]
+
+    def tiled_encode(self, x):
+        if self.encode_n_frames_a_time is None:
+            return self.spatial_tiled_encode(x)
+        assert x.dim() == 5
+        outs = []
+        for n, (a, b) in enumerate(self._windows(x.shape[2], self.encode_n_frames_a_time)):
+            z_i = self.spatial_tiled_encode(x[:, :, a:b])
+            outs.append(z_i if n == 0 else z_i[:, :, 1:])
+        return torch.cat(outs, dim=2)
+
+    def tiled_decode(self, z, **kwargs):
+        if self.decode_n_frames_a_time is None:
+            return self.spatial_tiled_decode(z, **kwargs)
+        assert z.dim() == 5
+        outs = []
+        for n, (a, b) in enumerate(self._windows(z.shape[2], self.decode_n_frames_a_time)):
+            x_i = self.spatial_tiled_decode(z[:, :, a:b], **kwargs)
+            outs.append(x_i if n == 0 else x_i[:, :, 1:])
+        return torch.cat(outs, dim=2)
+
+    # ---- public API (modeling_vae.py:212-228, 298-319, 114-142) ----------------------------------------
+    @torch.no_grad()
+    def encode(self, x: torch.Tensor, return_dict: bool = True):
+        if x.dim() == 4:
+            if self.num_video_frames is not None:
+                b = x.shape[0] // self.num_video_frames
+                x = x.reshape(b, self.num_video_frames, *x.shape[1:]).permute(0, 2, 1, 3, 4)
+            else:
+                x = x.unsqueeze(2)
+        moments = self.tiled_encode(x)
+        posterior = DiagonalGaussianDistribution(moments)
+        if not return_dict:
+            return (posterior,)
+        return AutoencoderKLOutput(latent_dist=posterior)
+
+    @torch.no_grad()
+    def decode(self, z: torch.Tensor, num_frames: Optional[int] = None, return_dict: bool = True):
+        if z.dim() == 4:
+            t = num_frames if num_frames is not None else self.num_latent_frames
+            if t is not None:
+                z = z.reshape(z.shape[0] // t, t, *z.shape[1:]).permute(0, 2, 1, 3, 4)
+            else:
+                z = z.unsqueeze(2)
+        x = self.tiled_decode(z)
+        if self.reshape_x_dim_to_4:
+            x = x.permute(0, 2, 1, 3, 4).reshape(-1, x.shape[1], *x.shape[3:])
+        if not return_dict:
+            return (x,)
+        return DecoderOutput(sample=x)
+
+    def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True,
+                generator: Optional[torch.Generator] = None, num_frames: Optional[int] = None
+                ) -> Union[DecoderOutput, Tuple[torch.Tensor]]:
+        posterior = self.encode(sample).latent_dist
+        z = posterior.sample(generator=generator) if sample_posterior else posterior.mode()
+        dec = self.decode(z, num_frames=num_frames).sample
+        if not return_dict:
+            return (dec,)
+        return DecoderOutput(sample=dec)
+
+
+class CVVAEModel(_CVVAEBase):
+    """'vae3d' (SD2.1-compatible, 4-ch latent): /root/reference/models/modeling_vae.py:20-341."""
+
+    _class_name = "CVVAEModel"
+    _defaults = dict(
+        double_z=True, z_channels=4, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 2, 4, 4], num_res_blocks=2,
+        attn_resolutions=[], dropout=0.0, use_3d_conv=True, half_3d=True, causal_encoder=True, causal_decoder=False,
+        encoder_attn_type="vanilla-xformers", decoder_attn_type="spatial-temporal-xformer", scaling_factor=0.18215,
+        force_upcast=True, en_de_n_frames_a_time=16, time_n_compress=4, spatial_n_compress=8, tile_spatial_size=576,
+        num_video_frames=None, tile_overlap_ratio=0.2222, reshape_z_dim_to_4=False, reshape_x_dim_to_4=False)
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self._init_common(kwargs)
+        c = self.config
+        unsupported = []
+        if not c.use_3d_conv or not c.half_3d:
+            unsupported.append("use_3d_conv/half_3d must be True")
+        if list(c.attn_resolutions):
+            unsupported.append("attn_resolutions must be []")
+        if c.dropout != 0.0:
+            unsupported.append("dropout must be 0")
+        if c.encoder_attn_type not in ("vanilla-xformers", "vanilla") or c.decoder_attn_type != "spatial-temporal-xformer":
+            unsupported.append("attention types other than the shipped vanilla(-xformers)/spatial-temporal-xformer")
+        if unsupported:
+            raise NotImplementedError("CVVAEModel on MI355X supports the shipped CV-VAE configuration only: " + "; ".join(unsupported))
+        self.encoder = Encoder(ch=c.ch, ch_mult=c.ch_mult, num_res_blocks=c.num_res_blocks, in_channels=c.in_channels,
+                               z_channels=c.z_channels, double_z=c.double_z, causal=c.causal_encoder)
+        self.decoder = Decoder(ch=c.ch, out_ch=c.out_ch, ch_mult=c.ch_mult, num_res_blocks=c.num_res_blocks,
+                               z_channels=c.z_channels, causal=c.causal_decoder)
+
+
+class CVVAESD3Model(_CVVAEBase):
+    """'vae3d_sd3' (SD3-compatible, 16-ch latent): /root/reference/models/modeling_vae.py:344-667."""
+
+    _class_name = "CVVAESD3Model"
+    _defaults = dict(
+        in_channels=3, out_channels=16, down_block_types=["DownEncoderBlock3D"] * 4, up_block_types=["UpDecoderBlock3D"] * 4,
+        block_out_channels=[128, 256, 512, 512], layers_per_block=2, norm_num_groups=32, act_fn="silu", double_z=True,
+        mid_block_add_attention=True, causal_encoder=True, causal_decoder=False, half_3d=True, en_de_n_frames_a_time=16,
+        time_n_compress=4, spatial_n_compress=8, tile_spatial_size=576, num_video_frames=None, tile_overlap_ratio=0.2222,
+        reshape_z_dim_to_4=False, reshape_x_dim_to_4=False)
+
+    def __init__(self, **kwargs):
+        super().__init__()
+        self._init_common(kwargs)
+        c = self.config
+        unsupported = []
+        if any(t != "DownEncoderBlock3D" for t in c.down_block_types) or any(t != "UpDecoderBlock3D" for t in c.up_block_types):
+            unsupported.append("block types other than DownEncoderBlock3D/UpDecoderBlock3D")
+        if c.norm_num_groups != 32 or c.act_fn not in ("silu", "swish") or not c.half_3d:
+            unsupported.append("norm_num_groups != 32, act_fn != silu or half_3d=False")
+        if unsupported:
+            raise NotImplementedError("CVVAESD3Model on MI355X supports the shipped CV-VAE configuration only: " + "; ".join(unsupported))
+        self.encoder = Encoder3D(in_channels=c.in_channels, out_channels=c.out_channels, block_out_channels=c.block_out_channels,
+                                 layers_per_block=c.layers_per_block, double_z=c.double_z,
+                                 mid_block_add_attention=c.mid_block_add_attention, causal=c.causal_encoder)
+        self.decoder = Decoder3D(in_channels=c.out_channels, out_channels=c.in_channels, block_out_channels=c.block_out_channels,
+                                 layers_per_block=c.layers_per_block, mid_block_add_attention=c.mid_block_add_attention,
+                                 causal=c.causal_decoder)
+
+
+# `north_star` calls the class AutoencoderKLCVVAE; the reference has no such name -- provide the alias.
+AutoencoderKLCVVAE = CVVAESD3Model

@@ -44,6 +44,7 @@ class PackedConv:
     cout: int
     cin: int                 # padded input channels the kernel consumes (multiple of kchunk)
     k: Tuple[int, int, int]
+    cin_real: int = 0        # channels of the source weight (algorithmic FLOP accounting)
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
@@ -72,7 +73,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, cout_, cin_pad, tuple(k))
+    return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_)
 
 
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
@@ -130,11 +131,22 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     if prologue != L.PRO_NONE:
         gsc, gsh = gn
         assert gsc.dtype == torch.float32 and gsc.shape[-1] == pw.cin and gsc.is_contiguous() and gsh.is_contiguous()
-    L.check(lib.cvvae_conv_fwd(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),
-                               residual.data_ptr() if residual is not None else None,
-                               gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
-                               out.data_ptr(), _stream()), "cvvae_conv_fwd")
+    def launch():
+        L.check(lib.cvvae_conv_fwd(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),
+                                   residual.data_ptr() if residual is not None else None,
+                                   gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
+                                   out.data_ptr(), _stream()), "cvvae_conv_fwd")
+
+    if PROFILE is None:
+        launch()
+    else:
+        PROFILE(d, pw, launch)
     return out
+
+
+# Optional launch observer used by bench.py's roofline pass: called as PROFILE(desc, packed, launch) where launch()
+# performs the kernel launch on the current stream.  None (the default) = launch directly.
+PROFILE = None
 
 
 def conv_kernel_name(d: "L.ConvDesc") -> Optional[str]:

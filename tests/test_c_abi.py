@@ -1,0 +1,60 @@
+"""The C-ABI library must load WITHOUT a GPU and export every function include/cvvae.h declares, with the
+argument checks reachable (no compute calls here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared():
+    src = open(os.path.join(ROOT, "include", "cvvae.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    names = re.findall(r"\b(cvvae_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(n for n in names if n != "cvvae_conv_kchunk"))  # static inline helper
+
+
+def test_library_exports_every_declared_symbol():
+    from cvvae_amd import _lib
+    lib = _lib.load()
+    names = declared()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/cvvae.h but not exported"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in cv-vae_amd/_lib.py"
+    assert lib.cvvae_abi_version() == _lib.ABI_VERSION
+
+
+def test_struct_layout_matches_header():
+    from cvvae_amd import _lib
+    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad) = 128 bytes
+    assert ctypes.sizeof(_lib.ConvDesc) == 128
+    assert _lib.ConvDesc.in_pix_stride.offset == 24 and _lib.ConvDesc.out_pix_stride.offset == 112
+    assert _lib.ConvDesc.alpha.offset == 120
+
+
+def test_argument_checks_without_gpu():
+    from cvvae_amd import _lib
+    lib = _lib.load()
+    assert lib.cvvae_conv_fwd(None, None, None, None, None, None, None, None, None) == -1
+    d = _lib.ConvDesc()
+    assert lib.cvvae_conv_kernel_name(d) is None
+    d.dtype, d.B, d.Ti, d.Hi, d.Wi, d.Cin, d.in_pix_stride = 1, 1, 5, 16, 16, 128, 128
+    d.kT = d.kH = d.kW = 3
+    d.sT = d.sH = d.sW = 1
+    d.To, d.Ho, d.Wo, d.Cout, d.out_pix_stride, d.gn_rows_per_batch = 5, 16, 16, 128, 128, 1
+    assert lib.cvvae_conv_kernel_name(d).decode().startswith("conv_k333_s111")
+    d.kT = 5
+    assert lib.cvvae_conv_fwd(d, 1, 1, 1, None, None, None, 1, None) == -2  # unsupported kernel size
+    assert lib.cvvae_packed_weight_bytes(128, 128, 27) == 128 * 128 * 27 * 2 + 8192
+    assert lib.cvvae_gn_stats(1, None, 1, 1, 128, 128, 32, 1e-6, None, None, None, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from cvvae_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcvvae_hip.so")
+    with pytest.raises(_lib.CvvaeError, match="no CPU/eager fallback"):
+        _lib.load()

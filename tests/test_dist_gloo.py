@@ -1,0 +1,73 @@
+"""N>1 path on CPU: world_size-2 (and 3) gloo processes shard the temporal windows, exchange the boundary frame
+point-to-point and all_gather the result; must equal the single-process wrapper bit for bit.  The nets are the
+test doubles of test_host_logic.py (the HIP engine needs a GPU; the sharding logic does not)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, T, time_sharded, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.test_host_logic import make
+        from cvvae_amd import dist as D
+        m = make("sd3", tile_spatial_size=144)
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand((1, 3, T, 160, 200), generator=g) * 2 - 1
+        full = m.encode(x).latent_dist.parameters
+        if time_sharded:
+            a, b = D.owned_frames(T, 16, world, rank)
+            got = D.encode_windows_sharded(m, x[:, :, a:b].contiguous(), T_total=T, time_sharded=True)
+        else:
+            got = D.encode_windows_sharded(m, x)
+        ok_e = torch.equal(got, full)
+        z = full[:, :4]
+        ref_y = m.decode(z).sample
+        Tz = z.shape[2]
+        if time_sharded:
+            a, b = D.owned_frames(Tz, 4, world, rank)
+            y = D.decode_windows_sharded(m, z[:, :, a:b].contiguous(), T_total=Tz, time_sharded=True)
+        else:
+            y = D.decode_windows_sharded(m, z)
+        ok_d = torch.equal(y, ref_y)
+        q.put((rank, ok_e, ok_d, tuple(got.shape), tuple(y.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T,time_sharded", [(2, 33, False), (2, 33, True), (2, 49, True), (3, 33, True), (2, 17, True)])
+def test_window_sharding_matches_single_process(world, T, time_sharded):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, T, time_sharded, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_e, ok_d, se, sy in res:
+        assert ok_e and ok_d, (rank, se, sy)
+
+
+def test_partition_helpers():
+    from cvvae_amd import dist as D
+    assert [D.split_contiguous(8, 8, r) for r in range(8)] == [(r, r + 1) for r in range(8)]
+    assert [D.split_contiguous(3, 2, r) for r in range(2)] == [(0, 2), (2, 3)]
+    # cfg 4: T=129 over 8 ranks -> rank 0 owns frames 0..16, rank r owns 16r+1..16r+16
+    assert [D.owned_frames(129, 16, 8, r) for r in range(8)] == [(0, 17)] + [(16 * r + 1, 16 * r + 17) for r in range(1, 8)]
+    assert D.owned_frames(17, 16, 2, 1) == (0, 0)  # fewer windows than ranks

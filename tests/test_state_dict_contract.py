@@ -1,0 +1,57 @@
+"""The on-disk contract: the product's state_dict keys/shapes must equal the reference's.
+oracle/shapes.py is the travelling copy of that table; when /root/reference is present it is re-derived live."""
+import pytest
+import torch
+
+from oracle.ref_loader import load_reference, reference_available
+from oracle.shapes import state_dict_shapes
+
+
+def _product(family, **cfg):
+    import cvvae_amd
+    cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
+    return cls(**cfg)
+
+
+@pytest.mark.parametrize("family", ["sd3", "vae3d"])
+def test_product_keys_match_table(family):
+    m = _product(family)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == state_dict_shapes(family)
+    assert len(got) == (244 if family == "sd3" else 254)  # SURVEY.md 8b [probe]
+
+
+@pytest.mark.skipif(not reference_available(), reason="/root/reference not mounted (GPU box)")
+@pytest.mark.parametrize("family", ["sd3", "vae3d"])
+def test_table_matches_reference(family):
+    ref = load_reference()
+    cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
+    with torch.device("meta"):
+        m = cls()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == state_dict_shapes(family)
+    # config keys and defaults (modeling_vae.py:26-50 / 350-380)
+    mine = _product(family).config.to_dict()
+    theirs = dict(m.config)
+    assert set(mine) == set(theirs)
+    for k in theirs:
+        assert mine[k] == theirs[k], k
+
+
+def test_from_pretrained_roundtrip(tmp_path):
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(tile_spatial_size=144)
+    d = tmp_path / "ckpt" / "vae3d_sd3"
+    m.save_pretrained(str(d))
+    m2 = cvvae_amd.CVVAESD3Model.from_pretrained(str(tmp_path / "ckpt"), subfolder="vae3d_sd3", torch_dtype=torch.float16)
+    assert m2.dtype == torch.float16 and m2.config.tile_spatial_size == 144 and not m2.training
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1.half(), v2)
+    assert m2.pixel_tile_size == 144 and m2.latent_tile_size == 18
+    assert m2.encode_n_frames_a_time == 16 and m2.decode_n_frames_a_time == 4
+
+
+def test_no_cpu_fallback():
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.encoder(torch.zeros(1, 3, 1, 32, 32))
