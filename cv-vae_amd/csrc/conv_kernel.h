@@ -93,7 +93,8 @@ struct Geo {
   static constexpr int NPASS = (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
   static constexpr int SBATCH = NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4);
   static constexpr int STEPS = NTAPS * KSUB;
-  static constexpr int PF = (STEPS % 4 == 0) ? 4 : 3;
+  // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
+  static constexpr int PF = (STEPS % 9 == 0) ? (MREP >= 8 ? 3 : 9) : (STEPS % 8 == 0 ? (MREP >= 8 ? 4 : 8) : (STEPS % 4 == 0 ? 4 : 3));
   static_assert(WM * WN == 8, "8 waves per workgroup");
   static_assert(BM % (32 * WM) == 0, "tile rows must split into 32-row MFMA fragments per wave");
   static_assert(STEPS % PF == 0, "weight prefetch ring must divide the steps of a chunk");
@@ -272,21 +273,28 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     if (active) {
       const char* lb = smem + cur * G::BUFB;
       const T* wc = wq + (size_t)c * (STEPS * 512);
+      // software-pipelined LDS reads: the activation fragments of step st+1 are requested while the MFMAs of
+      // step st issue (two register sets), so an MFMA never waits on the ds_read issued right before it.
+      v8 ab[2][MREP];
 #pragma unroll
-      for (int tap = 0; tap < G::NTAPS; ++tap) {
-        const int dt = tap / (KH * KW), dy = (tap / KW) % KH, dx = tap % KW;
-        const int tapoff = ((dt * G::FH + dy) * G::FW + dx) * PIXB;
+      for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(lb + aoff[r]);
 #pragma unroll
-        for (int ks = 0; ks < KSUB; ++ks) {
-          const int st = tap * KSUB + ks;
-          const v8 wv = wf[st % PF];
+      for (int st = 0; st < STEPS; ++st) {
+        const v8 wv = wf[st % PF];
+        const int nt = (st + 1) / KSUB, nks = (st + 1) % KSUB;  // next step's tap / k-sub-chunk
+        const int ndt = nt / (KH * KW), ndy = (nt / KW) % KH, ndx = nt % KW;
+        const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * 32;
 #pragma unroll
-          for (int r = 0; r < MREP; ++r) {
-            const v8 av = *reinterpret_cast<const v8*>(lb + aoff[r] + tapoff + ks * 32);
-            acc[r] = Tr<T>::mfma(wv, av, acc[r]);
-          }
-          wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF) * 512);
+        for (int r = 0; r < MREP; ++r) {
+          acc[r] = Tr<T>::mfma(wv, ab[st & 1][r], acc[r]);
+          if (st + 1 < STEPS) ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(lb + aoff[r] + noff);
         }
+        wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF) * 512);
+        // Fence per step: keeps the next step's ds_reads and the weight prefetch inside THIS step.  hipcc otherwise
+        // sinks every load to just before its first use, which exposes the LDS / L2 latency once per MFMA
+        // (measured on MI355X: 1158 -> 1240 TFLOP/s on 256->256 @9x256^2; pinning a strict MFMA/ds_read
+        // alternation with sched_group_barrier instead was 4 % slower than letting hipcc order the step).
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     if (grp == 1 && more) stage(c + 1, cur ^ 1);

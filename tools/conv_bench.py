@@ -1,0 +1,66 @@
+#!/usr/bin/env python
+"""Micro-benchmark of single conv launches (tuning aid; also the command profiled for profiles/*pmc*).
+usage: python tools/conv_bench.py [case ...] [--iters N] [--dtype bf16|f16]
+cases are the cfg-3 layer shapes of SURVEY.md 2.3."""
+import argparse
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import cvvae_amd  # noqa: E402,F401
+from cvvae_amd import _lib as L  # noqa: E402
+from cvvae_amd import ops  # noqa: E402
+
+P1 = ((1, 1), (1, 1), (1, 1))
+PC = ((2, 0), (1, 1), (1, 1))
+P2D = ((0, 0), (1, 1), (1, 1))
+# name: (Cin, Cout, k, T, H, W, pad, prologue, ups)
+CASES = {
+    "enc128": (128, 128, (3, 3, 3), 17, 512, 512, PC, 1, False),      # 128->128 @17x512^2 (config B)
+    "enc256": (256, 256, (3, 3, 3), 9, 256, 256, PC, 1, False),       # 256->256 @9x256^2 (config A)
+    "enc512": (512, 512, (3, 3, 3), 9, 128, 128, PC, 1, False),
+    "dec512s": (512, 512, (3, 3, 3), 5, 64, 64, P1, 1, False),
+    "dec256to128": (256, 128, (3, 3, 3), 17, 512, 512, P1, 1, False),
+    "up256to512": (256, 512, (3, 3, 3), 9, 256, 256, P1, 0, True),    # the 16.7 TFLOP upsample conv
+    "c2d128": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
+    "c2d512": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
+    "out128to3": (128, 3, (3, 3, 3), 17, 512, 512, P1, 1, False),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("cases", nargs="*", default=["enc128", "enc256", "up256to512", "c2d128"])
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--dtype", default="bf16")
+    a = ap.parse_args()
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    for name in a.cases:
+        cin, cout, k, T, H, W, pad, pro, ups = CASES[name]
+        x = (torch.rand((1, T, H, W, cin), device="cuda") * 2 - 1).to(dt)
+        w = (torch.rand((cout, cin) + k, device="cuda") * 2 - 1).to(dt) / (cin * k[0] * k[1] * k[2]) ** 0.5
+        pw = ops.pack_weight(w.reshape(cout, cin, -1), torch.zeros(cout, device="cuda"), k)
+        gn = None
+        if pro:
+            gn = ops.gn_stats(x, torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), 1e-6)
+        kw = dict(pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
+                  gn=gn, upsample2x=ups, out_mode=L.OUT_NCDHW if cout <= 32 else L.OUT_NDHWC)
+        y = ops.conv(x, pw, **kw)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            ops.conv(x, pw, out=y, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / a.iters
+        npix = y.numel() // cout
+        fl = 2.0 * npix * cout * cin * k[0] * k[1] * k[2]
+        print(f"{name:12s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  ({fl / 1e9:.0f} GFLOP, out {tuple(y.shape)})", flush=True)
+
+
+if __name__ == "__main__":
+    main()
