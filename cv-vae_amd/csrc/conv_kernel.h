@@ -245,12 +245,12 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // ---- MFMA plan
   const int nb = ntile * WN + wave_n;  // my 32-output-channel block
   const bool active = nb < p.nblk32;
-  int aoff[MREP];
+  unsigned aoff[MREP];
 #pragma unroll
   for (int r = 0; r < MREP; ++r) {
     const int m = (wave_m * MREP + r) * 32 + (lane & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
-    aoff[r] = (((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16;
+    aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16);
   }
   const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + lane * 8;
   v8 wf[PF];
@@ -271,13 +271,13 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     const bool more = (c + 1) < p.nchunks;
     if (grp == 0 && more) stage(c + 1, cur ^ 1);
     if (active) {
-      const char* lb = smem + cur * G::BUFB;
+      const unsigned lb = (unsigned)(cur * G::BUFB);  // 32-bit LDS offsets throughout (no 64-bit address math)
       const T* wc = wq + (size_t)c * (STEPS * 512);
       // software-pipelined LDS reads: the activation fragments of step st+1 are requested while the MFMAs of
       // step st issue (two register sets), so an MFMA never waits on the ds_read issued right before it.
       v8 ab[2][MREP];
 #pragma unroll
-      for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(lb + aoff[r]);
+      for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r]]);
 #pragma unroll
       for (int st = 0; st < STEPS; ++st) {
         const v8 wv = wf[st % PF];
@@ -287,7 +287,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
         for (int r = 0; r < MREP; ++r) {
           acc[r] = Tr<T>::mfma(wv, ab[st & 1][r], acc[r]);
-          if (st + 1 < STEPS) ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(lb + aoff[r] + noff);
+          if (st + 1 < STEPS) ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (unsigned)noff]);
         }
         wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF) * 512);
         // Fence per step: keeps the next step's ds_reads and the weight prefetch inside THIS step.  hipcc otherwise
@@ -303,16 +303,20 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   if (!active) return;
 
   // ---- epilogue: lane = one pixel, register quad g = 4 consecutive output channels
+  // (the opaque copy of `lane` stops hipcc from hoisting the 32 output addresses above the K loop, where they
+  //  would sit in 64 VGPRs for the whole kernel and push the BM=512 tiles into scratch)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
   const int C2 = p.Cout >> 1;
 #pragma unroll
   for (int r = 0; r < MREP; ++r) {
-    const int m = (wave_m * MREP + r) * 32 + (lane & 31);
+    const int m = (wave_m * MREP + r) * 32 + (lane_e & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
     const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
     if (to >= p.To || yo >= p.Ho || xo >= p.Wo) continue;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int cb = nb * 32 + g * 8 + (lane >> 5) * 4;
+      const int cb = nb * 32 + g * 8 + (lane_e >> 5) * 4;
       if (cb >= p.Cout) continue;
       float v[4];
       const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb);

@@ -10,7 +10,8 @@
 #define CVVAE_CONV_G2(X) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4, 1, 0,false) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4, 1, 1,false)
-// (BM=512 two-frame tiles for Cout=128 spill under the 256-VGPR cap of an 8-wave workgroup: not built yet)
+// (BM=512 tiles -- 2x8x32 for 3x3x3, 1x16x32 for 1x3x3 -- were measured: they need >256 VGPRs per wave in an
+//  8-wave workgroup, hipcc spills ~200 registers and they run 30 % SLOWER than the BM=256 tiles; not built)
 #define CVVAE_CONV_G3(X)
 #define CVVAE_CONV_G4(X) \
   X(3,3,3, 1,1,1, 1,8,32, 8,1, 1, 0,false) \

@@ -1,6 +1,7 @@
 // cvvae_api.hip -- extern "C" entry for the convolution: argument checking, tile/instance selection, launch.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/cvvae.h"
@@ -37,8 +38,14 @@ static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b;
 static const Instance* select_instance(const cvvae_conv_desc* d) {
   const Instance* best = nullptr;
   double best_cost = 0;
+  // tuning aid: CVVAE_CONV_FORCE="TTxTHxTW:WMxWN" restricts the choice (ignored when nothing matches)
+  int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0;
+  if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%d", &ft, &fh, &fw, &fm, &fn);
+  for (int pass = 0; pass < 2 && !best; ++pass)
   for (int i = 0; i < g_ntable; ++i) {
     const Instance& e = g_table[i];
+    if (pass == 0 && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn)) continue;
+    if (pass == 0 && !ft) { }
     if (e.kt != d->kT || e.kh != d->kH || e.kw != d->kW || e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
     if (e.pro != d->prologue || e.ups != (d->upsample2x ? 1 : 0)) continue;
     const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
