@@ -75,6 +75,10 @@ struct ConvArgs {
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
+// Every wave keeps PF packed-weight fragments (1 KiB each) in flight and never branches on "last step", so it reads up
+// to PF KiB past the last real fragment: cvvae_packed_weight_bytes() appends this many readable bytes.
+constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
+
 template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB>
 struct Geo {
   static constexpr int NTAPS = KT * KH * KW;
@@ -99,6 +103,7 @@ struct Geo {
   static_assert(BM % (32 * WM) == 0, "tile rows must split into 32-row MFMA fragments per wave");
   static_assert(STEPS % PF == 0, "weight prefetch ring must divide the steps of a chunk");
   static_assert(LDSB <= 160 * 1024, "LDS budget");
+  static_assert(PF * 1024 <= WEIGHT_TAIL_BYTES, "weight prefetch ring reads past the packed buffer's tail");
   static_assert(NPH <= NPIX || NPIX <= PPP, "split");
 };
 

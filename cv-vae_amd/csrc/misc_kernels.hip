@@ -433,7 +433,7 @@ extern "C" {
 
 size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps) {
   const size_t co = (size_t)((Cout + 31) / 32) * 32;
-  return co * (size_t)Cin * (size_t)taps * 2 + 8 * 1024;  // + read-ahead tail for the prefetch ring
+  return co * (size_t)Cin * (size_t)taps * 2 + WEIGHT_TAIL_BYTES;  // + read-ahead tail for the prefetch ring
 }
 
 int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
