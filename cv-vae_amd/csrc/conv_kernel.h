@@ -79,7 +79,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // to PF KiB past the last real fragment: cvvae_packed_weight_bytes() appends this many readable bytes.
 constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
 
-template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB>
+template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB>
 struct Geo {
   static constexpr int NTAPS = KT * KH * KW;
   static constexpr int BM = TT * TH * TW;
@@ -96,13 +96,18 @@ struct Geo {
   static constexpr int NPH = ((NPIX + 1) / 2 + PPP - 1) / PPP * PPP;  // pixels staged by group X
   static constexpr int NPASS = (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
   static constexpr int SBATCH = NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4);
-  static constexpr int STEPS = NTAPS * KSUB;
+  static constexpr int STEPS = NTAPS * KSUB;   // k16 steps per chunk, ordered ks-major: st = ks * NTAPS + tap
+  static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
   // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
-  static constexpr int PF = (STEPS % 9 == 0) ? (MREP >= 8 ? 3 : 9) : (STEPS % 8 == 0 ? (MREP >= 8 ? 4 : 8) : (STEPS % 4 == 0 ? 4 : 3));
-  static_assert(WM * WN == 8, "8 waves per workgroup");
+  static constexpr int PF = (STEPS_W % 9 == 0) ? (MREP >= 8 ? 3 : 9) : (STEPS_W % 8 == 0 ? (MREP >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
+  // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
+  static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
+  static constexpr int SMEMB = cmax(LDSB, REDB);
+  static_assert(WM * WN * KG == 8, "8 waves per workgroup");
+  static_assert(KG == 1 || (KG == 2 && KSUB % 2 == 0 && MREP % 2 == 0 && WM * WN == 4), "K-group split");
   static_assert(BM % (32 * WM) == 0, "tile rows must split into 32-row MFMA fragments per wave");
-  static_assert(STEPS % PF == 0, "weight prefetch ring must divide the steps of a chunk");
-  static_assert(LDSB <= 160 * 1024, "LDS budget");
+  static_assert(STEPS_W % PF == 0, "weight prefetch ring must divide the steps of a chunk");
+  static_assert(SMEMB <= 160 * 1024, "LDS budget");
   static_assert(PF * 1024 <= WEIGHT_TAIL_BYTES, "weight prefetch ring reads past the packed buffer's tail");
   static_assert(NPH <= NPIX || NPIX <= PPP, "split");
 };
@@ -133,22 +138,24 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
   return c;
 }
 
-template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB,
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
           int PRO, bool UPS>
 __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
-  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KSUB>;
+  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB>;
   using v8 = typename Tr<T>::v8;
   using v4 = typename Tr<T>::v4;
-  constexpr int MREP = G::MREP, PIXB = G::PIXB, NPASS = G::NPASS, STEPS = G::STEPS, PF = G::PF, CK = G::CK;
+  constexpr int MREP = G::MREP, PIXB = G::PIXB, NPASS = G::NPASS, STEPS = G::STEPS, STEPS_W = G::STEPS_W, PF = G::PF,
+                CK = G::CK, NTAPS = G::NTAPS;
 
-  __shared__ __attribute__((aligned(16))) char smem[G::LDSB];
+  __shared__ __attribute__((aligned(16))) char smem[G::SMEMB];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
   const int wave_n = wave % WN;
-  const int wave_m = wave / WN;
+  const int wave_m = (wave / WN) % WM;
+  const int kgrp = KG == 2 ? grp : 0;  // K-group: which half of the chunk's k16 sub-chunks this wave multiplies
 
   // ---- XCD-aware, bijective block remap: each XCD (bid % 8) gets a contiguous run of logical tiles, so
   //      neighbouring halo tiles and all N-tiles of one M-tile share one L2.
@@ -255,9 +262,11 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   for (int r = 0; r < MREP; ++r) {
     const int m = (wave_m * MREP + r) * 32 + (lane & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
-    aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16);
+    aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16 +
+                         kgrp * (KSUB / KG) * 32);
   }
-  const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + lane * 8;
+  const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) +
+                kgrp * (STEPS_W * 512) + lane * 8;
   v8 wf[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) wf[i] = *reinterpret_cast<const v8*>(wq + i * 512);
@@ -284,17 +293,18 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
       for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r]]);
 #pragma unroll
-      for (int st = 0; st < STEPS; ++st) {
+      for (int st = 0; st < STEPS_W; ++st) {
         const v8 wv = wf[st % PF];
-        const int nt = (st + 1) / KSUB, nks = (st + 1) % KSUB;  // next step's tap / k-sub-chunk
+        const int nks = (st + 1) / NTAPS, nt = (st + 1) % NTAPS;  // next step's k-sub-chunk (within my K-group) / tap
         const int ndt = nt / (KH * KW), ndy = (nt / KW) % KH, ndx = nt % KW;
         const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * 32;
 #pragma unroll
         for (int r = 0; r < MREP; ++r) {
           acc[r] = Tr<T>::mfma(wv, ab[st & 1][r], acc[r]);
-          if (st + 1 < STEPS) ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (unsigned)noff]);
+          if (st + 1 < STEPS_W) ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (unsigned)noff]);
         }
-        wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF) * 512);
+        // ring refill: my record st+PF of this chunk, or (wrapping) record st+PF-STEPS_W of the next chunk
+        wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512);
         // Fence per step: keeps the next step's ds_reads and the weight prefetch inside THIS step.  hipcc otherwise
         // sinks every load to just before its first use, which exposes the LDS / L2 latency once per MFMA
         // (measured on MI355X: 1158 -> 1240 TFLOP/s on 256->256 @9x256^2; pinning a strict MFMA/ds_read
@@ -304,6 +314,51 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     }
     if (grp == 1 && more) stage(c + 1, cur ^ 1);
     __syncthreads();
+  }
+  // ---- K-group reduction (KG == 2): group 0 keeps fragments [0,H) and parks [H,MREP) in LDS, group 1 the opposite;
+  //      after one barrier each adds its partner's parked half (same (wave_m, wave_n) slot of the other group).
+  //      The K loop ended on a barrier, so the halo buffers are dead.  Static fragment indices only (a runtime-indexed
+  //      accumulator array would go to scratch), hence the two wave-uniform branches.
+  if constexpr (KG == 2) {
+    constexpr int H = MREP / 2;
+    const int wslot = wave & 3;
+    float4* park = reinterpret_cast<float4*>(smem) + (size_t)((kgrp * 4 + wslot) * H * 4) * 64 + lane;
+    if (active) {
+      if (kgrp == 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            park[(h * 4 + q) * 64] = make_float4(acc[H + h][q * 4], acc[H + h][q * 4 + 1], acc[H + h][q * 4 + 2], acc[H + h][q * 4 + 3]);
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            park[(h * 4 + q) * 64] = make_float4(acc[h][q * 4], acc[h][q * 4 + 1], acc[h][q * 4 + 2], acc[h][q * 4 + 3]);
+      }
+    }
+    __syncthreads();
+    const float4* take = reinterpret_cast<const float4*>(smem) + (size_t)(((kgrp ^ 1) * 4 + wslot) * H * 4) * 64 + lane;
+    if (active) {
+      if (kgrp == 0) {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = take[(h * 4 + q) * 64];
+            acc[h][q * 4] += v.x; acc[h][q * 4 + 1] += v.y; acc[h][q * 4 + 2] += v.z; acc[h][q * 4 + 3] += v.w;
+          }
+      } else {
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const float4 v = take[(h * 4 + q) * 64];
+            acc[H + h][q * 4] += v.x; acc[H + h][q * 4 + 1] += v.y; acc[H + h][q * 4 + 2] += v.z; acc[H + h][q * 4 + 3] += v.w;
+          }
+      }
+    }
   }
   if (!active) return;
 
@@ -315,6 +370,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const int C2 = p.Cout >> 1;
 #pragma unroll
   for (int r = 0; r < MREP; ++r) {
+    if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
     const int m = (wave_m * MREP + r) * 32 + (lane_e & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
     const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
@@ -386,10 +442,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 }
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)
-template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KSUB,
+template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
           int PRO, bool UPS>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KSUB, PRO, UPS>), dim3(grid), dim3(512),
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS>), dim3(grid), dim3(512),
                      0, s, a);
   return (int)hipGetLastError();
 }

@@ -11,50 +11,52 @@
 namespace cvvae {
 
 // the instantiations live in conv_inst_*.hip
-#define CVVAE_EXTERN(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS) \
-  extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t); \
-  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t);
+#define CVVAE_EXTERN(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t); \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_ALL(CVVAE_EXTERN)
 
 typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 
 struct Instance {
-  int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, ksub, pro, ups;
+  int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, kg, ksub, pro, ups;
   launch_fn fn[2];  // [CVVAE_F16], [CVVAE_BF16]
   char name[96];
 };
 
-#define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,(UPS) ? 1 : 0, \
-   {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>, \
-    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KSUB,PRO,UPS>}, ""},
+#define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,(UPS) ? 1 : 0, \
+   {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>}, ""},
 
 static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
-// pick the instance with the least padded work (tile overhang x inactive N waves); ties -> larger tile
+// pick the instance with the least padded work (tile overhang x inactive N waves); ties -> table order
 static const Instance* select_instance(const cvvae_conv_desc* d) {
   const Instance* best = nullptr;
   double best_cost = 0;
-  // tuning aid: CVVAE_CONV_FORCE="TTxTHxTW:WMxWN" restricts the choice (ignored when nothing matches)
-  int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0;
-  if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%d", &ft, &fh, &fw, &fm, &fn);
+  // tuning aid: CVVAE_CONV_FORCE="TTxTHxTW:WMxWNxKG:KSUB" restricts the choice (ignored when nothing matches)
+  int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0, fg = 0, fk = 0;
+  if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%dx%d:%d", &ft, &fh, &fw, &fm, &fn, &fg, &fk);
   for (int pass = 0; pass < 2 && !best; ++pass)
   for (int i = 0; i < g_ntable; ++i) {
     const Instance& e = g_table[i];
-    if (pass == 0 && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn)) continue;
-    if (pass == 0 && !ft) { }
+    if (pass == 0 && ft &&
+        (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) continue;
     if (e.kt != d->kT || e.kh != d->kH || e.kw != d->kW || e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
     if (e.pro != d->prologue || e.ups != (d->upsample2x ? 1 : 0)) continue;
+    if (d->Cin % (16 * e.ksub)) continue;  // the instance's K-chunk must divide the consumed channels
     const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
     const long long tiles = cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
     const long long ntn = cdiv(d->Cout, bn);
     // cost ~ MFMA work issued (padded) + staging work (halo per N tile)
     double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
     cost *= 1.0 + 0.15 * 256.0 / (double)bn;   // staging share grows as BN shrinks
-    cost *= 1.0 + 0.05 * 256.0 / (double)bm;   // weight traffic share grows as BM shrinks
+    // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
+    cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
     if (!best || cost < best_cost) {
       best = &e;
       best_cost = cost;
@@ -65,8 +67,8 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
 
 static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
-    snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%d_pro%d_ups%d", e->kt, e->kh, e->kw, e->st, e->sh,
-             e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->pro, e->ups);
+    snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d", e->kt, e->kh, e->kw, e->st,
+             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups);
   (void)dtype;
   return e->name;
 }

@@ -441,7 +441,9 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
   if (!src || !dst || Cout_src <= 0 || Cin_src <= 0 || taps <= 0 || kchunk <= 0 || kchunk % 16 || Cin_pad % kchunk ||
       Cin_pad < Cin_src)
     return CVVAE_EINVAL;
-  const int nb = (Cout_src + 31) / 32, nchunks = Cin_pad / kchunk, ksub = kchunk / 16;
+  // the packed layout is the same for every kernel family: [Cout/32][Cin_pad/16][tap][64 lanes][8] (k16-major);
+  // kchunk only states the granularity Cin_pad was rounded to (the K-chunk of the consuming kernel instance)
+  const int nb = (Cout_src + 31) / 32, nchunks = Cin_pad / 16, ksub = 1;
   const long long n = (long long)nb * nchunks * taps * ksub * 64;
   const int grid = (int)((n + 255) / 256);
   hipStream_t s = (hipStream_t)stream;

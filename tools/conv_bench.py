@@ -36,7 +36,11 @@ def main():
     ap.add_argument("cases", nargs="*", default=["enc128", "enc256", "up256to512", "c2d128"])
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--force", action="append", default=None,
+                    help='CVVAE_CONV_FORCE values to A/B ("" = library default), e.g. --force "" --force 1x8x32:2x4x1:1')
+    ap.add_argument("--rounds", type=int, default=3)
     a = ap.parse_args()
+    forces = a.force or [""]
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
     for name in a.cases:
         cin, cout, k, T, H, W, pad, pro, ups = CASES[name]
@@ -48,18 +52,29 @@ def main():
             gn = ops.gn_stats(x, torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), 1e-6)
         kw = dict(pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
                   gn=gn, upsample2x=ups, out_mode=L.OUT_NCDHW if cout <= 32 else L.OUT_NDHWC)
-        y = ops.conv(x, pw, **kw)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(a.iters):
-            ops.conv(x, pw, out=y, **kw)
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / a.iters
-        npix = y.numel() // cout
+        npix = None
+        best = {}
+        for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
+            for f in forces:
+                os.environ["CVVAE_CONV_FORCE"] = f
+                y = ops.conv(x, pw, **kw)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    ops.conv(x, pw, out=y, **kw)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / a.iters
+                best.setdefault(f, []).append(ms)
+                npix = y.numel() // cout
         fl = 2.0 * npix * cout * cin * k[0] * k[1] * k[2]
-        print(f"{name:12s} {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  ({fl / 1e9:.0f} GFLOP, out {tuple(y.shape)})", flush=True)
+        for f in forces:
+            ms = sorted(best[f])[len(best[f]) // 2]
+            os.environ["CVVAE_CONV_FORCE"] = f
+            print(f"{name:12s} force={f or '-':22s} median {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  min {min(best[f]):8.3f} ms "
+                  f"({fl / 1e9:.0f} GFLOP)", flush=True)
+    os.environ["CVVAE_CONV_FORCE"] = ""
 
 
 if __name__ == "__main__":
