@@ -69,9 +69,24 @@ struct ConvArgs {
   int nchunks;   // Cin / CK
   int nblk32;    // ceil(Cout/32): number of packed 32-channel weight blocks
   int out_mode, out_f32;
+  int order;     // logical tile order: 1 = (ntile, t, x, y, b) fastest-first, 0 = (ntile, x, y, t, b)
   int gn_rpb;
   float alpha;
+  // tuning probe (tools/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
+  unsigned long long* dbg;
+  int dbg_block;
 };
+
+#ifdef CVVAE_CONV_PROBE
+#define CVVAE_PROBE_MARK()                                                                     \
+  do {                                                                                         \
+    if (p.dbg && (int)blockIdx.x == p.dbg_block && lane == 0 && probe_n < 128)                 \
+      p.dbg[wave * 128 + probe_n] = __builtin_amdgcn_s_memtime();                              \
+    ++probe_n;                                                                                 \
+  } while (0)
+#else
+#define CVVAE_PROBE_MARK() do { } while (0)
+#endif
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
@@ -165,14 +180,27 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // logical order: N-tile fastest (the N-tiles of one pixel tile re-use its halo from L2), then TIME, then x, y, b.
+  // Time-adjacent tiles share 2 of their 3 halo frames; with time next-fastest they run at the same moment on CUs of
+  // the same XCD, so the K-chunk passes over the halo stay inside that XCD's 4 MiB L2 instead of thrashing it.
   const int ntile = logical % p.ntiles_n;
   int mt = logical / p.ntiles_n;
-  const int tw_i = mt % p.tiles_w;
-  mt /= p.tiles_w;
-  const int th_i = mt % p.tiles_h;
-  mt /= p.tiles_h;
-  const int tt_i = mt % p.tiles_t;
-  const int b = mt / p.tiles_t;
+  int tw_i, th_i, tt_i, b;
+  if (p.order == 1) {
+    tt_i = mt % p.tiles_t;
+    mt /= p.tiles_t;
+    tw_i = mt % p.tiles_w;
+    mt /= p.tiles_w;
+    th_i = mt % p.tiles_h;
+    b = mt / p.tiles_h;
+  } else {
+    tw_i = mt % p.tiles_w;
+    mt /= p.tiles_w;
+    th_i = mt % p.tiles_h;
+    mt /= p.tiles_h;
+    tt_i = mt % p.tiles_t;
+    b = mt / p.tiles_t;
+  }
   const int t0 = tt_i * TT, y0 = th_i * TH, x0 = tw_i * TW;
 
   // ---- staging plan (chunk independent): which stored pixel feeds each of my halo slots
@@ -207,7 +235,13 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
   const size_t gn_row = (size_t)(b * p.gn_rpb + (p.gn_rpb > 1 ? t0 : 0)) * (size_t)p.Cin;
 
+#ifdef CVVAE_CONV_PROBE
+  int probe_n = 0;
+#endif
   auto stage = [&](int chunk, int bufsel) {
+#ifdef CVVAE_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(CVVAE_STAGE_PRIO);
+#endif
     const int c0 = chunk * CK + sq * 8;
     float sc[8], sh[8];
     if (PRO != 0) {
@@ -231,6 +265,13 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
           raw[kk] = *reinterpret_cast<const uint4*>(inp + (size_t)sp * (size_t)p.in_ps + c0);
         }
       }
+#ifdef CVVAE_CONV_PROBE
+      if (k0 == 0) {
+        CVVAE_PROBE_MARK();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        CVVAE_PROBE_MARK();
+      }
+#endif
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
@@ -252,6 +293,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         }
       }
     }
+#ifdef CVVAE_STAGE_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
   };
 
   // ---- MFMA plan
@@ -278,12 +322,16 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
 
   // ---- pipeline
+  CVVAE_PROBE_MARK();
   stage(0, 0);
+  CVVAE_PROBE_MARK();
   __syncthreads();
   for (int c = 0; c < p.nchunks; ++c) {
     const int cur = c & 1;
     const bool more = (c + 1) < p.nchunks;
+    CVVAE_PROBE_MARK();
     if (grp == 0 && more) stage(c + 1, cur ^ 1);
+    CVVAE_PROBE_MARK();
     if (active) {
       const unsigned lb = (unsigned)(cur * G::BUFB);  // 32-bit LDS offsets throughout (no 64-bit address math)
       const T* wc = wq + (size_t)c * (STEPS * 512);
@@ -312,9 +360,12 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    CVVAE_PROBE_MARK();
     if (grp == 1 && more) stage(c + 1, cur ^ 1);
+    CVVAE_PROBE_MARK();
     __syncthreads();
   }
+  CVVAE_PROBE_MARK();
   // ---- K-group reduction (KG == 2): group 0 keeps fragments [0,H) and parks [H,MREP) in LDS, group 1 the opposite;
   //      after one barrier each adds its partner's parked half (same (wave_m, wave_n) slot of the other group).
   //      The K loop ended on a barrier, so the halo buffers are dead.  Static fragment indices only (a runtime-indexed
@@ -362,83 +413,116 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   }
   if (!active) return;
 
-  // ---- epilogue: lane = one pixel, register quad g = 4 consecutive output channels
-  // (the opaque copy of `lane` stops hipcc from hoisting the 32 output addresses above the K loop, where they
-  //  would sit in 64 VGPRs for the whole kernel and push the BM=512 tiles into scratch)
+  // ---- epilogue.  Accumulator layout: lane = one pixel, register quad g = 4 consecutive output channels
+  //      (lanes 0-31: channels 8g..8g+3, lanes 32-63: channels 8g+4..8g+7 of the wave's 32-channel block).
+  // (the opaque copy of `lane` stops hipcc from hoisting the output addresses above the K loop, where they
+  //  would sit in VGPRs for the whole kernel)
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int C2 = p.Cout >> 1;
+  if (p.out_mode == 1) {  // NCDHW, dtype T (conv_out: few channels, scattered 2-byte stores)
+#pragma unroll
+    for (int r = 0; r < MREP; ++r) {
+      if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
+      const int m = (wave_m * MREP + r) * 32 + (lane_e & 31);
+      const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
+      const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
+      if (to >= p.To || yo >= p.Ho || xo >= p.Wo) continue;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int cb = nb * 32 + g * 8 + (lane_e >> 5) * 4;
+        if (cb >= p.Cout) continue;
+        const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb);
+        const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
+        T* o = reinterpret_cast<T*>(p.out);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (cb + j < p.Cout)
+            o[((((size_t)b * p.Cout + (cb + j)) * p.To + to) * p.Ho + yo) * (size_t)p.Wo + xo] =
+                (T)(acc[r][g * 4 + j] * p.alpha + bb[j]);
+      }
+    }
+    CVVAE_PROBE_MARK();
+    return;
+  }
+  // NDHWC / time-shuffle: the store tail is store-ISSUE bound (8-byte pieces of 32 different lines per instruction), so
+  // the two half-waves first exchange register quads with v_permlane32_swap: for each PAIR of quads (g, g+1) the lower
+  // half-wave ends up with channels 16*pair..+7 and the upper one with 16*pair+8..+15 of its pixel -- 8 consecutive
+  // channels per lane -> ONE 16-byte store (and one 16-byte residual load) instead of two 8-byte ones.
 #pragma unroll
   for (int r = 0; r < MREP; ++r) {
     if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
     const int m = (wave_m * MREP + r) * 32 + (lane_e & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
     const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
-    if (to >= p.To || yo >= p.Ho || xo >= p.Wo) continue;
+    const bool inside = to < p.To && yo < p.Ho && xo < p.Wo;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int cb = nb * 32 + g * 8 + (lane_e >> 5) * 4;
-      if (cb >= p.Cout) continue;
-      float v[4];
-      const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb);
-      v[0] = acc[r][g * 4 + 0] * p.alpha + bv.x;
-      v[1] = acc[r][g * 4 + 1] * p.alpha + bv.y;
-      v[2] = acc[r][g * 4 + 2] * p.alpha + bv.z;
-      v[3] = acc[r][g * 4 + 3] * p.alpha + bv.w;
-      if (p.out_mode == 1) {  // NCDHW, dtype T
-        T* o = reinterpret_cast<T*>(p.out);
+    for (int pr = 0; pr < 2; ++pr) {
+      float v[8];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (cb + j < p.Cout)
-            o[((((size_t)b * p.Cout + (cb + j)) * p.To + to) * p.Ho + yo) * (size_t)p.Wo + xo] = (T)v[j];
-        continue;
+      for (int j = 0; j < 4; ++j) {
+        // vdst = quad 2*pr (its upper-half lanes are exchanged), src = quad 2*pr+1 (its lower-half lanes).
+        // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) aliases the builtin's two results when they
+        // are scattered into an unrolled array (both halves came back as result 0).  The alpha multiply in front is the
+        // compiler's own VALU op, so the MFMA-result -> VALU hazard is padded by hipcc; `s_nop 1` covers the
+        // VALU-write -> v_permlane read hazard, which hipcc does not pad inside an asm statement.
+        float lo = acc[r][(2 * pr) * 4 + j] * p.alpha, hi = acc[r][(2 * pr + 1) * 4 + j] * p.alpha;
+        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+        v[j] = lo;
+        v[4 + j] = hi;
       }
-      int cc = cb, tq = to, Tq = p.To;
-      if (p.out_mode == 2) {  // channel -> time shuffle, drop frame -1
-        const int n = cb >= C2 ? 1 : 0;
-        cc = cb - n * C2;
+      const int c8 = nb * 32 + pr * 16 + (lane_e >> 5) * 8;  // my 8 consecutive output channels
+      if (!inside || c8 >= p.Cout) continue;
+      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c8);
+      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c8 + 4);
+      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+      v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+      int cc = c8, tq = to, Tq = p.To;
+      if (p.out_mode == 2) {  // channel -> time shuffle, drop frame -1 (C2 is a multiple of 8: an 8-run never straddles)
+        const int n = c8 >= C2 ? 1 : 0;
+        cc = c8 - n * C2;
         tq = 2 * to + n - 1;
         Tq = 2 * p.To - 1;
         if (tq < 0) continue;
       }
       const size_t off = ((((size_t)b * Tq + tq) * p.Ho + yo) * (size_t)p.Wo + xo) * (size_t)p.out_ps + cc;
-      const bool full = (cb + 3 < p.Cout);
+      const bool full = (c8 + 7 < p.Cout);
       if (p.res) {
         const T* rp = reinterpret_cast<const T*>(p.res) + off;
         if (full) {
-          const v4 rv = *reinterpret_cast<const v4*>(rp);
+          float rf[8];
+          unpack8<T>(*reinterpret_cast<const uint4*>(rp), rf);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] += (float)rv[j];
+          for (int j = 0; j < 8; ++j) v[j] += rf[j];
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (cb + j < p.Cout) v[j] += (float)rp[j];
+          for (int j = 0; j < 8; ++j)
+            if (c8 + j < p.Cout) v[j] += (float)rp[j];
         }
       }
       if (p.out_f32) {
         float* o = reinterpret_cast<float*>(p.out) + off;
         if (full) {
           *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (cb + j < p.Cout) o[j] = v[j];
+          for (int j = 0; j < 8; ++j)
+            if (c8 + j < p.Cout) o[j] = v[j];
         }
       } else {
         T* o = reinterpret_cast<T*>(p.out) + off;
         if (full) {
-          v4 ov;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) ov[j] = (T)v[j];
-          *reinterpret_cast<v4*>(o) = ov;
+          *reinterpret_cast<uint4*>(o) = pack8<T>(v);
         } else {
 #pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (cb + j < p.Cout) o[j] = (T)v[j];
+          for (int j = 0; j < 8; ++j)
+            if (c8 + j < p.Cout) o[j] = (T)v[j];
         }
       }
     }
   }
+  CVVAE_PROBE_MARK();
 }
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)

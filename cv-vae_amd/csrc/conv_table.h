@@ -13,10 +13,12 @@
 #define CVVAE_CONV_G2(X) \
   X(3,3,3, 1,1,1, 1,8,32, 1,4,2, 2, 0,false) \
   X(3,3,3, 1,1,1, 1,8,32, 1,4,2, 2, 1,false)
-// 3x3x3 stride 1, BN = 128 as 2 pixel slabs x 4 N-blocks (the pre-K-group configuration; kept for A/B)
+// 3x3x3 stride 1, BN = 128 as 2 pixel slabs x 4 N-blocks: 256-pixel tile, and a 2-frame 512-pixel tile whose halo is
+// 2.66 staged pixels per output pixel instead of 3.98 (every weight record feeds 8 MFMAs, no K-group reduction)
 #define CVVAE_CONV_G3(X) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 0,false) \
-  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,false)
+  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,false) \
+  X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,false)
 // BN = 32 (conv_out: Cout = 3 / 8 / 32) and the fused nearest-2x upsample conv
 #define CVVAE_CONV_G4(X) \
   X(3,3,3, 1,1,1, 1,8,32, 8,1,1, 1, 0,false) \

@@ -54,7 +54,9 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     const long long ntn = cdiv(d->Cout, bn);
     // cost ~ MFMA work issued (padded) + staging work (halo per N tile)
     double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
-    cost *= 1.0 + 0.15 * 256.0 / (double)bn;   // staging share grows as BN shrinks
+    // staging share: halo pixels staged per output pixel, once per N tile (grows as BN shrinks)
+    const double halo = (double)((e.tt - 1) * e.st + e.kt) * ((e.th - 1) * e.sh + e.kh) * ((e.tw - 1) * e.sw + e.kw) / (double)bm;
+    cost *= 1.0 + 0.04 * halo * 256.0 / (double)bn;
     // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
     cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
     if (!best || cost < best_cost) {
@@ -84,9 +86,9 @@ static int check_desc(const cvvae_conv_desc* d) {
   if (d->in_pix_stride < d->Cin || d->in_pix_stride % 8) return CVVAE_EINVAL;
   if (d->out_mode < 0 || d->out_mode > 2) return CVVAE_EINVAL;
   if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride < (d->out_mode == 2 ? d->Cout / 2 : d->Cout))) return CVVAE_EINVAL;
-  if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride % 4)) return CVVAE_EINVAL;
+  if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride % 8)) return CVVAE_EINVAL;  // 16-byte stores
   if (d->out_f32 && d->out_mode != CVVAE_OUT_NDHWC) return CVVAE_EINVAL;
-  if (d->out_mode == CVVAE_OUT_TIME_SHUFFLE && (d->Cout % 8)) return CVVAE_EINVAL;
+  if (d->out_mode == CVVAE_OUT_TIME_SHUFFLE && (d->Cout % 16)) return CVVAE_EINVAL;
   if (d->prologue < 0 || d->prologue > 2) return CVVAE_EINVAL;
   if (d->gn_rows_per_batch < 1) return CVVAE_EINVAL;
   if (d->gn_rows_per_batch > 1 && (d->kT != 1 || d->gn_rows_per_batch != d->Ti)) return CVVAE_EINVAL;
@@ -142,6 +144,8 @@ int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packe
   a.out_mode = d->out_mode;
   a.out_f32 = d->out_f32;
   a.gn_rpb = d->gn_rows_per_batch;
+  a.order = 1;
+  if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
   a.alpha = d->alpha;
   const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
   if (grid <= 0 || grid >= (1LL << 31)) return CVVAE_EUNSUPPORTED;

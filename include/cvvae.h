@@ -75,7 +75,7 @@ typedef struct cvvae_conv_desc {
   int32_t out_mode;           /* CVVAE_OUT_*; TIME_SHUFFLE: channel n*C+c of frame t -> frame 2t+n-1, channel c
                                  (C = Cout/2, frame -1 dropped): 'b (n c) t h w -> b c (t n) h w' then [:, :, 1:] */
   int32_t out_f32;            /* 1: store fp32 (NDHWC only), else dtype */
-  int64_t out_pix_stride;     /* NDHWC modes: elements between pixels of `out` and of `residual` */
+  int64_t out_pix_stride;     /* NDHWC modes: elements between pixels of `out` and of `residual` (multiple of 8) */
   float alpha;                /* out = alpha*acc + bias (+ residual) */
 } cvvae_conv_desc;
 

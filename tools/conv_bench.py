@@ -31,6 +31,16 @@ CASES = {
 }
 
 
+def setenv(f):
+    """f = "FORCE" or "FORCE@ORDER" (CVVAE_CONV_FORCE / CVVAE_CONV_ORDER tuning knobs of libcvvae_hip.so)"""
+    force, _, order = f.partition("@")
+    os.environ["CVVAE_CONV_FORCE"] = force
+    if order:
+        os.environ["CVVAE_CONV_ORDER"] = order
+    else:
+        os.environ.pop("CVVAE_CONV_ORDER", None)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("cases", nargs="*", default=["enc128", "enc256", "up256to512", "c2d128"])
@@ -56,7 +66,7 @@ def main():
         best = {}
         for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
             for f in forces:
-                os.environ["CVVAE_CONV_FORCE"] = f
+                setenv(f)
                 y = ops.conv(x, pw, **kw)
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -71,10 +81,9 @@ def main():
         fl = 2.0 * npix * cout * cin * k[0] * k[1] * k[2]
         for f in forces:
             ms = sorted(best[f])[len(best[f]) // 2]
-            os.environ["CVVAE_CONV_FORCE"] = f
             print(f"{name:12s} force={f or '-':22s} median {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  min {min(best[f]):8.3f} ms "
                   f"({fl / 1e9:.0f} GFLOP)", flush=True)
-    os.environ["CVVAE_CONV_FORCE"] = ""
+    setenv("")
 
 
 if __name__ == "__main__":
