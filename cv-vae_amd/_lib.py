@@ -11,7 +11,7 @@ F16, BF16, F32 = 0, 1, 2
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -46,6 +46,9 @@ PROTOTYPES = {
     "cvvae_pack_weights": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "cvvae_conv_fwd": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_conv_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc)]),
+    "cvvae_conv_gn_slabs": (_i64, [ctypes.POINTER(ConvDesc), _i32]),
+    "cvvae_conv_fwd_gn": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "cvvae_gn_finalize": (_i32, [_vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_gn_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cvvae_gn_stats": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_layernorm": (_i32, [_i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),

@@ -72,6 +72,11 @@ struct ConvArgs {
   int order;     // logical tile order: 1 = (ntile, t, x, y, b) fastest-first, 0 = (ntile, x, y, t, b)
   int gn_rpb;
   float alpha;
+  // fused GroupNorm statistics of the OUTPUT (NDHWC / time-shuffle modes): partial (n, mean, M2) records
+  float* gnp;        // [B][gn_slabs][gn_G][3], or null
+  int gn_slabs;      // records per batch row and group = pixel tiles * WM * KG * (4-channel slots per group)
+  int gn_G;          // groups of the stored tensor
+  int gn_sh;         // log2(channels per group), >= 2
   // tuning probe (tools/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
   unsigned long long* dbg;
   int dbg_block;
@@ -202,6 +207,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     b = mt / p.tiles_t;
   }
   const int t0 = tt_i * TT, y0 = th_i * TH, x0 = tw_i * TW;
+  const int tile_in_b = (tt_i * p.tiles_h + th_i) * p.tiles_w + tw_i;  // pixel-tile index inside batch row b
 
   // ---- staging plan (chunk independent): which stored pixel feeds each of my halo slots
   const int tl = tid & 255;
@@ -449,6 +455,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // the two half-waves first exchange register quads with v_permlane32_swap: for each PAIR of quads (g, g+1) the lower
   // half-wave ends up with channels 16*pair..+7 and the upper one with 16*pair+8..+15 of its pixel -- 8 consecutive
   // channels per lane -> ONE 16-byte store (and one 16-byte residual load) instead of two 8-byte ones.
+  // fused GroupNorm statistics of what is stored (the ROUNDED values, as the reference's GroupNorm sees them): per lane
+  // 4 slots (pr, q) of 4 consecutive channels each: sum, sum of squares; valid-pixel count per pr
+  float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gc[2] = {0.f, 0.f};
 #pragma unroll
   for (int r = 0; r < MREP; ++r) {
     if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
@@ -513,13 +522,68 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
       } else {
         T* o = reinterpret_cast<T*>(p.out) + off;
         if (full) {
-          *reinterpret_cast<uint4*>(o) = pack8<T>(v);
+          const uint4 pk = pack8<T>(v);
+          *reinterpret_cast<uint4*>(o) = pk;
+          if (p.gnp) {
+            float rv[8];
+            unpack8<T>(pk, rv);
+            gc[pr] += 1.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                gs[pr][q] += rv[q * 4 + j];
+                gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
+              }
+          }
         } else {
 #pragma unroll
           for (int j = 0; j < 8; ++j)
             if (c8 + j < p.Cout) o[j] = (T)v[j];
         }
       }
+    }
+  }
+  if (p.gnp) {
+    // wave reduction over the 32 pixels of each half-wave (the two halves hold different channels), then lanes 0 and 32
+    // write one (n, mean, M2) record per 4-channel slot: record index inside its group = the slot's position in the group
+#pragma unroll
+    for (int off = 16; off; off >>= 1) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        gc[pr] += __shfl_xor(gc[pr], off);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          gs[pr][q] += __shfl_xor(gs[pr][q], off);
+          gq[pr][q] += __shfl_xor(gq[pr][q], off);
+        }
+      }
+    }
+    if ((lane_e & 31) == 0) {
+      const int E = 1 << (p.gn_sh - 2);  // 4-channel slots per group
+      const int part = (tile_in_b * WM + wave_m) * KG + kgrp;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          int c = nb * 32 + pr * 16 + (lane_e >> 5) * 8 + q * 4;
+          if (c >= p.Cout) continue;
+          int slab = part;
+          if (p.out_mode == 2) {  // both channel halves land in the same stored channels (different frames): own slabs
+            const int n = c >= C2 ? 1 : 0;
+            c -= n * C2;
+            slab = part * 2 + n;
+          }
+          const int g = c >> p.gn_sh, sub = (c >> 2) & (E - 1);
+          const float n = gc[pr] * 4.f;
+          const float mean = n > 0.f ? gs[pr][q] / n : 0.f;
+          float m2 = gq[pr][q] - gs[pr][q] * mean;
+          m2 = m2 > 0.f ? m2 : 0.f;
+          float* o = p.gnp + (((size_t)b * p.gn_slabs + (size_t)(slab * E + sub)) * p.gn_G + g) * 3;
+          o[0] = n;
+          o[1] = mean;
+          o[2] = m2;
+        }
     }
   }
   CVVAE_PROBE_MARK();

@@ -108,10 +108,38 @@ const char* cvvae_conv_kernel_name(const cvvae_conv_desc* d) {
   return e ? instance_name(const_cast<Instance*>(e), d->dtype) : nullptr;
 }
 
+// channels per group of the tensor the conv stores, as a shift; -1 when (d, groups) cannot carry fused statistics
+static int gn_shift_of(const cvvae_conv_desc* d, int groups) {
+  if (groups <= 0 || d->out_mode == CVVAE_OUT_NCDHW || d->out_f32 || (d->Cout % 8)) return -1;
+  const int cst = d->out_mode == CVVAE_OUT_TIME_SHUFFLE ? d->Cout / 2 : d->Cout;
+  if (cst % groups) return -1;
+  const int cpg = cst / groups;
+  if (cpg < 4 || (cpg & (cpg - 1))) return -1;
+  int sh = 0;
+  while ((1 << sh) < cpg) ++sh;
+  return sh;
+}
+
+int64_t cvvae_conv_gn_slabs(const cvvae_conv_desc* d, int32_t groups) {
+  if (check_desc(d) != CVVAE_OK) return CVVAE_EINVAL;
+  const int sh = gn_shift_of(d, groups);
+  const Instance* e = select_instance(d);
+  if (sh < 0 || !e) return CVVAE_EUNSUPPORTED;
+  const long long tiles = cdiv(d->To, e->tt) * cdiv(d->Ho, e->th) * cdiv(d->Wo, e->tw);
+  return tiles * e->wm * e->kg * (d->out_mode == CVVAE_OUT_TIME_SHUFFLE ? 2 : 1) * (1LL << (sh - 2));
+}
+
 int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                    const float* gn_scale, const float* gn_shift, void* out, void* stream) {
+  return cvvae_conv_fwd_gn(d, in, w_packed, bias, residual, gn_scale, gn_shift, out, 0, nullptr, stream);
+}
+
+int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+                      const float* gn_scale, const float* gn_shift, void* out, int32_t out_groups, float* out_partials,
+                      void* stream) {
   int rc = check_desc(d);
   if (rc != CVVAE_OK) return rc;
+  if ((out_groups != 0) != (out_partials != nullptr)) return CVVAE_EINVAL;
   if (!in || !w_packed || !bias || !out) return CVVAE_EINVAL;
   if (d->prologue != CVVAE_PRO_NONE && (!gn_scale || !gn_shift)) return CVVAE_EINVAL;
   if (residual && d->out_mode != CVVAE_OUT_NDHWC) return CVVAE_EINVAL;
@@ -147,6 +175,15 @@ int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packe
   a.order = 1;
   if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
   a.alpha = d->alpha;
+  if (out_partials) {
+    const int sh = gn_shift_of(d, out_groups);
+    if (sh < 0) return CVVAE_EUNSUPPORTED;
+    a.gnp = out_partials;
+    a.gn_G = out_groups;
+    a.gn_sh = sh;
+    a.gn_slabs = (int)((long long)a.tiles_t * a.tiles_h * a.tiles_w * e->wm * e->kg *
+                       (d->out_mode == CVVAE_OUT_TIME_SHUFFLE ? 2 : 1) * (1LL << (sh - 2)));
+  }
   const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
   if (grid <= 0 || grid >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
   return e->fn[d->dtype](a, (int)grid, (hipStream_t)stream);

@@ -172,6 +172,47 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
   }
 }
 
+// Finalize for the statistics fused into the conv epilogue: grid (G, rows); the block merges the `slabs` records of
+// its (row, group) -- ws[(row*slabs + s)*G + g] = (n, mean, M2) -- in a fixed order (thread-strided, then a Chan tree)
+// and writes the affine table of the group's channels.
+__global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __restrict__ ws, long long slabs, int G, int C,
+                                                                float eps, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ scale,
+                                                                float* __restrict__ shift) {
+  const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  WStat acc = {0.f, 0.f, 0.f};
+  for (long long s = tid; s < slabs; s += 256) {
+    const float* o = ws + (((long long)row * slabs + s) * G + g) * 3;
+    WStat q = {o[0], o[1], o[2]};
+    chan_merge(acc, q);
+  }
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    WStat q;
+    q.n = __shfl_xor(acc.n, off);
+    q.mean = __shfl_xor(acc.mean, off);
+    q.m2 = __shfl_xor(acc.m2, off);
+    // both partners must end with the same value: merge in a fixed (lower lane first) order
+    WStat lo = (tid & off) ? q : acc, hi = (tid & off) ? acc : q;
+    chan_merge(lo, hi);
+    acc = lo;
+  }
+  __shared__ WStat sh[4];
+  if ((tid & 63) == 0) sh[tid >> 6] = acc;
+  __syncthreads();
+  WStat t = sh[0];
+  chan_merge(t, sh[1]);
+  chan_merge(t, sh[2]);
+  chan_merge(t, sh[3]);
+  const float mean = t.mean, rstd = rsqrtf(t.m2 / t.n + eps);
+  const int cpg = C / G;
+  for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
+    const float sc = gamma[c] * rstd;
+    scale[(long long)row * C + c] = sc;
+    shift[(long long)row * C + c] = beta[c] - mean * sc;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LayerNorm over C per pixel: one wave per pixel, C multiple of 8, C <= 64*8*4
 // ---------------------------------------------------------------------------------------------------------
@@ -486,6 +527,15 @@ int cvvae_gn_stats(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_
     return CVVAE_EINVAL;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(rows), dim3(256), 0, s, (const float*)workspace, nsplit, groups, C, eps, gamma,
                      beta, scale, shift);
+  CHECK_LAUNCH();
+}
+
+int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_t C, int32_t groups, float eps,
+                      const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+  if (!partials || !gamma || !beta || !scale || !shift || rows <= 0 || slabs <= 0 || groups <= 0 || C <= 0 || C % groups)
+    return CVVAE_EINVAL;
+  hipLaunchKernelGGL(gn_finalize_slabs_kernel, dim3(groups, rows), dim3(256), 0, (hipStream_t)stream, partials, (long long)slabs,
+                     groups, C, eps, gamma, beta, scale, shift);
   CHECK_LAUNCH();
 }
 

@@ -63,22 +63,40 @@ class WeightCache:
 
 
 def _flat(x: torch.Tensor) -> torch.Tensor:
-    """[B,T,H,W,C] -> [1,1,1,B*T*H*W,C] view for the 1-D pixel tiles of the 1x1x1 conv."""
-    return x.view(1, 1, 1, -1, x.shape[-1])
+    """[B,T,H,W,C] -> [B,1,1,T*H*W,C] view for the 1-D pixel tiles of the 1x1x1 conv (batch rows kept: GroupNorm
+    statistics are per sample)."""
+    return x.view(x.shape[0], 1, 1, -1, x.shape[-1])
 
 
 def conv1x1(wc: WeightCache, x: torch.Tensor, pre: str, residual: Optional[torch.Tensor] = None, prologue=L.PRO_NONE,
-            gn=None) -> torch.Tensor:
+            gn=None, gn_out: int = 0):
+    """1x1(x1) conv / nn.Linear on the flattened pixels of every sample.  gn_out: also return the output's GroupNorm
+    partials (per sample)."""
     pw = wc.conv(pre, (1, 1, 1))
-    y = ops.conv(_flat(x), pw, prologue=prologue, gn=gn, residual=_flat(residual) if residual is not None else None)
+    y = ops.conv(_flat(x), pw, prologue=prologue, gn=gn, residual=_flat(residual) if residual is not None else None,
+                 gn_out=gn_out)
+    if gn_out:
+        y, part = y
+        return y.view(*x.shape[:-1], pw.cout), part
     return y.view(*x.shape[:-1], pw.cout)
+
+
+G32 = 32  # every GroupNorm of both families has 32 groups
+
+
+def _norm(wc: WeightCache, x: torch.Tensor, part, pre: str, eps: float):
+    """(scale, shift) of the 5-D GroupNorm `pre` applied to x: from the statistics its producer's epilogue emitted when
+    available, else by a statistics pass over x."""
+    if part is not None:
+        return ops.gn_finalize(part, *wc.norm(pre), eps)
+    return ops.gn_stats(x, *wc.norm(pre), eps)
 
 
 # --------------------------------------------------------------------------------------------------------
 # single-head spatial self-attention per frame (both families)
 # --------------------------------------------------------------------------------------------------------
 def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: str, v: str, proj: str, eps: float,
-                      residual: bool) -> torch.Tensor:
+                      residual: bool, gn_out: int = 0):
     """sd3: AttentionWithExtraDim (vae_blocks3d_sd3.py:119-147) over diffusers Attention.
     vae3d: MemoryEfficientAttnBlock.attention + proj_out (vae_models.py:500-537).
     Per frame: GN(32) over (C/32, H*W) -> q,k,v (1x1) -> softmax(q k^T / sqrt(C)) v -> proj (+ x)."""
@@ -100,31 +118,34 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
         p = ops.softmax_rows(s.view(N, npad), N, x.dtype)                                      # [N, npad]
         vp = ops.pack_weight(vt[f], None, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
         ops.conv(p.view(1, 1, 1, N, npad), vp, out=o[f].view(1, 1, 1, N, C))
-    return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None)
+    return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 
 # --------------------------------------------------------------------------------------------------------
 # vae3d_sd3 family
 # --------------------------------------------------------------------------------------------------------
-def sd3_resnet(wc: WeightCache, x: torch.Tensor, pre: str, causal: bool) -> torch.Tensor:
+def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want_stats: bool = True):
     """ResnetBlock3D.forward, vae_blocks3d_sd3.py:517-569: GN(eps 1e-6)+SiLU fused into conv1 (replicate pad, causal
-    T(2,0) or (1,1)) and into conv2 (per-frame 3x3, zero pad); 1x1 shortcut; residual add in conv2's epilogue."""
-    g1 = ops.gn_stats(x, *wc.norm(pre + ".norm1"), 1e-6)
-    h = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
-                 prologue=L.PRO_GN_SILU, gn=g1)
-    g2 = ops.gn_stats(h, *wc.norm(pre + ".norm2"), 1e-6)
+    T(2,0) or (1,1)) and into conv2 (per-frame 3x3, zero pad); 1x1 shortcut; residual add in conv2's epilogue.
+    xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
+    g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
+    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+                     prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32)
+    g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     sc = conv1x1(wc, x, pre + ".conv_shortcut") if wc.has(pre + ".conv_shortcut.weight") else x
-    return ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
-                    residual=sc)
+    y = ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
+                 residual=sc, gn_out=G32 if want_stats else 0)
+    return y if want_stats else (y, None)
 
 
-def sd3_mid(wc: WeightCache, x: torch.Tensor, pre: str, causal: bool, attention: bool) -> torch.Tensor:
+def sd3_mid(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, attention: bool):
     """UNetMidBlock3D.forward, vae_blocks3d_sd3.py:847-856."""
-    x = sd3_resnet(wc, x, pre + ".resnets.0", causal)
+    x, xp = sd3_resnet(wc, x, xp, pre + ".resnets.0", causal, want_stats=not attention)
     if attention:
         a = pre + ".attentions.0"
-        x = spatial_attention(wc, x, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True)
-    return sd3_resnet(wc, x, pre + ".resnets.1", causal)
+        x, xp = spatial_attention(wc, x, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True,
+                                  gn_out=G32)
+    return sd3_resnet(wc, x, xp, pre + ".resnets.1", causal)
 
 
 def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
@@ -133,16 +154,17 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
     h = ops.ncdhw_to_ndhwc(x, 16, dtype)
-    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP)
+    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+                     gn_out=G32)
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"]):
-            h = sd3_resnet(wc, h, f"down_blocks.{i}.resnets.{j}", causal)
+            h, hp = sd3_resnet(wc, h, hp, f"down_blocks.{i}.resnets.{j}", causal)
         if i != len(boc) - 1:  # Downsample3D vae_blocks3d_sd3.py:224-239; time stride on even blocks (:115)
             st = (2, 2, 2) if i % 2 == 0 else (1, 2, 2)
-            h = ops.conv(h, wc.conv(f"down_blocks.{i}.downsamplers.0.conv", (3, 3, 3)), stride=st,
-                         pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP)
-    h = sd3_mid(wc, h, "mid_block", causal, cfg["mid_block_add_attention"])
-    g = ops.gn_stats(h, *wc.norm("conv_norm_out"), 1e-6)
+            h, hp = ops.conv(h, wc.conv(f"down_blocks.{i}.downsamplers.0.conv", (3, 3, 3)), stride=st,
+                             pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP, gn_out=G32)
+    h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"])
+    g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
     return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                     prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
 
@@ -155,16 +177,18 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     pad = PC if causal else P1
     zin = z.shape[1]
     h = ops.ncdhw_to_ndhwc(z, ops.round_up(zin, 16), dtype)
-    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP)
-    h = sd3_mid(wc, h, "mid_block", causal, cfg["mid_block_add_attention"])
+    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
+                     gn_out=G32)
+    h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"])
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"] + 1):
-            h = sd3_resnet(wc, h, f"up_blocks.{i}.resnets.{j}", causal)
+            h, hp = sd3_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}", causal)
         if i != len(boc) - 1:  # Upsample3D vae_blocks3d_sd3.py:314-364; up_time on even blocks (vae_models3d_sd3.py:289)
             up_time = i % 2 == 0
-            h = ops.conv(h, wc.conv(f"up_blocks.{i}.upsamplers.0.conv", (3, 3, 3)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
-                         upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC)
-    g = ops.gn_stats(h, *wc.norm("conv_norm_out"), 1e-6)
+            h, hp = ops.conv(h, wc.conv(f"up_blocks.{i}.upsamplers.0.conv", (3, 3, 3)), pad=pad, pad_mode_t=REP,
+                             pad_mode_hw=REP, upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC,
+                             gn_out=G32)
+    g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
     return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
 
@@ -177,15 +201,18 @@ def _v3_pad(causal: bool):
     return (PC, REP, ZERO) if causal else (P1, ZERO, ZERO)
 
 
-def v3_resnet(wc: WeightCache, x: torch.Tensor, pre: str, causal: bool) -> torch.Tensor:
-    """ResnetBlock3D.forward, vae_models.py:390-410 (GN eps 1e-5, swish, nin_shortcut 1x1x1)."""
+def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want_stats: bool = True):
+    """ResnetBlock3D.forward, vae_models.py:390-410 (GN eps 1e-5, swish, nin_shortcut 1x1x1).
+    xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
     pad, mt, mhw = _v3_pad(causal)
-    g1 = ops.gn_stats(x, *wc.norm(pre + ".norm1"), 1e-5)
-    h = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g1)
-    g2 = ops.gn_stats(h, *wc.norm(pre + ".norm2"), 1e-5)
+    g1 = _norm(wc, x, xp, pre + ".norm1", 1e-5)
+    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU,
+                     gn=g1, gn_out=G32)
+    g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-5)
     sc = conv1x1(wc, x, pre + ".nin_shortcut") if wc.has(pre + ".nin_shortcut.weight") else x
-    return ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
-                    residual=sc)
+    y = ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
+                 residual=sc, gn_out=G32 if want_stats else 0)
+    return y if want_stats else (y, None)
 
 
 def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
@@ -195,33 +222,34 @@ def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
     h = ops.ncdhw_to_ndhwc(x, 16, dtype)
-    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
+    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, gn_out=G32)
     for lvl in range(nlev):
         for j in range(cfg["num_res_blocks"]):
-            h = v3_resnet(wc, h, f"down.{lvl}.block.{j}", causal)
+            h, hp = v3_resnet(wc, h, hp, f"down.{lvl}.block.{j}", causal)
         if lvl != nlev - 1:  # Downsample3D vae_models.py:251-263: zero pad right/bottom, replicate T front 2
             st = (2, 2, 2) if lvl % 2 == 0 else (1, 2, 2)
-            h = ops.conv(h, wc.conv(f"down.{lvl}.downsample.conv", (3, 3, 3)), stride=st, pad=((2, 0), (0, 1), (0, 1)),
-                         pad_mode_t=REP, pad_mode_hw=ZERO)
-    h = v3_resnet(wc, h, "mid.block_1", causal)
+            h, hp = ops.conv(h, wc.conv(f"down.{lvl}.downsample.conv", (3, 3, 3)), stride=st, pad=((2, 0), (0, 1), (0, 1)),
+                             pad_mode_t=REP, pad_mode_hw=ZERO, gn_out=G32)
+    h, _ = v3_resnet(wc, h, hp, "mid.block_1", causal, want_stats=False)
     a = "mid.attn_1"
-    h = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True)
-    h = v3_resnet(wc, h, "mid.block_2", causal)
-    g = ops.gn_stats(h, *wc.norm("norm_out"), 1e-5)
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True, gn_out=G32)
+    h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
+    g = _norm(wc, h, hp, "norm_out", 1e-5)
     return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
 
 
-def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str) -> torch.Tensor:
+def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str):
     """MemoryEfficientAttnVideoBlock.forward, vae_models.py:619-629: spatial attention without residual, then over T
-    per pixel: LayerNorm -> q_t,k_t,v_t -> attention -> proj_out_t; one residual.  Stays NDHWC throughout."""
+    per pixel: LayerNorm -> q_t,k_t,v_t -> attention -> proj_out_t; one residual.  Stays NDHWC throughout.
+    Returns (out, GroupNorm partials of out)."""
     h = spatial_attention(wc, x, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, False)
     n = ops.layernorm(h, *wc.norm(a + ".norm_t"), 1e-5)
     q = conv1x1(wc, n, a + ".q_t")
     k = conv1x1(wc, n, a + ".k_t")
     v = conv1x1(wc, n, a + ".v_t")
     o = ops.temporal_attention(q, k, v)
-    return conv1x1(wc, o, a + ".proj_out_t", residual=x)
+    return conv1x1(wc, o, a + ".proj_out_t", residual=x, gn_out=G32)
 
 
 def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
@@ -232,17 +260,18 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     nlev = len(cfg["ch_mult"])
     zin = z.shape[1]
     h = ops.ncdhw_to_ndhwc(z, ops.round_up(zin, 16), dtype)
-    h = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
-    h = v3_resnet(wc, h, "mid.block_1", causal)
-    h = v3_attn_spatial_temporal(wc, h, "mid.attn_1")
-    h = v3_resnet(wc, h, "mid.block_2", causal)
+    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw,
+                     gn_out=G32)
+    h, _ = v3_resnet(wc, h, hp, "mid.block_1", causal, want_stats=False)
+    h, hp = v3_attn_spatial_temporal(wc, h, "mid.attn_1")
+    h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
     for lvl in reversed(range(nlev)):
         for j in range(cfg["num_res_blocks"] + 1):
-            h = v3_resnet(wc, h, f"up.{lvl}.block.{j}", causal)
+            h, hp = v3_resnet(wc, h, hp, f"up.{lvl}.block.{j}", causal)
         if lvl != 0:  # Upsample3D vae_models.py:214-235 (built non-causal, :936): zero pad W,H, replicate T (1,1)
             up_time = lvl % 2 == 1
-            h = ops.conv(h, wc.conv(f"up.{lvl}.upsample.conv", (3, 3, 3)), pad=P1, pad_mode_t=REP, pad_mode_hw=ZERO,
-                         upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC)
-    g = ops.gn_stats(h, *wc.norm("norm_out"), 1e-5)
+            h, hp = ops.conv(h, wc.conv(f"up.{lvl}.upsample.conv", (3, 3, 3)), pad=P1, pad_mode_t=REP, pad_mode_hw=ZERO,
+                             upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC, gn_out=G32)
+    g = _norm(wc, h, hp, "norm_out", 1e-5)
     return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)

@@ -76,12 +76,23 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_)
 
 
+@dataclass
+class GNPartials:
+    """per-tile (n, mean, M2) records of a conv output, written by the conv's epilogue (cvvae_conv_fwd_gn)"""
+    buf: torch.Tensor   # fp32 [rows, slabs, groups, 3]
+    rows: int
+    slabs: int
+    C: int
+    groups: int
+
+
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
          pad_mode_hw=L.PAD_ZERO, prologue=L.PRO_NONE, gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          gn_per_frame=False, residual: Optional[torch.Tensor] = None, upsample2x=False, out_mode=L.OUT_NDHWC,
-         out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None) -> torch.Tensor:
+         out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None, gn_out: int = 0):
     """x: [B,T,H,W,Cs] with Cs >= pw.cin.  pad = ((t_front,t_back),(h_front,h_back),(w_front,w_back)).
-    Returns [B,To,Ho,Wo,Cout(_pad)] (NDHWC), [B,2To-1,Ho,Wo,Cout/2] (TIME_SHUFFLE) or [B,Cout,To,Ho,Wo] (NCDHW)."""
+    Returns [B,To,Ho,Wo,Cout(_pad)] (NDHWC), [B,2To-1,Ho,Wo,Cout/2] (TIME_SHUFFLE) or [B,Cout,To,Ho,Wo] (NCDHW).
+    gn_out = G > 0: also returns the GNPartials of the stored tensor for a following G-group GroupNorm (gn_finalize)."""
     lib = L.load()
     _need_gpu(x)
     assert x.dim() == 5 and x.is_contiguous()
@@ -131,17 +142,37 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     if prologue != L.PRO_NONE:
         gsc, gsh = gn
         assert gsc.dtype == torch.float32 and gsc.shape[-1] == pw.cin and gsc.is_contiguous() and gsh.is_contiguous()
+    part = None
+    if gn_out:
+        slabs = lib.cvvae_conv_gn_slabs(d, gn_out)
+        if slabs <= 0:
+            L.check(int(slabs), "cvvae_conv_gn_slabs")
+        cst = cout // 2 if out_mode == L.OUT_TIME_SHUFFLE else cout
+        part = GNPartials(torch.empty((B, slabs, gn_out, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
+
     def launch():
-        L.check(lib.cvvae_conv_fwd(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),
-                                   residual.data_ptr() if residual is not None else None,
-                                   gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
-                                   out.data_ptr(), _stream()), "cvvae_conv_fwd")
+        L.check(lib.cvvae_conv_fwd_gn(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),
+                                      residual.data_ptr() if residual is not None else None,
+                                      gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
+                                      out.data_ptr(), gn_out, part.buf.data_ptr() if part is not None else None, _stream()),
+                "cvvae_conv_fwd_gn")
 
     if PROFILE is None:
         launch()
     else:
         PROFILE(d, pw, launch)
-    return out
+    return (out, part) if gn_out else out
+
+
+def gn_finalize(part: GNPartials, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
+    """merge the conv-epilogue statistics into the (scale, shift) fp32 tables [rows, C] the next conv's prologue consumes"""
+    lib = L.load()
+    assert gamma.dtype == torch.float32 and gamma.numel() == part.C and beta.numel() == part.C
+    scale = torch.empty((part.rows, part.C), dtype=torch.float32, device=part.buf.device)
+    shift = torch.empty((part.rows, part.C), dtype=torch.float32, device=part.buf.device)
+    L.check(lib.cvvae_gn_finalize(part.buf.data_ptr(), part.rows, part.slabs, part.C, part.groups, eps, gamma.data_ptr(),
+                                  beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()), "cvvae_gn_finalize")
+    return scale, shift
 
 
 # Optional launch observer used by bench.py's roofline pass: called as PROFILE(desc, packed, launch) where launch()

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 1
+#define CVVAE_ABI_VERSION 2
 
 enum { CVVAE_F16 = 0, CVVAE_BF16 = 1 };                       /* cvvae dtype */
 enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
@@ -94,6 +94,23 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
 
 int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                    const void* residual, const float* gn_scale, const float* gn_shift, void* out, void* stream);
+
+/*
+ * The same convolution that ALSO emits GroupNorm statistics of the tensor it stores (NDHWC / TIME_SHUFFLE outputs of
+ * dtype, Cout % 8 == 0), so that the GroupNorm of the NEXT layer never re-reads the activation: norm2 after conv1, norm1
+ * of the next ResnetBlock3D after conv2 (+residual), conv_norm_out -- models/vae_blocks3d_sd3.py:523,547,
+ * models/vae_models3d_sd3.py:204,382, models/vae_models.py:395,402,820,999 (5-D GroupNorm: statistics per sample).
+ * out_partials: [B][slabs][out_groups][3] fp32 records (n, mean, M2) of the ROUNDED stored values, one per pixel tile /
+ * wave slab / 4-channel slot, slabs = cvvae_conv_gn_slabs(d, out_groups); every record is written exactly once (no
+ * atomics: results are bit-reproducible).  cvvae_gn_finalize merges them (Chan, fixed order) into the affine table.
+ * out_groups = 0 and out_partials = NULL: identical to cvvae_conv_fwd.
+ */
+int64_t cvvae_conv_gn_slabs(const cvvae_conv_desc* d, int32_t out_groups);
+int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
+                      const void* residual, const float* gn_scale, const float* gn_shift, void* out, int32_t out_groups,
+                      float* out_partials, void* stream);
+int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_t C, int32_t groups, float eps,
+                      const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
 /*
  * GroupNorm statistics -> per-(row, channel) affine table consumed by the conv prologue.

@@ -48,7 +48,7 @@ def test_argument_checks_without_gpu():
     assert lib.cvvae_conv_kernel_name(d).decode().startswith("conv_k333_s111")
     d.kT = 5
     assert lib.cvvae_conv_fwd(d, 1, 1, 1, None, None, None, 1, None) == -2  # unsupported kernel size
-    assert lib.cvvae_packed_weight_bytes(128, 128, 27) == 128 * 128 * 27 * 2 + 8192
+    assert lib.cvvae_packed_weight_bytes(128, 128, 27) == 128 * 128 * 27 * 2 + 16384
     assert lib.cvvae_gn_stats(1, None, 1, 1, 128, 128, 32, 1e-6, None, None, None, None, None, None) == -1
 
 

@@ -181,6 +181,49 @@ def test_conv_small_cin_padded(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", ["c333_128", "c133_256_res", "ups_shuffle_512", "c111_512_b2", "down_222", "c333_128_t2"])
+def test_conv_fused_gn_stats(dtype, case):
+    """cvvae_conv_fwd_gn + cvvae_gn_finalize (statistics from the conv epilogue) must equal a statistics pass over the
+    stored output (cvvae_gn_stats) and torch's group_norm moments of it: every record written once, all layouts."""
+    ops, L = _ops()
+    cfg = {
+        # Cin, Cout, k, stride, pad, shape(B,T,H,W), ups, out_mode, residual
+        "c333_128": (128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), (1, 5, 24, 40), False, L.OUT_NDHWC, False),
+        "c333_128_t2": (128, 128, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), (2, 17, 16, 32), False, L.OUT_NDHWC, False),
+        "c133_256_res": (256, 256, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), (1, 3, 17, 33), False, L.OUT_NDHWC, True),
+        "ups_shuffle_512": (256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), (1, 3, 8, 16), True, L.OUT_TIME_SHUFFLE, False),
+        "c111_512_b2": (256, 512, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), (2, 1, 1, 300), False, L.OUT_NDHWC, True),
+        "down_222": (128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (1, 1), (1, 1)), (1, 5, 24, 40), False, L.OUT_NDHWC, False),
+    }[case]
+    Cin, Cout, k, stride, pad, (B, T, H, W), ups, out_mode, residual = cfg
+    x = to_ndhwc(rnd((B, Cin, T, H, W), dtype, 1, 1.0)).to(DEV)
+    w = rnd((Cout, Cin) + k, dtype, 2, 1.0 / (Cin * k[0] * k[1] * k[2]) ** 0.5)
+    bias = rnd((Cout,), torch.float32, 3, 0.5)  # a non-zero mean makes the (n, mean, M2) merge matter
+    pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k)
+    y0 = ops.conv(x, pw, stride=stride, pad=pad, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=ups, out_mode=out_mode)
+    res = rnd(tuple(y0.shape), dtype, 4, 1.0).to(DEV) if residual else None
+    y, part = ops.conv(x, pw, stride=stride, pad=pad, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=ups, out_mode=out_mode,
+                       residual=res, gn_out=32)
+    C = y.shape[-1]
+    gamma = (1.0 + rnd((C,), torch.float32, 5, 0.1)).to(DEV)
+    beta = rnd((C,), torch.float32, 6, 0.1).to(DEV)
+    sc_f, sh_f = ops.gn_finalize(part, gamma, beta, 1e-6)
+    sc_s, sh_s = ops.gn_stats(y, gamma, beta, 1e-6)
+    torch.cuda.synchronize()
+    yr = to_ncdhw(y.float().cpu())
+    mean = yr.reshape(B, 32, -1).mean(-1)
+    var = yr.reshape(B, 32, -1).var(-1, unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    cpg = C // 32
+    sc_ref = gamma.cpu().reshape(1, 32, cpg) * rstd.reshape(B, 32, 1)
+    sh_ref = beta.cpu().reshape(1, 32, cpg) - mean.reshape(B, 32, 1) * sc_ref
+    for got_sc, got_sh, what in ((sc_f, sh_f, "fused"), (sc_s, sh_s, "pass")):
+        e1 = (got_sc.cpu().reshape(B, 32, cpg) - sc_ref).abs().max().item() / sc_ref.abs().max().item()
+        e2 = (got_sh.cpu().reshape(B, 32, cpg) - sh_ref).abs().max().item() / max(sh_ref.abs().max().item(), 1.0)
+        assert e1 < 2e-5 and e2 < 2e-5, (what, e1, e2)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("per_frame", [False, True])
 def test_gn_stats(dtype, per_frame):
     ops, L = _ops()
