@@ -18,11 +18,13 @@
 #define CVVAE_CONV_G3(X) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 0,false) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,false) \
-  X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,false)
+  X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,false) \
+  X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 0,false)
 // BN = 32 (conv_out: Cout = 3 / 8 / 32) and the fused nearest-2x upsample conv
 #define CVVAE_CONV_G4(X) \
   X(3,3,3, 1,1,1, 1,8,32, 8,1,1, 1, 0,false) \
   X(3,3,3, 1,1,1, 1,8,32, 8,1,1, 1, 1,false) \
+  X(3,3,3, 1,1,1, 2,8,32, 8,1,1, 1, 1,false) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,true)
 // strided 3x3x3 (encoder downsamplers): 64-pixel tile, BN = 256
 #define CVVAE_CONV_G5(X) \
@@ -39,7 +41,8 @@
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,false) \
   X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 4, 1,false) \
   X(1,3,3, 1,1,1, 1,8,32, 1,4,2, 4, 1,false) \
-  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,false)
+  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,false) \
+  X(1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 1,false)
 // 1x1x1 (shortcuts, attention projections and the QK^T / PV products), K-chunk 128 channels, 1-D pixel tile
 #define CVVAE_CONV_G8(X) \
   X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 8, 0,false) \
