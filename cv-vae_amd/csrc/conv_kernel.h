@@ -69,6 +69,10 @@ struct ConvArgs {
   int nchunks;   // Cin / CK
   int nblk32;    // ceil(Cout/32): number of packed 32-channel weight blocks
   int out_mode, out_f32;
+  // UPS == 2 (nearest-2x upsample folded into four 3x2x2 phase convolutions over the stored input): To/Ho/Wo are the
+  // per-phase output dims (= Ti/Hi/Wi); output pixel (y, x) of phase (py, px) is stored at (2y+py, 2x+px) of a
+  // 2Ho x 2Wo frame; phase weights are w + phase * w_phase_stride (elements)
+  long long w_phase_stride;
   int order;     // logical tile order: 1 = (ntile, t, x, y, b) fastest-first, 0 = (ntile, x, y, t, b)
   int gn_rpb;
   float alpha;
@@ -159,7 +163,7 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
 }
 
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, bool UPS>
+          int PRO, int UPS>
 __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB>;
   using v8 = typename Tr<T>::v8;
@@ -190,6 +194,12 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // the same XCD, so the K-chunk passes over the halo stay inside that XCD's 4 MiB L2 instead of thrashing it.
   const int ntile = logical % p.ntiles_n;
   int mt = logical / p.ntiles_n;
+  int phase = 0;  // UPS == 2: the four (py, px) phases of a pixel tile are consecutive logical tiles (their halos coincide)
+  if (UPS == 2) {
+    phase = mt & 3;
+    mt >>= 2;
+  }
+  const int py = phase >> 1, px = phase & 1;
   int tw_i, th_i, tt_i, b;
   if (p.order == 1) {
     tt_i = mt % p.tiles_t;
@@ -227,9 +237,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
       const int hx = rem - hy * G::FW;
       bool zero = false;
       int ts = map_coord(t0 * ST + f - p.pt, p.Tl, p.mode_t, zero);
-      int ys = map_coord(y0 * SH + hy - p.ph, p.Hl, p.mode_hw, zero);
-      int xs = map_coord(x0 * SW + hx - p.pw, p.Wl, p.mode_hw, zero);
-      if (UPS) {
+      // UPS == 2: phase 0 along an axis reads rows {y-1, y} (front pad 1), phase 1 reads {y, y+1} (front pad 0)
+      int ys = map_coord(y0 * SH + hy - (UPS == 2 ? p.ph - py : p.ph), p.Hl, p.mode_hw, zero);
+      int xs = map_coord(x0 * SW + hx - (UPS == 2 ? p.pw - px : p.pw), p.Wl, p.mode_hw, zero);
+      if (UPS == 1) {
         ys >>= 1;
         xs >>= 1;
       }
@@ -315,8 +326,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16 +
                          kgrp * (KSUB / KG) * 32);
   }
-  const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) +
-                kgrp * (STEPS_W * 512) + lane * 8;
+  const T* wq = reinterpret_cast<const T*>(p.w) + (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
+                (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512) + lane * 8;
   v8 wf[PF];
 #pragma unroll
   for (int i = 0; i < PF; ++i) wf[i] = *reinterpret_cast<const v8*>(wq + i * 512);
@@ -494,7 +505,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         Tq = 2 * p.To - 1;
         if (tq < 0) continue;
       }
-      const size_t off = ((((size_t)b * Tq + tq) * p.Ho + yo) * (size_t)p.Wo + xo) * (size_t)p.out_ps + cc;
+      const size_t off = UPS == 2 ? ((((size_t)b * Tq + tq) * (2 * p.Ho) + (2 * yo + py)) * (size_t)(2 * p.Wo) + (2 * xo + px)) *
+                                        (size_t)p.out_ps + cc
+                                  : ((((size_t)b * Tq + tq) * p.Ho + yo) * (size_t)p.Wo + xo) * (size_t)p.out_ps + cc;
       const bool full = (c8 + 7 < p.Cout);
       if (p.res) {
         const T* rp = reinterpret_cast<const T*>(p.res) + off;
@@ -561,7 +574,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     }
     if ((lane_e & 31) == 0) {
       const int E = 1 << (p.gn_sh - 2);  // 4-channel slots per group
-      const int part = (tile_in_b * WM + wave_m) * KG + kgrp;
+      const int part = ((UPS == 2 ? tile_in_b * 4 + phase : tile_in_b) * WM + wave_m) * KG + kgrp;
 #pragma unroll
       for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
@@ -591,7 +604,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, bool UPS>
+          int PRO, int UPS>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
   hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS>), dim3(grid), dim3(512),
                      0, s, a);

@@ -25,7 +25,7 @@ struct Instance {
 };
 
 #define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,(UPS) ? 1 : 0, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
     &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>}, ""},
 
@@ -46,11 +46,16 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     const Instance& e = g_table[i];
     if (pass == 0 && ft &&
         (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) continue;
-    if (e.kt != d->kT || e.kh != d->kH || e.kw != d->kW || e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
-    if (e.pro != d->prologue || e.ups != (d->upsample2x ? 1 : 0)) continue;
+    // the folded upsample (upsample2x == 2) runs 3x2x2 phase kernels; everything else matches the descriptor's taps
+    const int fold = d->upsample2x == 2;
+    if (e.kt != d->kT || e.kh != (fold ? 2 : d->kH) || e.kw != (fold ? 2 : d->kW)) continue;
+    if (e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
+    if (e.pro != d->prologue || e.ups != d->upsample2x) continue;
     if (d->Cin % (16 * e.ksub)) continue;  // the instance's K-chunk must divide the consumed channels
     const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
-    const long long tiles = cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
+    // per-phase output grid for the folded upsample (4 phases of Ho/2 x Wo/2), the output grid otherwise
+    const long long tiles = fold ? cdiv(d->To, e.tt) * cdiv(d->Ho / 2, e.th) * cdiv(d->Wo / 2, e.tw) * d->B * 4
+                                 : cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
     const long long ntn = cdiv(d->Cout, bn);
     // cost ~ MFMA work issued (padded) + staging work (halo per N tile)
     double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
@@ -90,6 +95,10 @@ static int check_desc(const cvvae_conv_desc* d) {
   if (d->out_f32 && d->out_mode != CVVAE_OUT_NDHWC) return CVVAE_EINVAL;
   if (d->out_mode == CVVAE_OUT_TIME_SHUFFLE && (d->Cout % 16)) return CVVAE_EINVAL;
   if (d->prologue < 0 || d->prologue > 2) return CVVAE_EINVAL;
+  if (d->upsample2x < 0 || d->upsample2x > 2) return CVVAE_EINVAL;
+  if (d->upsample2x == 2 && (d->kT != 3 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pad_h != 1 ||
+                             d->pad_w != 1 || d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi || d->out_mode == CVVAE_OUT_NCDHW))
+    return CVVAE_EUNSUPPORTED;
   if (d->gn_rows_per_batch < 1) return CVVAE_EINVAL;
   if (d->gn_rows_per_batch > 1 && (d->kT != 1 || d->gn_rows_per_batch != d->Ti)) return CVVAE_EINVAL;
   if ((long long)d->B * d->Ti * d->Hi * d->Wi >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
@@ -125,7 +134,9 @@ int64_t cvvae_conv_gn_slabs(const cvvae_conv_desc* d, int32_t groups) {
   const int sh = gn_shift_of(d, groups);
   const Instance* e = select_instance(d);
   if (sh < 0 || !e) return CVVAE_EUNSUPPORTED;
-  const long long tiles = cdiv(d->To, e->tt) * cdiv(d->Ho, e->th) * cdiv(d->Wo, e->tw);
+  const int fold = d->upsample2x == 2;
+  const long long tiles = fold ? cdiv(d->To, e->tt) * cdiv(d->Ho / 2, e->th) * cdiv(d->Wo / 2, e->tw) * 4
+                               : cdiv(d->To, e->tt) * cdiv(d->Ho, e->th) * cdiv(d->Wo, e->tw);
   return tiles * e->wm * e->kg * (d->out_mode == CVVAE_OUT_TIME_SHUFFLE ? 2 : 1) * (1LL << (sh - 2));
 }
 
@@ -156,16 +167,18 @@ int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_pa
   a.gsh = gn_shift;
   a.out = out;
   a.B = d->B; a.Ti = d->Ti; a.Hi = d->Hi; a.Wi = d->Wi;
-  a.Tl = d->Ti; a.Hl = d->upsample2x ? 2 * d->Hi : d->Hi; a.Wl = d->upsample2x ? 2 * d->Wi : d->Wi;
+  const int fold = d->upsample2x == 2;
+  a.Tl = d->Ti; a.Hl = d->upsample2x == 1 ? 2 * d->Hi : d->Hi; a.Wl = d->upsample2x == 1 ? 2 * d->Wi : d->Wi;
   a.Cin = d->Cin;
   a.in_ps = d->in_pix_stride;
-  a.To = d->To; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+  a.To = d->To; a.Ho = fold ? d->Ho / 2 : d->Ho; a.Wo = fold ? d->Wo / 2 : d->Wo; a.Cout = d->Cout;  // per-phase grid when folded
+  a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 12) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;
   a.mode_t = d->pad_mode_t; a.mode_hw = d->pad_mode_hw;
   a.tiles_t = (int)cdiv(d->To, e->tt);
-  a.tiles_h = (int)cdiv(d->Ho, e->th);
-  a.tiles_w = (int)cdiv(d->Wo, e->tw);
+  a.tiles_h = (int)cdiv(a.Ho, e->th);
+  a.tiles_w = (int)cdiv(a.Wo, e->tw);
   a.ntiles_n = (int)cdiv(d->Cout, 32LL * e->wn);
   a.nchunks = d->Cin / (16 * e->ksub);
   a.nblk32 = (d->Cout + 31) / 32;
@@ -181,10 +194,10 @@ int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_pa
     a.gnp = out_partials;
     a.gn_G = out_groups;
     a.gn_sh = sh;
-    a.gn_slabs = (int)((long long)a.tiles_t * a.tiles_h * a.tiles_w * e->wm * e->kg *
+    a.gn_slabs = (int)((long long)a.tiles_t * a.tiles_h * a.tiles_w * (fold ? 4 : 1) * e->wm * e->kg *
                        (d->out_mode == CVVAE_OUT_TIME_SHUFFLE ? 2 : 1) * (1LL << (sh - 2)));
   }
-  const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
+  const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n * (fold ? 4 : 1);
   if (grid <= 0 || grid >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
   return e->fn[d->dtype](a, (int)grid, (hipStream_t)stream);
 }

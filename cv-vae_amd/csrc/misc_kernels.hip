@@ -39,6 +39,48 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
   *reinterpret_cast<typename Tr<T>::v8*>(dst + gid * 8) = v;
 }
 
+// Nearest-2x upsample folded into the conv weights (Upsample3D: F.interpolate(scale (1,2,2)) then a 3x3x3 conv,
+// models/vae_blocks3d_sd3.py:342-356, models/vae_models.py:218-229).  Output row 2y+py reads upsampled rows 2y+py-1..2y+py+1
+// = stored rows {y-1, y, y} (py = 0) or {y, y, y+1} (py = 1): two stored rows per phase, with the weights of the taps that
+// coincide summed.  Same along x.  So phase (py, px) is a 3x2x2 convolution over the stored input with
+//   a = 0: ky in {0}      (py = 0) | {0, 1} (py = 1);      a = 1: ky in {1, 2} (py = 0) | {2} (py = 1)
+// (likewise b / kx / px), summed in fp32 and rounded once to the storage dtype.  Packed layout per phase as above with
+// taps = 12, tap = (kt*2 + a)*2 + b.
+template <typename T>
+__global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin, int nchunks, T* __restrict__ dst,
+                                   long long per_phase_lanes, long long phase_stride_elems) {
+  const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid0 >= 4 * per_phase_lanes) return;
+  const int phase = (int)(gid0 / per_phase_lanes);
+  const long long gid = gid0 - (long long)phase * per_phase_lanes;
+  const int py = phase >> 1, px = phase & 1;
+  const int lane = (int)(gid & 63);
+  long long f = gid >> 6;
+  const int tap = (int)(f % 12);
+  f /= 12;
+  const int chunk = (int)(f % nchunks);
+  const int nb = (int)(f / nchunks);
+  const int kt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
+  // folded tap sets [lo, hi] along y and x
+  const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
+  const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
+  const int co = nb * 32 + (lane & 31);
+  const int ci0 = chunk * 16 + (lane >> 5) * 8;
+  typename Tr<T>::v8 v;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int ci = ci0 + j;
+    float acc = 0.f;
+    if (co < Cout && ci < Cin) {
+      const T* w = src + ((long long)co * Cin + ci) * 27 + kt * 9;
+      for (int ky = y_lo; ky <= y_hi; ++ky)
+        for (int kx = x_lo; kx <= x_hi; ++kx) acc += (float)w[ky * 3 + kx];
+    }
+    v[j] = (T)acc;
+  }
+  *reinterpret_cast<typename Tr<T>::v8*>(dst + (long long)phase * phase_stride_elems + gid * 8) = v;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm statistics.  Stage 1: grid (nsplit, rows); each block reduces a slab of pixels for all channels
 // with Welford/Chan updates on 4-channel quads; stage 2 merges the slabs and emits the affine table.
@@ -494,6 +536,25 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout_src, Cin_src,
                        taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, void* dst,
+                              void* stream) {
+  if (!src || !dst || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cin_pad % 16) return CVVAE_EINVAL;
+  const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16;
+  const long long per_phase = (long long)nb * nchunks * 12 * 64;
+  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, 12) / 2);
+  const int grid = (int)((4 * per_phase + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(pack_upfold_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, Cout, Cin, nchunks,
+                       (__bf16*)dst, per_phase, stride);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(pack_upfold_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout, Cin, nchunks,
+                       (_Float16*)dst, per_phase, stride);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

@@ -4,6 +4,7 @@ This is the host-side mirror of the reference's L1/L2 modules (SURVEY.md 8a rows
 the reference forward it reproduces.  What the reference does as separate ATen ops (F.pad, F.interpolate,
 GroupNorm, SiLU, add, rearrange) is folded into the conv launches -- see include/cvvae.h.
 """
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -43,6 +44,18 @@ class WeightCache:
         self._c[pre] = (key, pw)
         return pw
 
+    def conv_upfold(self, pre: str) -> ops.PackedConv:
+        """Upsample3D conv weights folded into the four 3x2x2 phase kernels (ops.pack_weight_upfold)."""
+        w = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(w, b)
+        hit = self._c.get(pre + "#upfold")
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        pw = ops.pack_weight_upfold(w.detach(), b.detach())
+        self._c[pre + "#upfold"] = (key, pw)
+        return pw
+
     def norm(self, pre: str) -> Tuple[torch.Tensor, torch.Tensor]:
         g = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
@@ -60,6 +73,24 @@ class WeightCache:
             return True
         except AttributeError:
             return False
+
+
+def fold_upsample() -> bool:
+    """Upsample3D = nearest x(1,2,2) + 3x3x3 conv.  Default: run it as four 3x2x2 phase convolutions over the stored input
+    with folded weights (2.25x fewer MFMAs; differs from the 27-tap form only by one rounding of each folded weight).
+    CVVAE_FOLD_UPSAMPLE=0 selects the 27-tap gather form (bit-for-bit the reference's summation terms)."""
+    return os.environ.get("CVVAE_FOLD_UPSAMPLE", "1") != "0"
+
+
+def upsample_conv(wc: WeightCache, h: torch.Tensor, pre: str, pad, mode_t, mode_hw, up_time: bool):
+    """Upsample3D.forward (vae_blocks3d_sd3.py:314-364, vae_models.py:214-235) in one launch: nearest-2x + conv + (up_time)
+    channel->time shuffle and drop of frame 0; also returns the GroupNorm partials of the result."""
+    om = L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC
+    if fold_upsample():
+        return ops.conv(h, wc.conv_upfold(pre), pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, upsample2x=2, out_mode=om,
+                        gn_out=G32)
+    return ops.conv(h, wc.conv(pre, (3, 3, 3)), pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, upsample2x=True, out_mode=om,
+                    gn_out=G32)
 
 
 def _flat(x: torch.Tensor) -> torch.Tensor:
@@ -185,9 +216,7 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
             h, hp = sd3_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}", causal)
         if i != len(boc) - 1:  # Upsample3D vae_blocks3d_sd3.py:314-364; up_time on even blocks (vae_models3d_sd3.py:289)
             up_time = i % 2 == 0
-            h, hp = ops.conv(h, wc.conv(f"up_blocks.{i}.upsamplers.0.conv", (3, 3, 3)), pad=pad, pad_mode_t=REP,
-                             pad_mode_hw=REP, upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC,
-                             gn_out=G32)
+            h, hp = upsample_conv(wc, h, f"up_blocks.{i}.upsamplers.0.conv", pad, REP, REP, up_time)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
     return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
@@ -270,8 +299,7 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
             h, hp = v3_resnet(wc, h, hp, f"up.{lvl}.block.{j}", causal)
         if lvl != 0:  # Upsample3D vae_models.py:214-235 (built non-causal, :936): zero pad W,H, replicate T (1,1)
             up_time = lvl % 2 == 1
-            h, hp = ops.conv(h, wc.conv(f"up.{lvl}.upsample.conv", (3, 3, 3)), pad=P1, pad_mode_t=REP, pad_mode_hw=ZERO,
-                             upsample2x=True, out_mode=L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC, gn_out=G32)
+            h, hp = upsample_conv(wc, h, f"up.{lvl}.upsample.conv", P1, REP, ZERO, up_time)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
     return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)

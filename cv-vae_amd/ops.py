@@ -45,6 +45,7 @@ class PackedConv:
     cin: int                 # padded input channels the kernel consumes (multiple of kchunk)
     k: Tuple[int, int, int]
     cin_real: int = 0        # channels of the source weight (algorithmic FLOP accounting)
+    folded: bool = False     # packed by pack_weight_upfold: only valid with conv(..., upsample2x=2)
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
@@ -86,6 +87,26 @@ class GNPartials:
     groups: int
 
 
+def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+    """Upsample3D's conv weight [Cout, Cin, 3, 3, 3] -> the four folded 3x2x2 phase weights (cvvae_pack_weights_upfold) for
+    conv(..., upsample2x=2)."""
+    lib = L.load()
+    _need_gpu(w)
+    dt = _dt(w.dtype)
+    w = w.contiguous()
+    cout_, cin_ = w.shape[0], w.shape[1]
+    assert w.numel() == cout_ * cin_ * 27
+    cin_pad = round_up(cin_, 32)
+    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 12)
+    out = torch.zeros(4 * per, dtype=torch.uint8, device=w.device)
+    L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, out.data_ptr(), _stream()),
+            "cvvae_pack_weights_upfold")
+    b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[:cout_] = bias.detach().to(torch.float32)
+    return PackedConv(out, b, cout_, cin_pad, (3, 3, 3), cin_, folded=True)
+
+
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
          pad_mode_hw=L.PAD_ZERO, prologue=L.PRO_NONE, gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          gn_per_frame=False, residual: Optional[torch.Tensor] = None, upsample2x=False, out_mode=L.OUT_NDHWC,
@@ -109,7 +130,9 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.dtype = dt
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, pw.cin
     d.in_pix_stride = Cs
-    d.upsample2x = 1 if upsample2x else 0
+    if pw.folded != (upsample2x == 2):
+        raise ValueError("folded upsample weights (pack_weight_upfold) go with upsample2x=2 and only with it")
+    d.upsample2x = int(upsample2x)
     d.kT, d.kH, d.kW = kT, kH, kW
     d.sT, d.sH, d.sW = stride
     d.pad_t, d.pad_h, d.pad_w = pad[0][0], pad[1][0], pad[2][0]

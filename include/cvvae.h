@@ -61,7 +61,10 @@ typedef struct cvvae_conv_desc {
   int32_t B, Ti, Hi, Wi;
   int32_t Cin;                /* channels consumed; multiple of cvvae_conv_kchunk(); extra channels must have zero weights */
   int64_t in_pix_stride;      /* elements between consecutive pixels (>= Cin, multiple of 8) */
-  int32_t upsample2x;         /* 1: the conv sees nearest x(1,2,2) of the stored input (never materialised) */
+  int32_t upsample2x;         /* 1: the conv sees nearest x(1,2,2) of the stored input (never materialised; 27 taps gathered
+                                 on the upsampled grid).  2: the same result from four 3x2x2 phase convolutions over the stored
+                                 input with FOLDED weights (cvvae_pack_weights_upfold): 12 taps instead of 27; the only numeric
+                                 difference is one rounding of each folded weight.  kT,kH,kW stay (3,3,3) (the reference op) */
   /* kernel */
   int32_t kT, kH, kW;         /* (3,3,3) | (1,3,3) | (1,1,1) */
   int32_t sT, sH, sW;         /* 1 or 2 each; stride > 1 only with (3,3,3) */
@@ -91,6 +94,11 @@ size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps);
 int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps,
                        int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst,
                        void* stream);
+
+/* Fold + pack for upsample2x == 2: src = torch conv weight [Cout][Cin][3][3][3] (contiguous, dtype); dst = 4 phase buffers
+ * of cvvae_packed_weight_bytes(Cout, Cin_pad, 12) bytes each, back to back (phase = 2*py + px). */
+int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, void* dst,
+                              void* stream);
 
 int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                    const void* residual, const float* gn_scale, const float* gn_shift, void* out, void* stream);

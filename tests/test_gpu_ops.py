@@ -79,6 +79,8 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         bb = torch.zeros(cin_pad); bb[:Cin] = beta
         assert cin_pad == Cin, "prologue cases use channel counts that need no padding"
         gn = ops.gn_stats(xd, g.to(DEV), bb.to(DEV), 1e-6)
+    if ups == 2:
+        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV))
     out = ops.conv(xd, pw, stride=stride, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=prologue, gn=gn,
                    residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode)
     torch.cuda.synchronize()
@@ -150,6 +152,18 @@ def test_conv333_upsample_time_shuffle(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mode_hw", [REP, ZERO])
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_conv333_upsample_folded(dtype, mode_hw, shuffle):
+    # Upsample3D as four folded 3x2x2 phase convs (upsample2x=2) against F.interpolate + 27-tap conv3d; odd sizes exercise
+    # tile overhang in every phase.  One extra rounding of each folded weight: tolerance 2x the plain conv's.
+    L = _ops()[1]
+    base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    run_conv_case(dtype, 256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, mode_hw, (1, 3, 9, 19), ups=2,
+                  out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC, tol=2 * base)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_conv333_upsample_vae3d_pad(dtype):
     # vae3d Upsample3D: nearest x2, zero pad W,H, replicate T (1,1), no time upsampling (vae_models.py:218-229)
     run_conv_case(dtype, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, ZERO, (1, 3, 8, 16), ups=True)
@@ -181,7 +195,8 @@ def test_conv_small_cin_padded(dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("case", ["c333_128", "c133_256_res", "ups_shuffle_512", "c111_512_b2", "down_222", "c333_128_t2"])
+@pytest.mark.parametrize("case", ["c333_128", "c133_256_res", "ups_shuffle_512", "upfold_shuffle_512", "upfold_256", "c111_512_b2", "down_222",
+                                  "c333_128_t2"])
 def test_conv_fused_gn_stats(dtype, case):
     """cvvae_conv_fwd_gn + cvvae_gn_finalize (statistics from the conv epilogue) must equal a statistics pass over the
     stored output (cvvae_gn_stats) and torch's group_norm moments of it: every record written once, all layouts."""
@@ -192,6 +207,8 @@ def test_conv_fused_gn_stats(dtype, case):
         "c333_128_t2": (128, 128, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), (2, 17, 16, 32), False, L.OUT_NDHWC, False),
         "c133_256_res": (256, 256, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), (1, 3, 17, 33), False, L.OUT_NDHWC, True),
         "ups_shuffle_512": (256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), (1, 3, 8, 16), True, L.OUT_TIME_SHUFFLE, False),
+        "upfold_shuffle_512": (256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), (1, 3, 9, 19), 2, L.OUT_TIME_SHUFFLE, False),
+        "upfold_256": (256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), (2, 2, 8, 16), 2, L.OUT_NDHWC, False),
         "c111_512_b2": (256, 512, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), (2, 1, 1, 300), False, L.OUT_NDHWC, True),
         "down_222": (128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (1, 1), (1, 1)), (1, 5, 24, 40), False, L.OUT_NDHWC, False),
     }[case]
@@ -199,7 +216,7 @@ def test_conv_fused_gn_stats(dtype, case):
     x = to_ndhwc(rnd((B, Cin, T, H, W), dtype, 1, 1.0)).to(DEV)
     w = rnd((Cout, Cin) + k, dtype, 2, 1.0 / (Cin * k[0] * k[1] * k[2]) ** 0.5)
     bias = rnd((Cout,), torch.float32, 3, 0.5)  # a non-zero mean makes the (n, mean, M2) merge matter
-    pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k)
+    pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV)) if ups == 2 else ops.pack_weight(w.to(DEV), bias.to(DEV), k)
     y0 = ops.conv(x, pw, stride=stride, pad=pad, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=ups, out_mode=out_mode)
     res = rnd(tuple(y0.shape), dtype, 4, 1.0).to(DEV) if residual else None
     y, part = ops.conv(x, pw, stride=stride, pad=pad, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=ups, out_mode=out_mode,

@@ -25,6 +25,8 @@ CASES = {
     "dec512s": (512, 512, (3, 3, 3), 5, 64, 64, P1, 1, False),
     "dec256to128": (256, 128, (3, 3, 3), 17, 512, 512, P1, 1, False),
     "up256to512": (256, 512, (3, 3, 3), 9, 256, 256, P1, 0, True),    # the 16.7 TFLOP upsample conv
+    "upfold256to512": (256, 512, (3, 3, 3), 9, 256, 256, P1, 0, 2),  # the same conv as four folded 3x2x2 phase convs
+    "upfold512": (512, 512, (3, 3, 3), 9, 128, 128, P1, 0, 2),
     "c2d128": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
     "c2d512": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
     "out128to3": (128, 3, (3, 3, 3), 17, 512, 512, P1, 1, False),
@@ -56,7 +58,10 @@ def main():
         cin, cout, k, T, H, W, pad, pro, ups = CASES[name]
         x = (torch.rand((1, T, H, W, cin), device="cuda") * 2 - 1).to(dt)
         w = (torch.rand((cout, cin) + k, device="cuda") * 2 - 1).to(dt) / (cin * k[0] * k[1] * k[2]) ** 0.5
-        pw = ops.pack_weight(w.reshape(cout, cin, -1), torch.zeros(cout, device="cuda"), k)
+        if ups == 2:
+            pw = ops.pack_weight_upfold(w, torch.zeros(cout, device="cuda"))
+        else:
+            pw = ops.pack_weight(w.reshape(cout, cin, -1), torch.zeros(cout, device="cuda"), k)
         gn = None
         if pro:
             gn = ops.gn_stats(x, torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), 1e-6)

@@ -30,6 +30,12 @@ static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
 #elif CFG == 4 // c2d512
 #define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,false
 static const int CIN = 512, COUT = 512, TT_ = 9, HH = 128, WW = 128, PT = 0;
+#elif CFG == 5 // enc256 without prologue (pro0) for comparison
+#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,false
+static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
+#elif CFG == 6 // enc256 with GN only (PRO=2: fma, no SiLU)
+#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 2,false
+static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #endif
 
 template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int PRO, bool UPS>
