@@ -183,10 +183,19 @@ def main():
         agg = roofline_pass(step)
         name, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = fl / sec / 1e12
+        # HBM traffic per launch of that kernel: from the committed PMC passes of this same command (profiles/)
+        traffic = None
+        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.isfile(tj):
+            with open(tj) as f:
+                k = json.load(f).get("kernels", {}).get(name.split("_", 3)[3] if name.count("_") >= 3 else name)
+            if k:
+                traffic = k["fetch_bytes"] + k["write_bytes"]
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "launches_per_step": n,
             "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": None,
+            "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": traffic,
+            "traffic_unit": "bytes/launch (PMC, profiles/pmc_traffic.json)",
         }
         out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3), "launches": v[2]}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}

@@ -223,7 +223,23 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
                                                                 float* __restrict__ shift) {
   const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
   WStat acc = {0.f, 0.f, 0.f};
-  for (long long s = tid; s < slabs; s += 256) {
+  // records are 12 bytes at a stride of G*12: latency-bound, so keep 8 independent loads in flight per thread and
+  // merge them in index order afterwards (the merge order, hence the result, does not depend on the batching)
+  constexpr int U = 8;
+  long long s = tid;
+  for (; s + (long long)(U - 1) * 256 < slabs; s += (long long)U * 256) {
+    WStat q[U];
+#pragma unroll
+    for (int i = 0; i < U; ++i) {
+      const float* o = ws + (((long long)row * slabs + s + (long long)i * 256) * G + g) * 3;
+      q[i].n = o[0];
+      q[i].mean = o[1];
+      q[i].m2 = o[2];
+    }
+#pragma unroll
+    for (int i = 0; i < U; ++i) chan_merge(acc, q[i]);
+  }
+  for (; s < slabs; s += 256) {
     const float* o = ws + (((long long)row * slabs + s) * G + g) * 3;
     WStat q = {o[0], o[1], o[2]};
     chan_merge(acc, q);

@@ -10,20 +10,20 @@ csv.field_size_limit(1 << 30)
 
 
 def short(n):
+    """library-style instance name from rocprofv3's kernel name.  rocprofv3's demangler garbles the leading template
+    arguments of conv_fwd_kernel (T, KT, KH, KW, ST, SH, SW); the tail TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS is reliable and
+    identifies the instance (suffix of the name cvvae_conv_kernel_name() reports: conv_k..._s..._<suffix>)."""
     m = re.search(r"conv_fwd_kernel<(.*?)>\(", n)
     if m:
         f = [x.strip() for x in m.group(1).split(",")]
-        # rocprofv3's demangler garbles the leading template arguments; the tail is reliable:
-        # ..., TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS
         t = f[-9:]
-        k = "k133" if "3,3,1,1,1" in ",".join(f[:-9]) and "ELi" not in ",".join(f[:3]) else ("k111" if f[-7] == "256" else "k3xx")
-        return f"conv_{k}_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{1 if t[8] == 'true' else 0}"
+        return f"conv_*_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{t[8]}"
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"^void ", "", n)
     return n[-60:]
 
 
-def main(d, flt=None):
+def main(d, flt=None, json_out=None):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0, 0.0]))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -47,6 +47,16 @@ def main(d, flt=None):
         hit, miss, ga = mean("TCC_HIT_sum"), mean("TCC_MISS_sum"), mean("GRBM_GUI_ACTIVE")
         durg = cs["GRBM_GUI_ACTIVE"][2] / cs["GRBM_GUI_ACTIVE"][0] if "GRBM_GUI_ACTIVE" in cs else None
         rows.append((dur * n, k, n, dur, fe, wr, hit, miss, ga, durg))
+    if json_out:
+        import json
+        js = {}
+        for _, k, n, dur, fe, wr, hit, miss, ga, durg in rows:
+            if k.startswith("conv_*_") and fe is not None and wr is not None:
+                js[k[len("conv_*_"):]] = {"fetch_bytes": round(fe * 2 * 1024), "write_bytes": round(wr * 1024), "dispatches": n,
+                                          "mean_duration_us": round(dur, 1)}
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py; fetch = 2 x FETCH_SIZE KiB "
+                             "(gfx950 correction of MI355X_MICROARCH.md), write = WRITE_SIZE KiB; mean per dispatch",
+                   "kernels": js}, open(json_out, "w"), indent=1)
     fmt = lambda v, s: ("%" + s) % v if v is not None else " " * (int(s.split(".")[0]) - 1) + "-"
     for _, k, n, dur, fe, wr, hit, miss, ga, durg in sorted(rows, reverse=True):
         print(f"{k:58s} {n:5d} {dur:9.1f} {fmt(fe * 2 * 1024 / 1e9 if fe is not None else None, '9.3f')} "
@@ -56,4 +66,6 @@ def main(d, flt=None):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2] if len(sys.argv) > 2 else None)
+    a = [x for x in sys.argv[1:] if not x.startswith("--json=")]
+    j = [x[7:] for x in sys.argv[1:] if x.startswith("--json=")]
+    main(a[0], a[1] if len(a) > 1 else None, j[0] if j else None)

@@ -15,6 +15,6 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" GRBM_GUI_ACTIVE; do
   tag=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$tag -- $BENCH > $O/pmc_$tag.log 2>&1
 done
-python $R/tools/pmc_summary.py $O > $O/pmc_summary.txt 2>&1
+python $R/tools/pmc_summary.py $O --json=$O/pmc_traffic.json > $O/pmc_summary.txt 2>&1
 rm -rf $O/trace $O/pmc_*/   # raw traces are large; the summaries are what is kept
 ls -la $O
