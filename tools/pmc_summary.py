@@ -35,7 +35,7 @@ def main(d, flt=None, json_out=None):
             a[1] += float(r["Counter_Value"])
             a[2] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     print("# per-dispatch means.  fetch_GB = 2 * FETCH_SIZE KiB (gfx950 correction), write_GB = WRITE_SIZE KiB, "
-          "l2_hit = TCC_HIT/(HIT+MISS), clk_GHz = GRBM_GUI_ACTIVE / duration")
+          "l2_hit = TCC_HIT/(HIT+MISS), clk_GHz = GRBM_GUI_ACTIVE / 8 XCDs / duration")
     print(f"{'kernel':58s} {'n':>5s} {'dur_us':>9s} {'fetch_GB':>9s} {'write_GB':>9s} {'l2_hit':>7s} {'clk_GHz':>8s}")
     rows = []
     for k, cs in acc.items():
@@ -62,7 +62,7 @@ def main(d, flt=None, json_out=None):
         print(f"{k:58s} {n:5d} {dur:9.1f} {fmt(fe * 2 * 1024 / 1e9 if fe is not None else None, '9.3f')} "
               f"{fmt(wr * 1024 / 1e9 if wr is not None else None, '9.3f')} "
               f"{fmt(hit / (hit + miss) if hit is not None and hit + miss > 0 else None, '7.3f')} "
-              f"{fmt(ga / (durg * 1e3) if ga is not None and durg else None, '8.3f')}")
+              f"{fmt(ga / 8.0 / (durg * 1e3) if ga is not None and durg else None, '8.3f')}")
 
 
 if __name__ == "__main__":
