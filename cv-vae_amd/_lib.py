@@ -58,6 +58,8 @@ PROTOTYPES = {
     "cvvae_temporal_attention": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     "cvvae_ncdhw_to_ndhwc": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_ndhwc_to_ncdhw": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp]),
+    "cvvae_frames_u8_to_ndhwc": (_i32, [_i32, _vp, _i64, _i32, _vp, _vp]),
+    "cvvae_ncdhw_to_frames_u8": (_i32, [_i32, _vp, _i64, _vp, _vp]),
     "cvvae_blend": (_i32, [_i32, _vp, _i32, _i32, _vp, _i32, _i32, _i64, _i32, _i32, _vp]),
 }
 

@@ -495,6 +495,43 @@ __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const T* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// pixel pre/post-processing of the inference scripts, on the device (cvvae_inference_video.py:24-38, 47-50).
+// The arithmetic is evaluated op by op in the storage dtype, as the script's half tensors do (fp32 op, one rounding each).
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void frames_u8_to_ndhwc_kernel(const uint8_t* __restrict__ f, long long npix, int Cpad,
+                                                                 T* __restrict__ out) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= npix) return;
+  float v[8];
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const T h = (T)(float)f[pix * 3 + c];        // .half()
+    const T d = (T)((float)h / 127.5f);          // / 127.5
+    v[c] = (float)(T)((float)d - 1.0f);          // - 1.0
+  }
+#pragma unroll
+  for (int c = 3; c < 8; ++c) v[c] = 0.f;
+  *reinterpret_cast<uint4*>(out + pix * Cpad) = pack8<T>(v);
+  const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int c0 = 8; c0 < Cpad; c0 += 8) *reinterpret_cast<uint4*>(out + pix * Cpad + c0) = pack8<T>(z);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ncdhw_to_frames_u8_kernel(const T* __restrict__ in, long long thw, uint8_t* __restrict__ f) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (pix >= thw) return;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float x = (float)in[(long long)c * thw + pix];
+    x = x < -1.0f ? -1.0f : (x > 1.0f ? 1.0f : x);   // torch.clamp(results, -1.0, 1.0)
+    const T a = (T)(x + 1.0f);                         // + 1.0
+    const T m = (T)((float)a * 127.5f);                // * 127.5
+    f[pix * 3 + c] = (uint8_t)(float)m;                // .to(torch.uint8): truncation
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // tile blending (in place on b): b[.., :o] = (1-w)*a[.., -o:] + w*b[.., :o], w = i/o in fp32
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -712,6 +749,34 @@ int cvvae_ndhwc_to_ncdhw(int32_t dtype, const void* in, int32_t B, int32_t C, in
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, C, THW,
                        (long long)pix_stride, npix, (_Float16*)out);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_frames_u8_to_ndhwc(int32_t dtype, const uint8_t* frames, int64_t npix, int32_t Cpad, void* out, void* stream) {
+  if (!frames || !out || npix <= 0 || Cpad < 8 || Cpad % 8) return CVVAE_EINVAL;
+  const int grid = (int)((npix + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(frames_u8_to_ndhwc_kernel<__bf16>, dim3(grid), dim3(256), 0, s, frames, (long long)npix, Cpad, (__bf16*)out);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(frames_u8_to_ndhwc_kernel<_Float16>, dim3(grid), dim3(256), 0, s, frames, (long long)npix, Cpad,
+                       (_Float16*)out);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t* frames, void* stream) {
+  if (!in || !frames || thw <= 0) return CVVAE_EINVAL;
+  const int grid = (int)((thw + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(ncdhw_to_frames_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)in, (long long)thw, frames);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(ncdhw_to_frames_u8_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, (long long)thw,
+                       frames);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

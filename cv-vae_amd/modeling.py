@@ -508,6 +508,28 @@ class _CVVAEBase(nn.Module):
             return (x,)
         return DecoderOutput(sample=x)
 
+    # ---- device-side pixel pre/post-processing of the inference scripts ------------------------
+    @torch.no_grad()
+    def encode_frames_u8(self, frames: torch.Tensor, return_dict: bool = True):
+        """frames: uint8 [T,H,W,3] on the device (decord's layout).  Equivalent to the scripts' host-side
+        `rearrange -> .half() -> / 127.5 - 1.0 -> [:, :, :frame_end]` (cvvae_inference_video.py:24-38) followed by
+        `encode`; the normalisation runs on the MI355X in the model's dtype with the scripts' rounding steps."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
+            raise ValueError(f"expected uint8 frames [T,H,W,3], got {frames.dtype} {tuple(frames.shape)}")
+        T = frames.shape[0]
+        frame_end = 1 + (T - 1) // 4 * 4
+        x = ops.frames_u8_to_ndhwc(frames[:frame_end].contiguous(), 8, self.dtype)
+        return self.encode(x[..., :3].permute(0, 4, 1, 2, 3), return_dict=return_dict)
+
+    @torch.no_grad()
+    def decode_to_frames_u8(self, z: torch.Tensor, num_frames: Optional[int] = None) -> torch.Tensor:
+        """`decode(z).sample` followed by the scripts' `(clamp(x,-1,1)+1)*127.5 -> uint8` ('t h w c',
+        cvvae_inference_video.py:47-50) on the device.  One clip (B = 1)."""
+        x = self.decode(z, num_frames=num_frames).sample
+        if x.dim() != 5 or x.shape[0] != 1:
+            raise ValueError("decode_to_frames_u8 handles one clip [1,C,T,H,W] (reshape_x_dim_to_4 must be off)")
+        return ops.ncdhw_to_frames_u8(x.contiguous())
+
     def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True,
                 generator: Optional[torch.Generator] = None, num_frames: Optional[int] = None
                 ) -> Union[DecoderOutput, Tuple[torch.Tensor]]:

@@ -309,3 +309,27 @@ def blend_(a: torch.Tensor, b: torch.Tensor, overlap: int, axis: int) -> torch.T
     L.check(lib.cvvae_blend(_dt(b.dtype), a.data_ptr(), a.shape[3], a.shape[4], b.data_ptr(), b.shape[3], b.shape[4], rows,
                             overlap, axis, _stream()), "cvvae_blend")
     return b
+
+
+def frames_u8_to_ndhwc(frames: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """uint8 frames [T,H,W,3] -> [1,T,H,W,cpad] dtype = u8/127.5 - 1 (the scripts' normalisation, in dtype arithmetic)."""
+    lib = L.load()
+    _need_gpu(frames)
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3 and frames.is_contiguous()
+    T, H, W, _ = frames.shape
+    out = torch.empty((1, T, H, W, cpad), dtype=dtype, device=frames.device)
+    L.check(lib.cvvae_frames_u8_to_ndhwc(_dt(dtype), frames.data_ptr(), T * H * W, cpad, out.data_ptr(), _stream()),
+            "cvvae_frames_u8_to_ndhwc")
+    return out
+
+
+def ncdhw_to_frames_u8(x: torch.Tensor) -> torch.Tensor:
+    """decoder output [1,3,T,H,W] -> uint8 frames [T,H,W,3] = u8((clamp(x,-1,1)+1)*127.5) (the scripts' post-processing)."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3 and x.is_contiguous()
+    _, _, T, H, W = x.shape
+    out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=x.device)
+    L.check(lib.cvvae_ncdhw_to_frames_u8(_dt(x.dtype), x.data_ptr(), T * H * W, out.data_ptr(), _stream()),
+            "cvvae_ncdhw_to_frames_u8")
+    return out

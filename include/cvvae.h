@@ -159,6 +159,14 @@ int cvvae_ncdhw_to_ndhwc(int32_t src_dtype, int32_t dst_dtype, const void* in, i
 int cvvae_ndhwc_to_ncdhw(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
                          int64_t pix_stride, void* out, void* stream);
 
+/* Pixel pre/post-processing of the inference scripts on the device (cvvae_inference_video.py:24-38 and 47-50; SURVEY 8f
+ * row 1), evaluated op by op in dtype exactly as the scripts' half tensors are:
+ *   frames uint8 [T][H][W][3] (decord layout) -> NDHWC [1][T][H][W][Cpad] dtype = ((dtype)u8 / 127.5) - 1.0, pad channels 0
+ *     (npix = T*H*W) -- the tensor conv_in consumes, so the NCDHW float clip is never built;
+ *   decoder output NCDHW [1][3][T][H][W] dtype -> frames uint8 [T][H][W][3] = u8((clamp(x,-1,1) + 1.0) * 127.5)  (thw = T*H*W). */
+int cvvae_frames_u8_to_ndhwc(int32_t dtype, const uint8_t* frames, int64_t npix, int32_t Cpad, void* out, void* stream);
+int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t* frames, void* stream);
+
 /* Tile blending, in place on b (blend_h / blend_v, models/modeling_vae.py:321-341,647-667): NCDHW tensors,
  * b[..., :o] = (1-w)*a[..., -o:] + w*b[..., :o], w = arange(o)/o in fp32.  axis: 0 = H (blend_v), 1 = W (blend_h).
  * rows = B*C*T.  a is [rows][Ha][Wa], b is [rows][Hb][Wb]. */

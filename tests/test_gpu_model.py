@@ -117,3 +117,67 @@ def test_inference_script_plumbing():
     results = results.squeeze(0).permute(1, 2, 3, 0)
     results = ((torch.clamp(results, -1.0, 1.0) + 1.0) * 127.5).to("cpu", dtype=torch.uint8)
     assert results.shape == (9, 64, 96, 3)
+
+
+def test_t2i_pipeline_contract():
+    """The diffusion pipeline's use of the VAE (pipelines/pipeline_stable_diffusion.py:248,536-537,1046): 4-D image latents,
+    `vae.config.scaling_factor`, `decode(latents / sf, num_frames=1).sample` and `decode(..., return_dict=False)[0]`,
+    `vae.config.spatial_n_compress`, the slicing/tiling toggles.  Image mode = T=1 through the 3-D decoder, checked
+    per image against the CPU oracle."""
+    dtype = torch.float16
+    m, sd = build("vae3d", {}, dtype, 0)
+    assert m.config.spatial_n_compress == 8 and abs(m.config.scaling_factor - 0.18215) < 1e-9
+    m.enable_slicing(); m.enable_tiling(); m.disable_slicing(); m.disable_tiling()
+    g = torch.Generator().manual_seed(3)
+    latents = torch.randn((2, 4, 8, 8), generator=g) * m.config.scaling_factor   # what the UNet hands over
+    z = (latents / m.config.scaling_factor).to(dtype).cuda()
+    img = m.decode(z, num_frames=1).sample
+    assert img.shape == (2, 3, 1, 64, 64)                                        # 5-D unless reshape_x_dim_to_4
+    img2 = m.decode(z, return_dict=False)[0]
+    assert torch.equal(img, img2)
+    with torch.no_grad():
+        for i in range(2):
+            ref = O.decode_sample((latents[i:i + 1] / m.config.scaling_factor).to(dtype).float().unsqueeze(2), sd, {}, "vae3d")
+            assert (img[i:i + 1].float().cpu() - ref).abs().max() <= TOL[dtype]["recon"]
+    # reshape_x_dim_to_4 hands the pipeline 4-D frames back (modeling_vae.py:312-315)
+    m4, _ = build("vae3d", {"reshape_x_dim_to_4": True}, dtype, 0)
+    assert m4.decode(z, num_frames=1).sample.shape == (2, 3, 64, 64)
+
+
+def test_batch_of_clips_matches_single_clips():
+    """GroupNorm statistics are per sample: a batch of B clips must equal B single-clip calls bit for bit (cfg 5 is a
+    batch-8 encode); covers the per-sample rows of the fused statistics and of the 1x1 convs."""
+    dtype = torch.bfloat16
+    m, _ = build("sd3", {}, dtype, 1)
+    x = seeded_input((3, 3, 5, 64, 96), 9).to(dtype).cuda()
+    zb = m.encode(x).latent_dist.parameters
+    yb = m.decode(zb[:, :16]).sample
+    for i in range(3):
+        zi = m.encode(x[i:i + 1]).latent_dist.parameters
+        assert torch.equal(zb[i:i + 1], zi)
+        assert torch.equal(yb[i:i + 1], m.decode(zi[:, :16]).sample)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_device_pre_post_processing_matches_script_ops(dtype):
+    """encode_frames_u8 / decode_to_frames_u8 (cvvae_frames_u8_to_ndhwc, cvvae_ncdhw_to_frames_u8) against the scripts'
+    own tensor ops (cvvae_inference_video.py:24-38, 47-50), bit for bit."""
+    from cvvae_amd import ops
+    m, _ = build("sd3", {}, dtype, 0)
+    g = torch.Generator().manual_seed(0)
+    video_u8 = torch.randint(0, 256, (10, 64, 96, 3), generator=g, dtype=torch.uint8)          # t h w c, as decord returns
+    # the script, on the host
+    video = video_u8.permute(3, 0, 1, 2).unsqueeze(0).to(dtype)
+    frame_end = 1 + (10 - 1) // 4 * 4
+    video = (video / 127.5 - 1.0)[:, :, :frame_end]
+    x_dev = ops.frames_u8_to_ndhwc(video_u8[:frame_end].cuda().contiguous(), 8, dtype)
+    assert torch.equal(x_dev[..., :3].permute(0, 4, 1, 2, 3).cpu(), video) and (x_dev[..., 3:] == 0).all()
+    z_ref = m.encode(video.cuda()).latent_dist.parameters
+    z = m.encode_frames_u8(video_u8.cuda()).latent_dist.parameters
+    assert torch.equal(z, z_ref)
+    lat = z[:, :16]
+    results = m.decode(lat).sample
+    want = ((torch.clamp(results.squeeze(0).permute(1, 2, 3, 0), -1.0, 1.0) + 1.0) * 127.5).to("cpu", dtype=torch.uint8)
+    got = m.decode_to_frames_u8(lat)
+    assert got.dtype == torch.uint8 and got.shape == (9, 64, 96, 3)
+    assert torch.equal(got.cpu(), want)
