@@ -27,12 +27,19 @@ import torch  # noqa: E402
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
 
 WORKLOADS = {
-    # name: (family, B, T, H, W)
+    # name: (family, B, T, H, W)            -- BASELINE.json configs; cfg 3 is the one the metric is quoted on (default)
     "cfg3_sd3_T17_512": ("sd3", 1, 17, 512, 512),
     "cfg2_vae3d_T17_256": ("vae3d", 1, 17, 256, 256),
+    # cfg 4: ONE long clip, its 8 temporal windows (x 6 spatial tiles each) sharded over the ranks (cv-vae_amd/dist.py):
+    # strong scaling, encode + decode of the whole clip, gathered latents
+    "cfg4_sd3_T129_720x1280": ("sd3", 1, 129, 720, 1280),
+    # cfg 5: batch-8 T=33 encode-only (training-side latent pre-compute); the batch is split over the ranks
+    "cfg5_sd3_B8_T33_512_encode": ("sd3", 8, 33, 512, 512),
 }
-# algorithmic FLOPs per clip (2*M*N*K of every conv/linear + attention)
-ALG_TFLOP = {"cfg3_sd3_T17_512": 91.41, "cfg2_vae3d_T17_256": 22.79}
+ENC_TFLOP = {"cfg3_sd3_T17_512": 22.842, "cfg2_vae3d_T17_256": 5.674}  # encoder share of ALG_TFLOP
+# algorithmic FLOPs per unit of work (BASELINE.md section 3 / SURVEY 8d: 2*M*N*K of every conv/linear + attention)
+ALG_TFLOP = {"cfg3_sd3_T17_512": 91.41, "cfg2_vae3d_T17_256": 22.79, "cfg4_sd3_T129_720x1280": 3656.0,
+             "cfg5_sd3_B8_T33_512_encode": 365.4}
 
 
 def parse():
@@ -82,7 +89,7 @@ def roofline_pass(step_fn):
     return agg
 
 
-def cpu_baseline(family):
+def cpu_baseline(family, H=512, W=512):
     """CPU oracle on a bounded sample: the same network on a 17-frame window at 128x128 (1/16 of the 512x512 frame
     area; one temporal window, no spatial tiling -- like the workload), scaled to 512x512-equivalent frames/s."""
     from oracle import cvvae_oracle as O
@@ -100,14 +107,14 @@ def cpu_baseline(family):
         rec = O.decode_sample(O.posterior_mode(mom), sd, {}, family)
         dt = time.time() - t0
     assert rec.shape == x.shape
-    area_scale = (512 * 512) / float(hw * hw)
+    area_scale = (H * W) / float(hw * hw)
     return {
         "value": round(17.0 / (dt * area_scale), 5),
         "unit": "frames/s",
         "cores": cores,
         "kind": "port",
         "sample": f"oracle (PyTorch-CPU fp32 restatement) encode+decode of 1x3x17x{hw}x{hw} in {dt:.1f}s; value = 17 frames "
-                  f"/ (t * {area_scale:.0f}) i.e. scaled by pixel count to the 512x512 workload",
+                  f"/ (t * {area_scale:.1f}) i.e. scaled by pixel count to the {H}x{W} workload",
     }
 
 
@@ -133,12 +140,30 @@ def main():
     torch.manual_seed(0)
     cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
     vae = cls().to(dtype).cuda().eval()  # random-init weights of the named architecture (no checkpoint access)
-    g = torch.Generator().manual_seed(1000 + rank)
+    cfg4 = args.workload.startswith("cfg4")
+    cfg5 = args.workload.startswith("cfg5")
+    if cfg5:
+        if B % world:
+            raise SystemExit(f"cfg5 splits its batch of {B} over the ranks: --gpus must divide {B}")
+        B = B // world
+    # cfg 3 / 2: every rank codes its own clip (weak scaling).  cfg 4: every rank holds the same clip (seed without rank)
+    g = torch.Generator().manual_seed(1000 + (0 if cfg4 else rank))
     x = (torch.rand((B, 3, T, H, W), generator=g) * 2 - 1).to(dtype).cuda()
 
-    def step():
-        z = vae.encode(x).latent_dist.mode()
-        return vae.decode(z).sample
+    if cfg4 and dist is not None:
+        from cvvae_amd import dist as D
+
+        def step():
+            mom = D.encode_windows_sharded(vae, x)                     # all_gather of the latents (15 MB)
+            z = mom[:, :mom.shape[1] // 2]
+            return D.decode_windows_sharded(vae, z, gather=False)      # pixels stay sharded (713 MB if gathered)
+    elif cfg5:
+        def step():
+            return vae.encode(x).latent_dist.mode()
+    else:
+        def step():
+            z = vae.encode(x).latent_dist.mode()
+            return vae.decode(z).sample
 
     for _ in range(args.warmup):
         step()
@@ -154,15 +179,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    assert y.shape == x.shape
+    assert cfg5 or (cfg4 and dist is not None) or y.shape == x.shape
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    frames = world * B * T * args.steps
+    strong = cfg4                                 # one fixed clip split over the ranks; everything else: per-rank work fixed
+    frames = (1 if strong else world) * B * T * args.steps
+    units = (1 if strong else world) * (B if cfg5 else 1) * args.steps / (8 if cfg5 else 1)  # ALG_TFLOP units done
     out = {
-        "metric": "encode+decode frames/sec (T=17, 512x512)" if args.workload.startswith("cfg3") else "encode+decode frames/sec",
+        "metric": "encode+decode frames/sec (T=17, 512x512)" if args.workload.startswith("cfg3") else
+                  ("encode-only frames/sec" if cfg5 else "encode+decode frames/sec"),
         "value": round(frames / elapsed, 3),
         "unit": "frames/s",
         "n_gpus": world,
@@ -170,15 +198,35 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic uniform[-1,1) clip, random-init weights (seed 0) of the named architecture",
-        "config": {"workload": f"{args.workload}: {family} encode(x).mode() + decode(z), x=[{B},3,{T},{H},{W}] per GPU",
-                   "clips_per_gpu": B, "parallelism": f"window-sharded x{world} (no collective)"},
-        "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * world * args.steps / elapsed, 1),
+        "config": {"workload": f"{args.workload}: {family} " + ("encode(x).mode()" if cfg5 else "encode(x).mode() + decode(z)") +
+                               f", x=[{B},3,{T},{H},{W}] per GPU",
+                   "clips_per_gpu": B,
+                   "parallelism": (f"temporal windows sharded x{world}, latents all-gathered" if strong else
+                                   f"independent clips x{world} (no collective)")},
+        "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * units / elapsed, 1),
     }
 
+    if rank == 0 and not (cfg5 or (cfg4 and dist is not None)):
+        # encode / decode split of one step (separate, untimed pass; events on the launch stream)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        for _ in range(2):
+            ev[0].record()
+            zz = vae.encode(x).latent_dist.mode()
+            ev[1].record()
+            vae.decode(zz)
+            ev[2].record()
+        torch.cuda.synchronize()
+        enc_ms, dec_ms = ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2])
+        out["encode_ms"], out["decode_ms"] = round(enc_ms, 3), round(dec_ms, 3)
+        if args.workload in ENC_TFLOP:
+            et = ENC_TFLOP[args.workload]
+            out["encode_tflops"] = round(et / enc_ms * 1e3, 1)
+            out["decode_tflops"] = round((ALG_TFLOP[args.workload] - et) / dec_ms * 1e3, 1)
+            out["encode_frac_of_mfma_peak"] = round(et / enc_ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
     if rank == 0 and not args.no_roofline:
         agg = roofline_pass(step)
         name, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
@@ -200,7 +248,7 @@ def main():
         out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3), "launches": v[2]}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(family)
+        out["cpu_baseline"] = cpu_baseline(family, H, W)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

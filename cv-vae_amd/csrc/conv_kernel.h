@@ -469,90 +469,122 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // fused GroupNorm statistics of what is stored (the ROUNDED values, as the reference's GroupNorm sees them): per lane
   // 4 slots (pr, q) of 4 consecutive channels each: sum, sum of squares; valid-pixel count per pr
   float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gc[2] = {0.f, 0.f};
+  // per channel pair pr (tile independent): my 8-channel run, its bias, where it lands
+  int c8v[2], ccv[2], nshv[2];
+  float bia[2][8];
 #pragma unroll
-  for (int r = 0; r < MREP; ++r) {
-    if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
+  for (int pr = 0; pr < 2; ++pr) {
+    const int c8 = nb * 32 + pr * 16 + (lane_e >> 5) * 8;  // my 8 consecutive output channels (bias is padded to 32)
+    const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c8);
+    const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c8 + 4);
+    bia[pr][0] = b0.x; bia[pr][1] = b0.y; bia[pr][2] = b0.z; bia[pr][3] = b0.w;
+    bia[pr][4] = b1.x; bia[pr][5] = b1.y; bia[pr][6] = b1.z; bia[pr][7] = b1.w;
+    const int n = (p.out_mode == 2 && c8 >= C2) ? 1 : 0;  // channel -> time shuffle (C2 % 8 == 0: a run never straddles)
+    c8v[pr] = c8;
+    nshv[pr] = n;
+    ccv[pr] = c8 - n * C2;
+  }
+  // Fragments go through the epilogue in batches of RB: first every output offset of the batch is computed and ALL its
+  // residual loads are issued (one dependent load -> add -> store chain per fragment cost 25 k cycles per tile on the
+  // ResnetBlock conv2 layers), then the math and the stores follow.
+  // linear output pixel of fragment r / channel pair pr for this lane, or -1 when there is nothing to store (recomputed in
+  // both passes: cheaper than 16 live registers).  32-bit: the host checks the pixel count.
+  auto locate = [&](int r, int pr) -> int {
     const int m = (wave_m * MREP + r) * 32 + (lane_e & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
     const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
-    const bool inside = to < p.To && yo < p.Ho && xo < p.Wo;
+    int tq = to, Tq = p.To;
+    if (p.out_mode == 2) {  // frame 2t+n-1; frame -1 is dropped
+      tq = 2 * to + nshv[pr] - 1;
+      Tq = 2 * p.To - 1;
+    }
+    const bool valid = to < p.To && yo < p.Ho && xo < p.Wo && c8v[pr] < p.Cout && tq >= 0;
+    const int pix = UPS == 2 ? (((b * Tq + tq) * (2 * p.Ho) + (2 * yo + py)) * (2 * p.Wo) + (2 * xo + px))
+                             : (((b * Tq + tq) * p.Ho + yo) * p.Wo + xo);
+    return valid ? pix : -1;
+  };
+  constexpr int RB = MREP >= 4 ? 4 : MREP;  // (a single batch of 8 measured the same and needs 16 more VGPRs)
 #pragma unroll
-    for (int pr = 0; pr < 2; ++pr) {
-      float v[8];
+  for (int r0 = 0; r0 < MREP; r0 += RB) {
+    uint4 rres[RB][2];
+    if (p.res) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // vdst = quad 2*pr (its upper-half lanes are exchanged), src = quad 2*pr+1 (its lower-half lanes).
-        // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) aliases the builtin's two results when they
-        // are scattered into an unrolled array (both halves came back as result 0).  The alpha multiply in front is the
-        // compiler's own VALU op, so the MFMA-result -> VALU hazard is padded by hipcc; `s_nop 1` covers the
-        // VALU-write -> v_permlane read hazard, which hipcc does not pad inside an asm statement.
-        float lo = acc[r][(2 * pr) * 4 + j] * p.alpha, hi = acc[r][(2 * pr + 1) * 4 + j] * p.alpha;
-        asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-        v[j] = lo;
-        v[4 + j] = hi;
+      for (int ri = 0; ri < RB; ++ri) {
+        const int r = r0 + ri;
+        if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          const int pix = locate(r, pr);
+          // unconditional 16-byte load (pixel 0 for lanes with nothing to store) keeps the loads branch-free
+          rres[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) +
+                                                         (long long)(pix < 0 ? 0 : pix) * (long long)p.out_ps + ccv[pr]);
+        }
       }
-      const int c8 = nb * 32 + pr * 16 + (lane_e >> 5) * 8;  // my 8 consecutive output channels
-      if (!inside || c8 >= p.Cout) continue;
-      const float4 b0 = *reinterpret_cast<const float4*>(p.bias + c8);
-      const float4 b1 = *reinterpret_cast<const float4*>(p.bias + c8 + 4);
-      v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-      v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-      int cc = c8, tq = to, Tq = p.To;
-      if (p.out_mode == 2) {  // channel -> time shuffle, drop frame -1 (C2 is a multiple of 8: an 8-run never straddles)
-        const int n = c8 >= C2 ? 1 : 0;
-        cc = c8 - n * C2;
-        tq = 2 * to + n - 1;
-        Tq = 2 * p.To - 1;
-        if (tq < 0) continue;
-      }
-      const size_t off = UPS == 2 ? ((((size_t)b * Tq + tq) * (2 * p.Ho) + (2 * yo + py)) * (size_t)(2 * p.Wo) + (2 * xo + px)) *
-                                        (size_t)p.out_ps + cc
-                                  : ((((size_t)b * Tq + tq) * p.Ho + yo) * (size_t)p.Wo + xo) * (size_t)p.out_ps + cc;
-      const bool full = (c8 + 7 < p.Cout);
-      if (p.res) {
-        const T* rp = reinterpret_cast<const T*>(p.res) + off;
-        if (full) {
+    }
+#pragma unroll
+    for (int ri = 0; ri < RB; ++ri) {
+      const int r = r0 + ri;
+      if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          // vdst = quad 2*pr (its upper-half lanes are exchanged), src = quad 2*pr+1 (its lower-half lanes).
+          // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) aliases the builtin's two results when
+          // they are scattered into an unrolled array (both halves came back as result 0).  The alpha multiply in front is
+          // the compiler's own VALU op, so the MFMA-result -> VALU hazard is padded by hipcc; `s_nop 1` covers the
+          // VALU-write -> v_permlane read hazard, which hipcc does not pad inside an asm statement.
+          float lo = acc[r][(2 * pr) * 4 + j] * p.alpha, hi = acc[r][(2 * pr + 1) * 4 + j] * p.alpha;
+          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+          v[j] = lo;
+          v[4 + j] = hi;
+        }
+        const int pix = locate(r, pr);
+        if (pix < 0) continue;
+        const long long off = (long long)pix * (long long)p.out_ps + ccv[pr];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += bia[pr][j];
+        if (p.res) {
           float rf[8];
-          unpack8<T>(*reinterpret_cast<const uint4*>(rp), rf);
+          unpack8<T>(rres[ri][pr], rf);
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += rf[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (c8 + j < p.Cout) v[j] += (float)rp[j];
         }
-      }
-      if (p.out_f32) {
-        float* o = reinterpret_cast<float*>(p.out) + off;
-        if (full) {
-          *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
+        const int c8 = c8v[pr];
+        const bool full = (c8 + 7 < p.Cout);
+        if (p.out_f32) {
+          float* o = reinterpret_cast<float*>(p.out) + off;
+          if (full) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (c8 + j < p.Cout) o[j] = v[j];
-        }
-      } else {
-        T* o = reinterpret_cast<T*>(p.out) + off;
-        if (full) {
-          const uint4 pk = pack8<T>(v);
-          *reinterpret_cast<uint4*>(o) = pk;
-          if (p.gnp) {
-            float rv[8];
-            unpack8<T>(pk, rv);
-            gc[pr] += 1.f;
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-              for (int j = 0; j < 4; ++j) {
-                gs[pr][q] += rv[q * 4 + j];
-                gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
-              }
+            for (int j = 0; j < 8; ++j)
+              if (c8 + j < p.Cout) o[j] = v[j];
           }
         } else {
+          T* o = reinterpret_cast<T*>(p.out) + off;
+          if (full) {
+            const uint4 pk = pack8<T>(v);
+            *reinterpret_cast<uint4*>(o) = pk;
+            if (p.gnp) {
+              float rv[8];
+              unpack8<T>(pk, rv);
+              gc[pr] += 1.f;
 #pragma unroll
-          for (int j = 0; j < 8; ++j)
-            if (c8 + j < p.Cout) o[j] = (T)v[j];
+              for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  gs[pr][q] += rv[q * 4 + j];
+                  gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
+                }
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              if (c8 + j < p.Cout) o[j] = (T)v[j];
+          }
         }
       }
     }

@@ -102,6 +102,7 @@ static int check_desc(const cvvae_conv_desc* d) {
   if (d->gn_rows_per_batch < 1) return CVVAE_EINVAL;
   if (d->gn_rows_per_batch > 1 && (d->kT != 1 || d->gn_rows_per_batch != d->Ti)) return CVVAE_EINVAL;
   if ((long long)d->B * d->Ti * d->Hi * d->Wi >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
+  if ((long long)d->B * (2LL * d->To) * d->Ho * d->Wo >= (1LL << 31)) return CVVAE_EUNSUPPORTED;  // 32-bit pixel indices
   return CVVAE_OK;
 }
 

@@ -16,25 +16,28 @@ using namespace cvvae;
 #endif
 //                     KT KH KW ST SH SW TT TH TW WM WN KG KSUB PRO UPS   Cin  Cout T   H    W
 #if CFG == 0   // c2d128, 2 pixel slabs x 4 N
-#define INST 1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,false
+#define INST 1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0
 static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 0;
 #elif CFG == 1 // c2d128 K-group
-#define INST 1,3,3, 1,1,1, 1,8,32, 1,4,2, 2, 1,false
+#define INST 1,3,3, 1,1,1, 1,8,32, 1,4,2, 2, 1,0
 static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 0;
 #elif CFG == 2 // enc256
-#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,false
+#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #elif CFG == 3 // enc128 2-frame tile
-#define INST 3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,false
+#define INST 3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0
 static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
 #elif CFG == 4 // c2d512
-#define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,false
+#define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0
 static const int CIN = 512, COUT = 512, TT_ = 9, HH = 128, WW = 128, PT = 0;
+#elif CFG == 7 // c2d256: ResnetBlock conv2 at 9x256^2
+#define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0
+static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 0;
 #elif CFG == 5 // enc256 without prologue (pro0) for comparison
-#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,false
+#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #elif CFG == 6 // enc256 with GN only (PRO=2: fma, no SiLU)
-#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 2,false
+#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 2,0
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #endif
 
@@ -66,6 +69,13 @@ int run() {
   a.tiles_t = (TT_ + TT - 1) / TT; a.tiles_h = HH / TH; a.tiles_w = WW / TW; a.ntiles_n = (COUT + 32 * WN - 1) / (32 * WN);
   a.nchunks = CIN / (16 * KSUB); a.nblk32 = (COUT + 31) / 32; a.order = 1; a.gn_rpb = 1; a.alpha = 1.f;
   const int grid = a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
+  if (getenv("PROBE_RES")) {  // residual add + fused GroupNorm statistics in the epilogue (what a ResnetBlock conv2 does)
+    void* res; hipMalloc(&res, npix * COUT * 2); hipMemcpy(res, in, (npix * COUT * 2 < npix * CIN * 2 ? npix * COUT * 2 : npix * CIN * 2), hipMemcpyDeviceToDevice);
+    a.res = res;
+    const int cpg = COUT / 32; int sh = 0; while ((1 << sh) < cpg) ++sh;
+    a.gn_G = 32; a.gn_sh = sh; a.gn_slabs = a.tiles_t * a.tiles_h * a.tiles_w * WM * KG * (1 << (sh - 2));
+    float* gnp; hipMalloc(&gnp, (size_t)a.gn_slabs * 32 * 3 * 4); a.gnp = gnp;
+  }
   a.dbg = dbg; a.dbg_block = getenv("PROBE_BLOCK") ? atoi(getenv("PROBE_BLOCK")) : grid / 2 + 3;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) {
