@@ -181,3 +181,60 @@ def test_device_pre_post_processing_matches_script_ops(dtype):
     got = m.decode_to_frames_u8(lat)
     assert got.dtype == torch.uint8 and got.shape == (9, 64, 96, 3)
     assert torch.equal(got.cpu(), want)
+
+
+def test_spatial_tiles_full_size_720p():
+    """BASELINE cfg-4 frame size (720x1280 -> 2x3 pixel tiles of 576/272 x 576/576/384) on one 5-frame
+    window: the wrapper's tiled encode / decode must equal encoder / decoder calls on the tiles composed with the
+    reference's blend + crop + cat rule (recomputed here with torch ops on the tile outputs), bit for bit; tile counts and
+    shapes as in the reference."""
+    dtype = torch.bfloat16
+    m, _ = build("sd3", {}, dtype, 2)
+    x = seeded_input((1, 3, 5, 720, 1280), 4).to(dtype).cuda()
+    calls = []
+    enc = m.encoder.forward
+
+    def spy(t, **kw):
+        calls.append(tuple(t.shape[-2:]))
+        return enc(t, **kw)
+
+    m.encoder.forward = spy
+    try:
+        z = m.encode(x).latent_dist.parameters
+    finally:
+        m.encoder.forward = enc
+    assert calls == [(576, 576), (576, 576), (576, 384), (272, 576), (272, 576), (272, 384)]
+    assert z.shape == (1, 32, 2, 90, 160)
+
+    def blend(a, b, o, dim):  # modeling_vae.py:647-667, on copies
+        w = (torch.arange(o, device=b.device) / o).float()
+        w = w.view(-1, 1) if dim == 3 else w
+        if dim == 3:
+            b[:, :, :, :o] = ((1 - w) * a[:, :, :, -o:].float() + w * b[:, :, :, :o].float()).to(b.dtype)
+        else:
+            b[..., :o] = ((1 - w) * a[..., -o:].float() + w * b[..., :o].float()).to(b.dtype)
+        return b
+
+    rows = []
+    for i in (0, 448):
+        cols = [m.encoder(x[:, :, :, i:i + 576, j:j + 576].contiguous()).clone() for j in (0, 448, 896)]
+        rows.append(cols)
+    out_rows = []
+    for i, cols in enumerate(rows):
+        rc = []
+        for j, t in enumerate(cols):
+            if i > 0:
+                t = blend(rows[i - 1][j], t, 16, 3)
+            if j > 0:
+                t = blend(cols[j - 1], t, 16, 4)
+            cols[j] = t
+            rc.append(t)
+        out_rows.append(rc)
+    comp = []
+    for i, cols in enumerate(out_rows):
+        cc = [t[:, :, :, :56 if i < len(out_rows) - 1 else None, :56 if j < len(cols) - 1 else None] for j, t in enumerate(cols)]
+        comp.append(torch.cat(cc, dim=4))
+    assert torch.equal(z, torch.cat(comp, dim=3))
+    y = m.decode(z[:, :16]).sample
+    assert y.shape == (1, 3, 5, 720, 1280) and torch.isfinite(y).all()
+    assert torch.equal(y, m.decode(z[:, :16]).sample)
