@@ -5,7 +5,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcvvae_hip.so")
+# CVVAE_LIB: tuning aid -- load another build of the same ABI (A/B of kernel variants); the product path is the in-tree file
+LIB_PATH = os.environ.get("CVVAE_LIB") or os.path.join(_HERE, "libcvvae_hip.so")
 
 F16, BF16, F32 = 0, 1, 2
 PAD_ZERO, PAD_REPLICATE = 0, 1
