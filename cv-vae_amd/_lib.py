@@ -45,7 +45,8 @@ PROTOTYPES = {
     "cvvae_abi_version": (_i32, []),
     "cvvae_packed_weight_bytes": (ctypes.c_size_t, [_i32, _i32, _i32]),
     "cvvae_pack_weights": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
-    "cvvae_pack_weights_upfold": (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_pack_weights_upfold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_pack_weights_fold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _vp]),
     "cvvae_conv_fwd": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_conv_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc)]),
     "cvvae_conv_gn_slabs": (_i64, [ctypes.POINTER(ConvDesc), _i32]),

@@ -34,6 +34,10 @@
 #define CVVAE_CONV_G9(X) \
   X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2) \
   X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
+// image mode (T = 1, time taps folded into the weights): strided per-frame conv and the 1x2x2 upsample phases
+#define CVVAE_CONV_G10(X) \
+  X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
+  X(1,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
 #define CVVAE_CONV_G5(X) \
   X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0)
@@ -57,4 +61,4 @@
 
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \
-  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X)
+  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X)

@@ -15,7 +15,7 @@ namespace cvvae {
 template <typename T>
 __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
                                     long long s_ci, long long s_tap, int nchunks, int ksub, T* __restrict__ dst,
-                                    long long nfrag_lanes) {
+                                    long long nfrag_lanes, int fold_n, long long s_fold) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nfrag_lanes) return;
   const int lane = (int)(gid & 63);
@@ -33,7 +33,16 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
   for (int j = 0; j < 8; ++j) {
     const int ci = ci0 + j;
     T x = (T)0.f;
-    if (co < Cout_src && ci < Cin_src) x = src[(long long)co * s_co + (long long)ci * s_ci + (long long)tap * s_tap];
+    if (co < Cout_src && ci < Cin_src) {
+      const T* e = src + (long long)co * s_co + (long long)ci * s_ci + (long long)tap * s_tap;
+      if (fold_n <= 1) {
+        x = e[0];
+      } else {  // taps that read the same input element are summed (fp32) and rounded once
+        float a = 0.f;
+        for (int f = 0; f < fold_n; ++f) a += (float)e[(long long)f * s_fold];
+        x = (T)a;
+      }
+    }
     v[j] = x;
   }
   *reinterpret_cast<typename Tr<T>::v8*>(dst + gid * 8) = v;
@@ -48,7 +57,7 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
 // taps = 12, tap = (kt*2 + a)*2 + b.
 template <typename T>
 __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin, int nchunks, T* __restrict__ dst,
-                                   long long per_phase_lanes, long long phase_stride_elems) {
+                                   long long per_phase_lanes, long long phase_stride_elems, int tfold) {
   const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid0 >= 4 * per_phase_lanes) return;
   const int phase = (int)(gid0 / per_phase_lanes);
@@ -56,11 +65,13 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
   const int py = phase >> 1, px = phase & 1;
   const int lane = (int)(gid & 63);
   long long f = gid >> 6;
-  const int tap = (int)(f % 12);
-  f /= 12;
+  const int ntap = tfold ? 4 : 12;  // tfold: the three time taps read the same (single) frame -> one 1x2x2 kernel per phase
+  const int tap = (int)(f % ntap);
+  f /= ntap;
   const int chunk = (int)(f % nchunks);
   const int nb = (int)(f / nchunks);
   const int kt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
+  const int kt_lo = tfold == 1 ? 0 : (tfold == 2 ? 1 : kt), kt_hi = tfold == 1 ? 2 : (tfold == 2 ? 1 : kt);
   // folded tap sets [lo, hi] along y and x
   const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
   const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
@@ -72,9 +83,10 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
     const int ci = ci0 + j;
     float acc = 0.f;
     if (co < Cout && ci < Cin) {
-      const T* w = src + ((long long)co * Cin + ci) * 27 + kt * 9;
-      for (int ky = y_lo; ky <= y_hi; ++ky)
-        for (int kx = x_lo; kx <= x_hi; ++kx) acc += (float)w[ky * 3 + kx];
+      const T* w = src + ((long long)co * Cin + ci) * 27;
+      for (int k = kt_lo; k <= kt_hi; ++k)
+        for (int ky = y_lo; ky <= y_hi; ++ky)
+          for (int kx = x_lo; kx <= x_hi; ++kx) acc += (float)w[k * 9 + ky * 3 + kx];
     }
     v[j] = (T)acc;
   }
@@ -574,8 +586,14 @@ size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps) {
 
 int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
                        int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream) {
+  return cvvae_pack_weights_fold(dtype, src, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst, stream);
+}
+
+int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
+                            int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad, int32_t kchunk,
+                            void* dst, void* stream) {
   if (!src || !dst || Cout_src <= 0 || Cin_src <= 0 || taps <= 0 || kchunk <= 0 || kchunk % 16 || Cin_pad % kchunk ||
-      Cin_pad < Cin_src)
+      Cin_pad < Cin_src || fold_n < 1)
     return CVVAE_EINVAL;
   // the packed layout is the same for every kernel family: [Cout/32][Cin_pad/16][tap][64 lanes][8] (k16-major);
   // kchunk only states the granularity Cin_pad was rounded to (the K-chunk of the consuming kernel instance)
@@ -585,29 +603,31 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, Cout_src, Cin_src, taps,
-                       (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (__bf16*)dst, n);
+                       (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (__bf16*)dst, n, fold_n,
+                       (long long)s_fold);
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout_src, Cin_src,
-                       taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n);
+                       taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n, fold_n,
+                       (long long)s_fold);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
 }
 
-int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, void* dst,
-                              void* stream) {
-  if (!src || !dst || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cin_pad % 16) return CVVAE_EINVAL;
-  const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16;
-  const long long per_phase = (long long)nb * nchunks * 12 * 64;
-  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, 12) / 2);
+int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t tfold,
+                              void* dst, void* stream) {
+  if (!src || !dst || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cin_pad % 16 || tfold < 0 || tfold > 2) return CVVAE_EINVAL;
+  const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16, ntap = tfold ? 4 : 12;
+  const long long per_phase = (long long)nb * nchunks * ntap * 64;
+  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, ntap) / 2);
   const int grid = (int)((4 * per_phase + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
     hipLaunchKernelGGL(pack_upfold_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, Cout, Cin, nchunks,
-                       (__bf16*)dst, per_phase, stride);
+                       (__bf16*)dst, per_phase, stride, tfold);
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_upfold_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout, Cin, nchunks,
-                       (_Float16*)dst, per_phase, stride);
+                       (_Float16*)dst, per_phase, stride, tfold);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

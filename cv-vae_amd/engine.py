@@ -44,16 +44,30 @@ class WeightCache:
         self._c[pre] = (key, pw)
         return pw
 
-    def conv_upfold(self, pre: str) -> ops.PackedConv:
-        """Upsample3D conv weights folded into the four 3x2x2 phase kernels (ops.pack_weight_upfold)."""
+    def conv_upfold(self, pre: str, tfold: int = 0) -> ops.PackedConv:
+        """Upsample3D conv weights folded into the four 3x2x2 (tfold: 1x2x2) phase kernels (ops.pack_weight_upfold)."""
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        hit = self._c.get(pre + "#upfold")
+        tag = f"{pre}#upfold{tfold}"
+        hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
-        pw = ops.pack_weight_upfold(w.detach(), b.detach())
-        self._c[pre + "#upfold"] = (key, pw)
+        pw = ops.pack_weight_upfold(w.detach(), b.detach(), tfold)
+        self._c[tag] = (key, pw)
+        return pw
+
+    def conv_t1(self, pre: str, mode: str, cin_pad: Optional[int] = None) -> ops.PackedConv:
+        """3 x kH x kW weights as the single-frame (T = 1) input sees them: time taps summed ('sum') or centre tap ('center')."""
+        w = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(w, b)
+        tag = f"{pre}#t1{mode}"
+        hit = self._c.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        pw = ops.pack_weight_t1(w.detach(), b.detach(), mode, cin_pad=cin_pad)
+        self._c[tag] = (key, pw)
         return pw
 
     def norm(self, pre: str) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -82,10 +96,30 @@ def fold_upsample() -> bool:
     return os.environ.get("CVVAE_FOLD_UPSAMPLE", "1") != "0"
 
 
+def fold_t1() -> bool:
+    """Single-frame inputs (image mode: T = 1 through the 3-D networks, e.g. the T2I pipeline's decode(z, num_frames=1)): the
+    three time taps of every 3x3x3 conv read the same frame (replicate padding) or zeros (zero padding), so the layer runs as
+    a per-frame conv with the coinciding taps summed into the weights (3x fewer MFMAs).  CVVAE_FOLD_T1=0 disables it."""
+    return os.environ.get("CVVAE_FOLD_T1", "1") != "0"
+
+
+def conv3(wc: WeightCache, x: torch.Tensor, pre: str, *, pad, pad_mode_t, pad_mode_hw, stride=(1, 1, 1), cin_pad=None, **kw):
+    """One 3x3x3 convolution of the path (CausalConv3d / Conv3d / nn.Conv3d / Downsample3D).  On a single-frame input whose
+    time padding makes the three taps coincide it runs as the temporally folded 1x3x3 conv (fold_t1)."""
+    if x.shape[1] == 1 and fold_t1() and pad[0][0] + pad[0][1] == 2:
+        pw = wc.conv_t1(pre, "sum" if pad_mode_t == REP else "center", cin_pad=cin_pad)
+        return ops.conv(x, pw, stride=(1, stride[1], stride[2]), pad=((0, 0), pad[1], pad[2]), pad_mode_hw=pad_mode_hw, **kw)
+    return ops.conv(x, wc.conv(pre, (3, 3, 3), cin_pad=cin_pad), stride=stride, pad=pad, pad_mode_t=pad_mode_t,
+                    pad_mode_hw=pad_mode_hw, **kw)
+
+
 def upsample_conv(wc: WeightCache, h: torch.Tensor, pre: str, pad, mode_t, mode_hw, up_time: bool):
     """Upsample3D.forward (vae_blocks3d_sd3.py:314-364, vae_models.py:214-235) in one launch: nearest-2x + conv + (up_time)
     channel->time shuffle and drop of frame 0; also returns the GroupNorm partials of the result."""
     om = L.OUT_TIME_SHUFFLE if up_time else L.OUT_NDHWC
+    if h.shape[1] == 1 and fold_t1() and fold_upsample() and pad[0][0] + pad[0][1] == 2:
+        return ops.conv(h, wc.conv_upfold(pre, 1 if mode_t == REP else 2), pad=((0, 0), pad[1], pad[2]), pad_mode_hw=mode_hw,
+                        upsample2x=2, out_mode=om, gn_out=G32)
     if fold_upsample():
         return ops.conv(h, wc.conv_upfold(pre), pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, upsample2x=2, out_mode=om,
                         gn_out=G32)
@@ -160,7 +194,7 @@ def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, wan
     T(2,0) or (1,1)) and into conv2 (per-frame 3x3, zero pad); 1x1 shortcut; residual add in conv2's epilogue.
     xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
-    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+    h, hp = conv3(wc, x, pre + ".conv1", pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                      prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     sc = conv1x1(wc, x, pre + ".conv_shortcut") if wc.has(pre + ".conv_shortcut.weight") else x
@@ -184,19 +218,20 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
-    h = ops.ncdhw_to_ndhwc(x, 16, dtype)
-    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+    cpad = 32 if (x.shape[2] == 1 and fold_t1()) else 16  # the folded single-frame path runs 32-channel K-chunks
+    h = ops.ncdhw_to_ndhwc(x, cpad, dtype)
+    h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                      gn_out=G32)
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"]):
             h, hp = sd3_resnet(wc, h, hp, f"down_blocks.{i}.resnets.{j}", causal)
         if i != len(boc) - 1:  # Downsample3D vae_blocks3d_sd3.py:224-239; time stride on even blocks (:115)
             st = (2, 2, 2) if i % 2 == 0 else (1, 2, 2)
-            h, hp = ops.conv(h, wc.conv(f"down_blocks.{i}.downsamplers.0.conv", (3, 3, 3)), stride=st,
+            h, hp = conv3(wc, h, f"down_blocks.{i}.downsamplers.0.conv", stride=st,
                              pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP, gn_out=G32)
     h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"])
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
-    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+    return conv3(wc, h, "conv_out", pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                     prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
 
 
@@ -207,8 +242,9 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     boc = cfg["block_out_channels"]
     pad = PC if causal else P1
     zin = z.shape[1]
-    h = ops.ncdhw_to_ndhwc(z, ops.round_up(zin, 16), dtype)
-    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
+    cpad = ops.round_up(zin, 32 if (z.shape[2] == 1 and fold_t1()) else 16)
+    h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
+    h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
                      gn_out=G32)
     h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"])
     for i in range(len(boc)):
@@ -218,7 +254,7 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
             up_time = i % 2 == 0
             h, hp = upsample_conv(wc, h, f"up_blocks.{i}.upsamplers.0.conv", pad, REP, REP, up_time)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
-    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
+    return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
 
 
@@ -235,7 +271,7 @@ def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want
     xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
     pad, mt, mhw = _v3_pad(causal)
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-5)
-    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU,
+    h, hp = conv3(wc, x, pre + ".conv1", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU,
                      gn=g1, gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-5)
     sc = conv1x1(wc, x, pre + ".nin_shortcut") if wc.has(pre + ".nin_shortcut.weight") else x
@@ -250,21 +286,22 @@ def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
-    h = ops.ncdhw_to_ndhwc(x, 16, dtype)
-    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=16), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, gn_out=G32)
+    cpad = 32 if (x.shape[2] == 1 and fold_t1()) else 16  # the folded single-frame path runs 32-channel K-chunks
+    h = ops.ncdhw_to_ndhwc(x, cpad, dtype)
+    h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, gn_out=G32)
     for lvl in range(nlev):
         for j in range(cfg["num_res_blocks"]):
             h, hp = v3_resnet(wc, h, hp, f"down.{lvl}.block.{j}", causal)
         if lvl != nlev - 1:  # Downsample3D vae_models.py:251-263: zero pad right/bottom, replicate T front 2
             st = (2, 2, 2) if lvl % 2 == 0 else (1, 2, 2)
-            h, hp = ops.conv(h, wc.conv(f"down.{lvl}.downsample.conv", (3, 3, 3)), stride=st, pad=((2, 0), (0, 1), (0, 1)),
+            h, hp = conv3(wc, h, f"down.{lvl}.downsample.conv", stride=st, pad=((2, 0), (0, 1), (0, 1)),
                              pad_mode_t=REP, pad_mode_hw=ZERO, gn_out=G32)
     h, _ = v3_resnet(wc, h, hp, "mid.block_1", causal, want_stats=False)
     a = "mid.attn_1"
     h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True, gn_out=G32)
     h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
-    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
+    return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
 
 
@@ -288,8 +325,9 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
     zin = z.shape[1]
-    h = ops.ncdhw_to_ndhwc(z, ops.round_up(zin, 16), dtype)
-    h, hp = ops.conv(h, wc.conv("conv_in", (3, 3, 3), cin_pad=ops.round_up(zin, 16)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw,
+    cpad = ops.round_up(zin, 32 if (z.shape[2] == 1 and fold_t1()) else 16)
+    h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
+    h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw,
                      gn_out=G32)
     h, _ = v3_resnet(wc, h, hp, "mid.block_1", causal, want_stats=False)
     h, hp = v3_attn_spatial_temporal(wc, h, "mid.attn_1")
@@ -301,5 +339,5 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
             up_time = lvl % 2 == 1
             h, hp = upsample_conv(wc, h, f"up.{lvl}.upsample.conv", P1, REP, ZERO, up_time)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
-    return ops.conv(h, wc.conv("conv_out", (3, 3, 3)), pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
+    return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)

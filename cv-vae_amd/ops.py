@@ -50,7 +50,7 @@ class PackedConv:
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
                 strides: Optional[Tuple[int, int, int]] = None, cout: Optional[int] = None, cin: Optional[int] = None,
-                out: Optional[torch.Tensor] = None) -> PackedConv:
+                out: Optional[torch.Tensor] = None, fold: Tuple[int, int] = (1, 0), offset: int = 0) -> PackedConv:
     """Pack a conv / linear weight ([Cout, Cin, *k] contiguous, or any strided view described by `strides` =
     (s_co, s_ci, s_tap) in elements) into MFMA fragment order for cvvae_conv_fwd."""
     lib = L.load()
@@ -69,8 +69,11 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     if out is None:
         out = torch.zeros(nbytes, dtype=torch.uint8, device=w.device)
     assert out.numel() * out.element_size() >= nbytes
-    L.check(lib.cvvae_pack_weights(dt, w.data_ptr(), cout_, cin_, taps, strides[0], strides[1], strides[2], cin_pad, ck,
-                                   out.data_ptr(), _stream()), "cvvae_pack_weights")
+    # fold = (n, stride): every packed element is the sum of n source elements `stride` apart (coinciding taps);
+    # offset: element offset of the first source element (e.g. the centre time tap)
+    L.check(lib.cvvae_pack_weights_fold(dt, w.data_ptr() + offset * w.element_size(), cout_, cin_, taps, strides[0],
+                                        strides[1], strides[2], fold[0], fold[1], cin_pad, ck, out.data_ptr(), _stream()),
+            "cvvae_pack_weights_fold")
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
@@ -87,9 +90,20 @@ class GNPartials:
     groups: int
 
 
-def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin_pad: Optional[int] = None) -> PackedConv:
+    """[Cout, Cin, 3, kH, kW] weight -> the 1 x kH x kW weight a single-frame input sees: mode 'sum' (replicate time padding:
+    all three time taps read the one frame) or 'center' (zero time padding: only the centre tap reads data)."""
+    assert w.dim() == 5 and w.shape[2] == 3 and mode in ("sum", "center")
+    w = w.contiguous()
+    co, ci, _, kh, kw = w.shape
+    hw = kh * kw
+    return pack_weight(w, bias, (1, kh, kw), cin_pad=cin_pad, strides=(ci * 3 * hw, 3 * hw, 1), cout=co, cin=ci,
+                       fold=(3, hw) if mode == "sum" else (1, 0), offset=0 if mode == "sum" else hw)
+
+
+def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int = 0) -> PackedConv:
     """Upsample3D's conv weight [Cout, Cin, 3, 3, 3] -> the four folded 3x2x2 phase weights (cvvae_pack_weights_upfold) for
-    conv(..., upsample2x=2)."""
+    conv(..., upsample2x=2).  tfold 1 / 2 (single-frame input: time taps summed / centre tap only): 1x2x2 phases."""
     lib = L.load()
     _need_gpu(w)
     dt = _dt(w.dtype)
@@ -97,14 +111,14 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedC
     cout_, cin_ = w.shape[0], w.shape[1]
     assert w.numel() == cout_ * cin_ * 27
     cin_pad = round_up(cin_, 32)
-    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 12)
+    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 4 if tfold else 12)
     out = torch.zeros(4 * per, dtype=torch.uint8, device=w.device)
-    L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, out.data_ptr(), _stream()),
+    L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, tfold, out.data_ptr(), _stream()),
             "cvvae_pack_weights_upfold")
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, cout_, cin_pad, (3, 3, 3), cin_, folded=True)
+    return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True)
 
 
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,

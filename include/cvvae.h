@@ -97,8 +97,24 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
 
 /* Fold + pack for upsample2x == 2: src = torch conv weight [Cout][Cin][3][3][3] (contiguous, dtype); dst = 4 phase buffers
  * of cvvae_packed_weight_bytes(Cout, Cin_pad, 12) bytes each, back to back (phase = 2*py + px). */
-int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, void* dst,
-                              void* stream);
+int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t tfold,
+                              void* dst, void* stream);
+
+/*
+ * Single-frame ("image mode", T = 1: the T2I pipeline's decode(latents, num_frames=1), BASELINE config 1) inputs: every
+ * 3x3x3 conv of the path pads time to 3 frames, so its three time taps read the SAME frame (replicate padding:
+ * CausalConv3d / Conv3d / Upsample3D / Downsample3D) or two of them read zeros (nn.Conv3d(padding=1) of the vae3d decoder).
+ * The taps that coincide are summed into the weights (fp32 sum, one rounding) and the layer runs as a 1x3x3 (or 1x2x2
+ * phase) convolution: 3x fewer MFMAs, same result up to that rounding.
+ *   cvvae_pack_weights_fold = cvvae_pack_weights whose source element is the sum of fold_n elements s_fold apart
+ *     (fold_n = 3, s_fold = kH*kW on a [Cout][Cin][3][kH][kW] weight: replicate time padding; fold_n = 1 with src advanced to
+ *     the centre tap: zero time padding);
+ *   tfold of cvvae_pack_weights_upfold: 0 = keep the 3 time taps (12 taps per phase), 1 = sum them, 2 = centre tap only
+ *     (4 taps per phase; used with kT = 1, upsample2x = 2).
+ */
+int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
+                            int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad, int32_t kchunk,
+                            void* dst, void* stream);
 
 int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                    const void* residual, const float* gn_scale, const float* gn_shift, void* out, void* stream);

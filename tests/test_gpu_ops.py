@@ -164,6 +164,47 @@ def test_conv333_upsample_folded(dtype, mode_hw, shuffle):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", ["sum", "center", "sum_down", "sum_up", "center_up_shuffle"])
+def test_conv333_single_frame_temporal_fold(dtype, case):
+    """Image mode (T = 1): a 3x3x3 conv whose time padding makes its three taps read the one frame (replicate) or zeros
+    (zero padding) runs as a 1x3x3 / 1x2x2-phase conv with the coinciding taps summed into the weights
+    (cvvae_pack_weights_fold, tfold of cvvae_pack_weights_upfold).  Reference: the unfolded conv3d on the padded frame."""
+    ops, L = _ops()
+    Cin, Cout = 256, 256
+    mode_t = ZERO if case.startswith("center") else REP
+    stride = (2, 2, 2) if case == "sum_down" else (1, 1, 1)
+    ups = case.endswith("up") or case.endswith("up_shuffle")
+    shuffle = case.endswith("shuffle")
+    padt = (2, 0) if case == "sum_down" else (1, 1)
+    B, H, W = 2, 12, 20
+    x = rnd((B, Cin, 1, H, W), dtype, 1, 1.0)
+    w = rnd((Cout, Cin, 3, 3, 3), dtype, 2, 1.0 / (Cin * 27) ** 0.5)
+    bias = rnd((Cout,), torch.float32, 3, 0.1)
+    xr = x.float()
+    if ups:
+        xr = F.interpolate(xr, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+    xr = ref_pad(xr, (padt, (1, 1), (1, 1)), mode_t, REP)
+    ref = F.conv3d(xr, w.float(), bias, stride=stride)
+    if shuffle:
+        b_, nc, t_, h_, w_ = ref.shape
+        ref = ref.reshape(b_, 2, nc // 2, t_, h_, w_).permute(0, 2, 3, 1, 4, 5).reshape(b_, nc // 2, 2 * t_, h_, w_)[:, :, 1:]
+    xd = to_ndhwc(x).to(DEV)
+    if ups:
+        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), 2 if mode_t == ZERO else 1)
+        out = ops.conv(xd, pw, pad=((0, 0), (1, 1), (1, 1)), pad_mode_hw=REP, upsample2x=2,
+                       out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC)
+    else:
+        pw = ops.pack_weight_t1(w.to(DEV), bias.to(DEV), "center" if mode_t == ZERO else "sum")
+        out = ops.conv(xd, pw, stride=(1, stride[1], stride[2]), pad=((0, 0), (1, 1), (1, 1)), pad_mode_hw=REP)
+    torch.cuda.synchronize()
+    got = to_ncdhw(out.float().cpu())
+    assert got.shape == ref.shape, (got.shape, ref.shape)
+    base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (got - ref).abs().max().item()
+    assert err <= 2 * base * ref.abs().max().item() + 1e-6, err
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_conv333_upsample_vae3d_pad(dtype):
     # vae3d Upsample3D: nearest x2, zero pad W,H, replicate T (1,1), no time upsampling (vae_models.py:218-229)
     run_conv_case(dtype, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, ZERO, (1, 3, 8, 16), ups=True)
