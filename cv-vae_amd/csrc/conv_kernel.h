@@ -73,6 +73,9 @@ struct ConvArgs {
   // per-phase output dims (= Ti/Hi/Wi); output pixel (y, x) of phase (py, px) is stored at (2y+py, 2x+px) of a
   // 2Ho x 2Wo frame; phase weights are w + phase * w_phase_stride (elements)
   long long w_phase_stride;
+  // sub-range launches (an odd frame count is covered by a two-frame-tile launch over [0, To-1) plus a one-frame-tile
+  // launch for the last frame): first output frame of this launch, and its first pixel-tile index inside a batch row
+  int t_begin, tile_base;
   int order;     // logical tile order: 1 = (ntile, t, x, y, b) fastest-first, 0 = (ntile, x, y, t, b)
   int gn_rpb;
   float alpha;
@@ -216,8 +219,11 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     tt_i = mt % p.tiles_t;
     b = mt / p.tiles_t;
   }
-  const int t0 = tt_i * TT, y0 = th_i * TH, x0 = tw_i * TW;
-  const int tile_in_b = (tt_i * p.tiles_h + th_i) * p.tiles_w + tw_i;  // pixel-tile index inside batch row b
+  const int t0 = tt_i * TT + p.t_begin, y0 = th_i * TH, x0 = tw_i * TW;
+  const int tile_in_b = p.tile_base + (tt_i * p.tiles_h + th_i) * p.tiles_w + tw_i;  // pixel-tile index inside batch row b
+  // time-shuffle stores drop output frame -1 = channels [0, Cout/2) of conv frame 0: a workgroup whose whole tile is that
+  // is done before it starts (the host zero-fills the GroupNorm records, so the missing ones read as empty)
+  if (UPS != 1 && TT == 1 && p.out_mode == 2 && t0 == 0 && (ntile + 1) * G::BN <= (p.Cout >> 1)) return;
 
   // ---- staging plan (chunk independent): which stored pixel feeds each of my halo slots
   const int tl = tid & 255;

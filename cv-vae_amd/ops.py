@@ -185,7 +185,9 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
         if slabs <= 0:
             L.check(int(slabs), "cvvae_conv_gn_slabs")
         cst = cout // 2 if out_mode == L.OUT_TIME_SHUFFLE else cout
-        part = GNPartials(torch.empty((B, slabs, gn_out, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
+        # time-shuffle outputs: workgroups whose whole tile is the dropped frame exit without writing their records
+        alloc = torch.zeros if out_mode == L.OUT_TIME_SHUFFLE else torch.empty
+        part = GNPartials(alloc((B, slabs, gn_out, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
 
     def launch():
         L.check(lib.cvvae_conv_fwd_gn(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),

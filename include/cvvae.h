@@ -127,6 +127,8 @@ int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packe
  * out_partials: [B][slabs][out_groups][3] fp32 records (n, mean, M2) of the ROUNDED stored values, one per pixel tile /
  * wave slab / 4-channel slot, slabs = cvvae_conv_gn_slabs(d, out_groups); every record is written exactly once (no
  * atomics: results are bit-reproducible).  cvvae_gn_finalize merges them (Chan, fixed order) into the affine table.
+ * With out_mode = TIME_SHUFFLE the caller ZERO-FILLS out_partials first: workgroups whose whole tile is the dropped frame
+ * (channels [0, Cout/2) of conv frame 0) exit early and leave their records untouched (an all-zero record is empty).
  * out_groups = 0 and out_partials = NULL: identical to cvvae_conv_fwd.
  */
 int64_t cvvae_conv_gn_slabs(const cvvae_conv_desc* d, int32_t out_groups);
