@@ -40,7 +40,9 @@
   X(1,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
 #define CVVAE_CONV_G5(X) \
   X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
-  X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0)
+  X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0) \
+  X(3,3,3, 2,2,2, 1,8,16, 1,8,1, 1, 0,0) \
+  X(3,3,3, 1,2,2, 1,8,16, 1,8,1, 1, 0,0)
 // 1x3x3 per-frame conv (ResnetBlock conv2), K-chunk 32 channels
 #define CVVAE_CONV_G6(X) \
   X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 0,0) \

@@ -27,6 +27,9 @@ CASES = {
     "up256to512": (256, 512, (3, 3, 3), 9, 256, 256, P1, 0, True),    # the 16.7 TFLOP upsample conv
     "upfold256to512": (256, 512, (3, 3, 3), 9, 256, 256, P1, 0, 2),  # the same conv as four folded 3x2x2 phase convs
     "upfold512": (512, 512, (3, 3, 3), 9, 128, 128, P1, 0, 2),
+    "down128": (128, 128, (3, 3, 3), 17, 512, 512, PC, 0, False),     # encoder downsamplers (stride set below)
+    "down256": (256, 256, (3, 3, 3), 9, 256, 256, PC, 0, False),
+    "down512": (512, 512, (3, 3, 3), 9, 128, 128, PC, 0, False),
     "c2d128": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
     "c2d512": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
     "out128to3": (128, 3, (3, 3, 3), 17, 512, 512, P1, 1, False),
@@ -65,7 +68,11 @@ def main():
         gn = None
         if pro:
             gn = ops.gn_stats(x, torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), 1e-6)
-        kw = dict(pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
+        if name.startswith("down"):
+            stride = (1, 2, 2) if name == "down256" else (2, 2, 2)
+        else:
+            stride = (1, 1, 1)
+        kw = dict(stride=stride, pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
                   gn=gn, upsample2x=ups, out_mode=L.OUT_NCDHW if cout <= 32 else L.OUT_NDHWC)
         npix = None
         best = {}
