@@ -1,7 +1,7 @@
 // conv_kernel.h -- implicit-GEMM convolution for CDNA4 (gfx950): the hot kernel of the CV-VAE codec.
 //
-// One workgroup = 512 threads = 8 wave64.  It owns an output tile of BM = TT*TH*TW pixels x BN = 32*WN
-// output channels and walks K = taps x Cin in chunks of CK = 16*KSUB input channels:
+// One workgroup = 512 threads = 8 wave64 (2 per SIMD, one workgroup per CU).  It owns an output tile of
+// BM = TT*TH*TW pixels x BN = 32*WN output channels and walks K = taps x Cin in chunks of CK = 16*KSUB input channels:
 //
 //   * the INPUT HALO TILE of the chunk ((TT-1)*sT+kT) x ((TH-1)*sH+kH) x ((TW-1)*sW+kW) pixels x CK channels
 //     is staged ONCE into LDS (register-staged: pad-mode / nearest-2x coordinate mapping, GroupNorm affine +
@@ -9,15 +9,23 @@
 //     im2col is then pure LDS addressing: tap (dt,dy,dx) is an immediate offset on the ds_read_b128.
 //     Pixel stride in LDS is CK*2+16 bytes, which makes every 16-lane ds_read_b128 group conflict-free.
 //   * the halo tile is DOUBLE BUFFERED and the 8 waves are split in two groups with opposite phase order
-//     (X: stage next chunk -> MFMA; Y: MFMA -> stage next chunk), so on every SIMD one wave's staging VALU /
-//     global-load latency hides under its partner's MFMA stream.  One s_barrier per chunk.
-//   * WEIGHTS never go through LDS: they are pre-packed in MFMA-fragment order (cvvae_pack_weights) and each
+//     (X: stage next chunk -> MFMA; Y: MFMA -> stage next chunk).  One s_barrier per chunk.
+//   * WEIGHTS never go through LDS: they are pre-packed in MFMA-fragment order (cvvae_pack_weights*) and each
 //     wave streams its own 32-output-channel slice straight HBM/L2 -> VGPR (1 KiB per wave per k16 step,
 //     contiguous, software-prefetched PF steps ahead).
 //   * MFMA is v_mfma_f32_32x32x16 with SWAPPED operands (A = weights, B = activations): the accumulator
-//     lane then holds, for ONE pixel, 4 consecutive output channels per register quad -> 8-byte NDHWC stores.
+//     lane then holds, for ONE pixel, 4 consecutive output channels per register quad; the epilogue pairs the
+//     half-waves with v_permlane32_swap so every lane stores 16 bytes (8 channels) at a time.
+//   * WM x WN x KG = 8 waves: WM pixel slabs x WN 32-channel blocks x KG K-groups (KG = 2: the two wave groups
+//     split the chunk's channels and reduce their accumulators through LDS).
+//   * UPS = 1: nearest-2x gather fused into the staging; UPS = 2: the upsample folded into four 3x2x2 phase
+//     convolutions over the stored input (phase = 2 extra bits of the logical tile index).
+//   * the epilogue optionally emits GroupNorm statistics of what it stores (one (n, mean, M2) record per pixel tile,
+//     wave slab and 4-channel slot; no atomics).
+//   * logical tile order: N-tile (and phase) fastest, then time, x, y, batch; XCD-aware bijective block remap.
 //
-// Reference semantics implemented here (file:line in /root/reference): see include/cvvae.h.
+// Reference semantics implemented here (file:line in /root/reference): see include/cvvae.h.  Design notes and
+// measurements: DESIGN.md section 3.1.  -DCVVAE_CONV_PROBE adds s_memtime stamps (tools/conv_probe.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -262,9 +270,6 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   int probe_n = 0;
 #endif
   auto stage = [&](int chunk, int bufsel) {
-#ifdef CVVAE_STAGE_PRIO
-    __builtin_amdgcn_s_setprio(CVVAE_STAGE_PRIO);
-#endif
     const int c0 = chunk * CK + sq * 8;
     float sc[8], sh[8];
     if (PRO != 0) {
@@ -316,9 +321,6 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         }
       }
     }
-#ifdef CVVAE_STAGE_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
   };
 
   // ---- MFMA plan
