@@ -1,0 +1,38 @@
+#!/usr/bin/env python
+"""Per-launch timing of one encode+decode step (HIP events around every conv launch): where the step's time goes, layer by
+layer.  usage (GPU box): python tools/layer_times.py [--workload cfg3]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import cvvae_amd
+from cvvae_amd import ops
+
+torch.manual_seed(0)
+dtype = torch.bfloat16
+vae = cvvae_amd.CVVAESD3Model().to(dtype).cuda().eval()
+x = (torch.rand((1, 3, 17, 512, 512)) * 2 - 1).to(dtype).cuda()
+rec = []
+
+
+def obs(d, pw, launch):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); launch(); e1.record()
+    fl = 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * pw.cin_real * d.kT * d.kH * d.kW
+    rec.append((ops.conv_kernel_name(d), (d.Ti, d.Hi, d.Wi, d.Cin), (d.To, d.Ho, d.Wo, d.Cout), fl, e0, e1))
+
+
+for it in range(2):
+    rec.clear()
+    ops.PROFILE = obs if it == 1 else None
+    z = vae.encode(x).latent_dist.mode()
+    n_enc = len(rec)
+    y = vae.decode(z).sample
+    torch.cuda.synchronize()
+ops.PROFILE = None
+tot = 0.0
+for i, (name, ishp, oshp, fl, e0, e1) in enumerate(rec):
+    ms = e0.elapsed_time(e1)
+    tot += ms
+    print(f"{'enc' if i < n_enc else 'dec'} {i:3d} {name:48s} in {str(ishp):22s} out {str(oshp):22s} {ms:7.3f} ms {fl / ms / 1e9:7.1f} TF")
+print(f"sum of conv launches {tot:.2f} ms")
