@@ -81,6 +81,7 @@ struct ConvArgs {
   // per-phase output dims (= Ti/Hi/Wi); output pixel (y, x) of phase (py, px) is stored at (2y+py, 2x+px) of a
   // 2Ho x 2Wo frame; phase weights are w + phase * w_phase_stride (elements)
   long long w_phase_stride;
+  long long w_bstride;  // elements between the packed weights of consecutive batch items (0: shared)
   // sub-range launches (an odd frame count is covered by a two-frame-tile launch over [0, To-1) plus a one-frame-tile
   // launch for the last frame): first output frame of this launch, and its first pixel-tile index inside a batch row
   int t_begin, tile_base;
@@ -334,7 +335,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16 +
                          kgrp * (KSUB / KG) * 32);
   }
-  const T* wq = reinterpret_cast<const T*>(p.w) + (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
+  const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
+                (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
                 (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512) + lane * 8;
   v8 wf[PF];
 #pragma unroll

@@ -110,6 +110,7 @@ static int check_desc(const cvvae_conv_desc* d) {
   if (d->out_mode == CVVAE_OUT_TIME_SHUFFLE && (d->Cout % 16)) return CVVAE_EINVAL;
   if (d->prologue < 0 || d->prologue > 2) return CVVAE_EINVAL;
   if (d->upsample2x < 0 || d->upsample2x > 2) return CVVAE_EINVAL;
+  if (d->w_batch_stride < 0 || d->w_batch_stride % 16) return CVVAE_EINVAL;
   if (d->upsample2x == 2 && ((d->kT != 3 && d->kT != 1) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pad_h != 1 ||
                              d->pad_w != 1 || d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi || d->out_mode == CVVAE_OUT_NCDHW))
     return CVVAE_EUNSUPPORTED;
@@ -188,6 +189,7 @@ int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_pa
   a.Cin = d->Cin;
   a.in_ps = d->in_pix_stride;
   a.To = d->To; a.Ho = fold ? d->Ho / 2 : d->Ho; a.Wo = fold ? d->Wo / 2 : d->Wo; a.Cout = d->Cout;  // per-phase grid when folded
+  a.w_bstride = d->w_batch_stride / 2;
   a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;

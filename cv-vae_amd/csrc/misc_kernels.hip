@@ -15,9 +15,12 @@ namespace cvvae {
 template <typename T>
 __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
                                     long long s_ci, long long s_tap, int nchunks, int ksub, T* __restrict__ dst,
-                                    long long nfrag_lanes, int fold_n, long long s_fold) {
+                                    long long nfrag_lanes, int fold_n, long long s_fold, long long s_batch,
+                                    long long d_batch) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nfrag_lanes) return;
+  src += (long long)blockIdx.y * s_batch;  // batch item (grid.y)
+  dst += (long long)blockIdx.y * d_batch;
   const int lane = (int)(gid & 63);
   long long f = gid >> 6;
   const int ks = (int)(f % ksub);
@@ -589,9 +592,28 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
   return cvvae_pack_weights_fold(dtype, src, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst, stream);
 }
 
+static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src, int32_t Cin_src,
+                     int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad,
+                     int32_t kchunk, void* dst, int64_t d_batch_bytes, void* stream);
+
 int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
                             int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad, int32_t kchunk,
                             void* dst, void* stream) {
+  return pack_impl(dtype, src, 1, 0, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, fold_n, s_fold, Cin_pad, kchunk, dst, 0, stream);
+}
+
+int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src,
+                               int32_t Cin_src, int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad,
+                               int32_t kchunk, void* dst, int64_t dst_batch_stride, void* stream) {
+  if (batch <= 0 || dst_batch_stride % 16 || (size_t)dst_batch_stride < cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps))
+    return CVVAE_EINVAL;
+  return pack_impl(dtype, src, batch, s_batch, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst,
+                   dst_batch_stride, stream);
+}
+
+static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src, int32_t Cin_src,
+                     int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad,
+                     int32_t kchunk, void* dst, int64_t d_batch_bytes, void* stream) {
   if (!src || !dst || Cout_src <= 0 || Cin_src <= 0 || taps <= 0 || kchunk <= 0 || kchunk % 16 || Cin_pad % kchunk ||
       Cin_pad < Cin_src || fold_n < 1)
     return CVVAE_EINVAL;
@@ -602,13 +624,13 @@ int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, in
   const int grid = (int)((n + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
-    hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, Cout_src, Cin_src, taps,
-                       (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (__bf16*)dst, n, fold_n,
-                       (long long)s_fold);
+    hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid, batch), dim3(256), 0, s, (const __bf16*)src, Cout_src, Cin_src,
+                       taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (__bf16*)dst, n, fold_n,
+                       (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2));
   else if (dtype == CVVAE_F16)
-    hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout_src, Cin_src,
-                       taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n, fold_n,
-                       (long long)s_fold);
+    hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid, batch), dim3(256), 0, s, (const _Float16*)src, Cout_src,
+                       Cin_src, taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n,
+                       fold_n, (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2));
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

@@ -175,14 +175,14 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
     vv = ops.conv(xf, wc.conv(v, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
     npad = ops.round_up(N, 128)
     vt = ops.transpose(vv.view(B * T, N, C))                          # [BT, C, N]
-    o = torch.empty((B * T, 1, 1, N, C), dtype=x.dtype, device=x.device)
     scale = float(C) ** -0.5
-    for f in range(B * T):
-        kp = ops.pack_weight(kk[f], None, (1, 1, 1), cin_pad=C, strides=(C, 1, 0), cout=N, cin=C)
-        s = ops.conv(qq[f].view(1, 1, 1, N, C), kp, out_f32=True, alpha=scale, cout_pad=npad)   # [1,1,1,N,npad] fp32
-        p = ops.softmax_rows(s.view(N, npad), N, x.dtype)                                      # [N, npad]
-        vp = ops.pack_weight(vt[f], None, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
-        ops.conv(p.view(1, 1, 1, N, npad), vp, out=o[f].view(1, 1, 1, N, C))
+    # every frame's K (and V^T) is a weight matrix of its own: packed in one launch, consumed by ONE batched conv launch
+    # (cvvae_conv_desc.w_batch_stride) -- QK^T with fp32 scores, softmax, PV
+    kp = ops.pack_weight_batched(kk.view(B * T, N, C), (1, 1, 1), cin_pad=C, strides=(C, 1, 0), cout=N, cin=C)
+    s = ops.conv(qq, kp, out_f32=True, alpha=scale, cout_pad=npad)                              # [BT,1,1,N,npad] fp32
+    p = ops.softmax_rows(s.view(B * T * N, npad), N, x.dtype)                                  # [BT*N, npad]
+    vp = ops.pack_weight_batched(vt, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
+    o = ops.conv(p.view(B * T, 1, 1, N, npad), vp)                                             # [BT,1,1,N,C]
     return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 

@@ -39,13 +39,14 @@ def round_up(x: int, m: int) -> int:
 
 @dataclass
 class PackedConv:
-    w: torch.Tensor          # packed, fragment order (opaque bytes)
+    w: torch.Tensor          # packed, fragment order (opaque bytes); [batch, bytes] when batch_stride > 0
     bias: torch.Tensor       # fp32, padded to a multiple of 32
     cout: int
     cin: int                 # padded input channels the kernel consumes (multiple of kchunk)
     k: Tuple[int, int, int]
     cin_real: int = 0        # channels of the source weight (algorithmic FLOP accounting)
     folded: bool = False     # packed by pack_weight_upfold: only valid with conv(..., upsample2x=2)
+    batch_stride: int = 0    # bytes between the packed weights of consecutive batch items (pack_weight_batched)
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
@@ -88,6 +89,25 @@ class GNPartials:
     slabs: int
     C: int
     groups: int
+
+
+def pack_weight_batched(w: torch.Tensor, k: Tuple[int, int, int], cin_pad: int, strides: Tuple[int, int, int], cout: int,
+                        cin: int) -> PackedConv:
+    """w: [batch, ...] (contiguous per item); item i is packed from w[i] read with `strides` (s_co, s_ci, s_tap): one
+    launch for the per-frame K / V^T matrices of the attention blocks.  Used with conv() on a [batch, ...] input."""
+    lib = L.load()
+    _need_gpu(w)
+    dt = _dt(w.dtype)
+    assert w.is_contiguous()
+    batch = w.shape[0]
+    taps = k[0] * k[1] * k[2]
+    per = round_up(lib.cvvae_packed_weight_bytes(cout, cin_pad, taps), 16)
+    out = torch.zeros((batch, per), dtype=torch.uint8, device=w.device)
+    L.check(lib.cvvae_pack_weights_batched(dt, w.data_ptr(), batch, w[0].numel(), cout, cin, taps, strides[0], strides[1],
+                                           strides[2], cin_pad, kchunk(k), out.data_ptr(), per, _stream()),
+            "cvvae_pack_weights_batched")
+    b = torch.zeros(round_up(cout, 32), dtype=torch.float32, device=w.device)
+    return PackedConv(out, b, cout, cin_pad, tuple(k), cin, batch_stride=per)
 
 
 def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin_pad: Optional[int] = None) -> PackedConv:
@@ -157,6 +177,8 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.out_mode = out_mode
     d.out_f32 = 1 if out_f32 else 0
     d.alpha = alpha
+    d.w_batch_stride = pw.batch_stride
+    assert pw.batch_stride == 0 or pw.w.shape[0] == B, "batched weights: one packed set per batch item of the input"
     odt = torch.float32 if out_f32 else x.dtype
     if out_mode == L.OUT_NCDHW:
         shape = (B, cout, To, Ho, Wo)

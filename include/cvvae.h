@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 2
+#define CVVAE_ABI_VERSION 3
 
 enum { CVVAE_F16 = 0, CVVAE_BF16 = 1 };                       /* cvvae dtype */
 enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
@@ -80,6 +80,9 @@ typedef struct cvvae_conv_desc {
   int32_t out_f32;            /* 1: store fp32 (NDHWC only), else dtype */
   int64_t out_pix_stride;     /* NDHWC modes: elements between pixels of `out` and of `residual` (multiple of 8) */
   float alpha;                /* out = alpha*acc + bias (+ residual) */
+  int64_t w_batch_stride;     /* 0: one packed weight set for every batch item; else batch item b uses
+                                 w_packed + b*w_batch_stride BYTES (a multiple of 16): per-frame K / V^T of the attention
+                                 blocks, so QK^T and PV of all frames are one launch each */
 } cvvae_conv_desc;
 
 /* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */
@@ -112,6 +115,11 @@ int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int3
  *   tfold of cvvae_pack_weights_upfold: 0 = keep the 3 time taps (12 taps per phase), 1 = sum them, 2 = centre tap only
  *     (4 taps per phase; used with kT = 1, upsample2x = 2).
  */
+/* batch of `batch` packings in one launch: item i reads src + i*s_batch elements and writes dst + i*dst_batch_stride bytes
+ * (dst_batch_stride >= cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps), multiple of 16) */
+int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src,
+                               int32_t Cin_src, int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad,
+                               int32_t kchunk, void* dst, int64_t dst_batch_stride, void* stream);
 int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
                             int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad, int32_t kchunk,
                             void* dst, void* stream);
