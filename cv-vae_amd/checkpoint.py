@@ -9,7 +9,6 @@ configs/cvvae_sd3_constraint_training.yaml:10-37).  `convert_training_checkpoint
 diffusers-style directory the drop-in classes read.  No GPU is needed for any of this.
 """
 import argparse
-import os
 from typing import Dict, Optional
 
 import torch

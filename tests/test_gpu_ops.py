@@ -129,9 +129,6 @@ def test_conv333_cout128_two_frame_tiles_and_odd_frame_split(dtype, T):
     # 128-channel 3x3x3 layers run two-frame tiles; an odd frame count is split into a two-frame-tile launch over
     # [0, T-1) and a one-frame-tile launch for the last frame (cvvae_api.hip odd_frame_sibling) -- conv numerics of both
     # launches against conv3d, with the fused GroupNorm+SiLU prologue and a residual
-    L = _ops()[1]
-    ops, _ = _ops()
-    d = L.ConvDesc()
     run_conv_case(dtype, 128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, T, 16, 32), prologue=1,
                   residual=True)
 
