@@ -55,8 +55,9 @@ def parse():
 
 
 def conv_flops(d, pw):
-    taps = d.kT * d.kH * d.kW
-    return 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * pw.cin_real * taps
+    # ALGORITHMIC work of the reference op: folded forms count the taps of the op they replace; + the fused 1x1 shortcut
+    taps = getattr(pw, "alg_taps", 0) or d.kT * d.kH * d.kW
+    return 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * (pw.cin_real * taps + d.sc_Cin)
 
 
 def roofline_pass(step_fn):

@@ -12,7 +12,7 @@ F16, BF16, F32 = 0, 1, 2
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class ConvDesc(ctypes.Structure):
@@ -36,6 +36,8 @@ class ConvDesc(ctypes.Structure):
         ("out_pix_stride", ctypes.c_int64),
         ("alpha", ctypes.c_float),
         ("w_batch_stride", ctypes.c_int64),
+        ("sc_Cin", ctypes.c_int32), ("sc_reserved", ctypes.c_int32),
+        ("sc_in_pix_stride", ctypes.c_int64),
     ]
 
 
@@ -53,6 +55,7 @@ PROTOTYPES = {
     "cvvae_conv_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc)]),
     "cvvae_conv_gn_slabs": (_i64, [ctypes.POINTER(ConvDesc), _i32]),
     "cvvae_conv_fwd_gn": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "cvvae_conv_fwd_gn_sc": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "cvvae_gn_finalize": (_i32, [_vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_gn_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cvvae_gn_stats": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),

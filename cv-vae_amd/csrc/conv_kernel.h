@@ -30,6 +30,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace cvvae {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -82,6 +84,12 @@ struct ConvArgs {
   // 2Ho x 2Wo frame; phase weights are w + phase * w_phase_stride (elements)
   long long w_phase_stride;
   long long w_bstride;  // elements between the packed weights of consecutive batch items (0: shared)
+  // fused 1x1 shortcut (1x3x3 instances): after the K loop over `in`, nchunks2 more chunks over `in2` (same B,T,H,W, no
+  // prologue) through the centre tap only, with the 1x1 weights w2 -- ResnetBlock conv2 + conv_shortcut in one accumulator
+  const void* in2;
+  const void* w2;
+  long long in2_ps;
+  int nchunks2;
   // sub-range launches (an odd frame count is covered by a two-frame-tile launch over [0, To-1) plus a one-frame-tile
   // launch for the last frame): first output frame of this launch, and its first pixel-tile index inside a batch row
   int t_begin, tile_base;
@@ -270,10 +278,11 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #ifdef CVVAE_CONV_PROBE
   int probe_n = 0;
 #endif
-  auto stage = [&](int chunk, int bufsel) {
+  auto stage_from = [&](auto pro_tag, const T* __restrict__ src, size_t src_ps, int chunk, int bufsel) {
+    constexpr int PRO_ = decltype(pro_tag)::value;  // prologue applied to THIS source (the shortcut input has none)
     const int c0 = chunk * CK + sq * 8;
     float sc[8], sh[8];
-    if (PRO != 0) {
+    if (PRO_ != 0) {
       const float4* ps = reinterpret_cast<const float4*>(p.gsc + gn_row + c0);
       const float4* pb = reinterpret_cast<const float4*>(p.gsh + gn_row + c0);
       float4 a0 = ps[0], a1 = ps[1], b0 = pb[0], b1 = pb[1];
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         if (k < NPASS) {
           // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
           const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
-          raw[kk] = *reinterpret_cast<const uint4*>(inp + (size_t)sp * (size_t)p.in_ps + c0);
+          raw[kk] = *reinterpret_cast<const uint4*>(src + (size_t)sp * src_ps + c0);
         }
       }
 #ifdef CVVAE_CONV_PROBE
@@ -307,13 +316,13 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         if (k < NPASS) {
           if (srcpix[k] == -2) continue;
           uint4 o = raw[kk];
-          if (PRO != 0) {
+          if (PRO_ != 0) {
             float f[8];
             unpack8<T>(raw[kk], f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               float v = f[j] * sc[j] + sh[j];
-              f[j] = (PRO == 1) ? silu_f(v) : v;
+              f[j] = (PRO_ == 1) ? silu_f(v) : v;
             }
             o = pack8<T>(f);
           }
@@ -322,6 +331,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         }
       }
     }
+  };
+  auto stage = [&](int chunk, int bufsel) {
+    stage_from(std::integral_constant<int, PRO>{}, inp, (size_t)p.in_ps, chunk, bufsel);
   };
 
   // ---- MFMA plan
@@ -391,6 +403,38 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     if (grp == 1 && more) stage(c + 1, cur ^ 1);
     CVVAE_PROBE_MARK();
     __syncthreads();
+  }
+  // ---- fused 1x1 shortcut: more K chunks over the second input through the centre tap (the final barrier of the loop
+  //      above has released both halo buffers)
+  if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0) {
+    if (p.in2 != nullptr) {
+      const T* __restrict__ inp2 = reinterpret_cast<const T*>(p.in2);
+      auto stage2 = [&](int chunk, int bufsel) {
+        stage_from(std::integral_constant<int, 0>{}, inp2, (size_t)p.in2_ps, chunk, bufsel);
+      };
+      constexpr unsigned ctr = (unsigned)((1 * G::FW + 1) * PIXB);  // centre tap (dy = dx = 1)
+      const T* w2q = reinterpret_cast<const T*>(p.w2) + (size_t)(active ? nb : 0) * (size_t)p.nchunks2 * (KSUB * 512) + lane * 8;
+      stage2(0, 0);
+      __syncthreads();
+      for (int c = 0; c < p.nchunks2; ++c) {
+        const int cur = c & 1;
+        const bool more = (c + 1) < p.nchunks2;
+        if (grp == 0 && more) stage2(c + 1, cur ^ 1);
+        if (active) {
+          const unsigned lb = (unsigned)(cur * G::BUFB);
+          v8 wv[KSUB];
+#pragma unroll
+          for (int ks = 0; ks < KSUB; ++ks) wv[ks] = *reinterpret_cast<const v8*>(w2q + ((size_t)c * KSUB + ks) * 512);
+#pragma unroll
+          for (int ks = 0; ks < KSUB; ++ks)
+#pragma unroll
+            for (int r = 0; r < MREP; ++r)
+              acc[r] = Tr<T>::mfma(wv[ks], *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + ctr + ks * 32]), acc[r]);
+        }
+        if (grp == 1 && more) stage2(c + 1, cur ^ 1);
+        __syncthreads();
+      }
+    }
   }
   CVVAE_PROBE_MARK();
   // ---- K-group reduction (KG == 2): group 0 keeps fragments [0,H) and parks [H,MREP) in LDS, group 1 the opposite;

@@ -52,6 +52,7 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     if (e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
     if (e.pro != d->prologue || e.ups != d->upsample2x) continue;
     if (d->Cin % (16 * e.ksub)) continue;  // the instance's K-chunk must divide the consumed channels
+    if (d->sc_Cin && (e.kg != 1 || e.ups != 0 || d->sc_Cin % (16 * e.ksub))) continue;  // fused shortcut: KG = 1 instances
     const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
     // per-phase output grid for the folded upsample (4 phases of Ho/2 x Wo/2), the output grid otherwise
     const long long tiles = fold ? cdiv(d->To, e.tt) * cdiv(d->Ho / 2, e.th) * cdiv(d->Wo / 2, e.tw) * d->B * 4
@@ -111,6 +112,9 @@ static int check_desc(const cvvae_conv_desc* d) {
   if (d->prologue < 0 || d->prologue > 2) return CVVAE_EINVAL;
   if (d->upsample2x < 0 || d->upsample2x > 2) return CVVAE_EINVAL;
   if (d->w_batch_stride < 0 || d->w_batch_stride % 16) return CVVAE_EINVAL;
+  if (d->sc_Cin < 0 || (d->sc_Cin && (d->sc_in_pix_stride < d->sc_Cin || d->sc_in_pix_stride % 8))) return CVVAE_EINVAL;
+  if (d->sc_Cin && (d->kT != 1 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->upsample2x))
+    return CVVAE_EUNSUPPORTED;
   if (d->upsample2x == 2 && ((d->kT != 3 && d->kT != 1) || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->pad_h != 1 ||
                              d->pad_w != 1 || d->Ho != 2 * d->Hi || d->Wo != 2 * d->Wi || d->out_mode == CVVAE_OUT_NCDHW))
     return CVVAE_EUNSUPPORTED;
@@ -162,9 +166,27 @@ int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packe
   return cvvae_conv_fwd_gn(d, in, w_packed, bias, residual, gn_scale, gn_shift, out, 0, nullptr, stream);
 }
 
+static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+                     const float* gn_scale, const float* gn_shift, const void* sc_in, const void* sc_w, void* out,
+                     int32_t out_groups, float* out_partials, void* stream);
+
 int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                       const float* gn_scale, const float* gn_shift, void* out, int32_t out_groups, float* out_partials,
                       void* stream) {
+  if (d && d->sc_Cin) return CVVAE_EINVAL;  // a descriptor with a shortcut goes through cvvae_conv_fwd_gn_sc
+  return conv_impl(d, in, w_packed, bias, residual, gn_scale, gn_shift, nullptr, nullptr, out, out_groups, out_partials, stream);
+}
+
+int cvvae_conv_fwd_gn_sc(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
+                         const float* gn_scale, const float* gn_shift, const void* sc_in, const void* sc_w_packed, void* out,
+                         int32_t out_groups, float* out_partials, void* stream) {
+  if (!d || !d->sc_Cin || !sc_in || !sc_w_packed) return CVVAE_EINVAL;
+  return conv_impl(d, in, w_packed, bias, nullptr, gn_scale, gn_shift, sc_in, sc_w_packed, out, out_groups, out_partials, stream);
+}
+
+static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
+                     const float* gn_scale, const float* gn_shift, const void* sc_in, const void* sc_w, void* out,
+                     int32_t out_groups, float* out_partials, void* stream) {
   int rc = check_desc(d);
   if (rc != CVVAE_OK) return rc;
   if ((out_groups != 0) != (out_partials != nullptr)) return CVVAE_EINVAL;
@@ -190,6 +212,12 @@ int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_pa
   a.in_ps = d->in_pix_stride;
   a.To = d->To; a.Ho = fold ? d->Ho / 2 : d->Ho; a.Wo = fold ? d->Wo / 2 : d->Wo; a.Cout = d->Cout;  // per-phase grid when folded
   a.w_bstride = d->w_batch_stride / 2;
+  if (sc_in) {
+    a.in2 = sc_in;
+    a.w2 = sc_w;
+    a.in2_ps = d->sc_in_pix_stride;
+    a.nchunks2 = d->sc_Cin / (16 * e->ksub);
+  }
   a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;

@@ -70,6 +70,19 @@ class WeightCache:
         self._c[tag] = (key, pw)
         return pw
 
+    def bias_sum(self, pre_a: str, pre_b: str) -> torch.Tensor:
+        """fp32 b_a + b_b padded to a multiple of 32: the bias of a conv with a fused 1x1 shortcut"""
+        ba, bb = self.m.get_parameter(pre_a + ".bias"), self.m.get_parameter(pre_b + ".bias")
+        key = self._key(ba, bb)
+        tag = f"{pre_a}+{pre_b}#bias"
+        hit = self._c.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        out = torch.zeros(ops.round_up(ba.numel(), 32), dtype=torch.float32, device=ba.device)
+        out[:ba.numel()] = ba.detach().float() + bb.detach().float()
+        self._c[tag] = (key, out)
+        return out
+
     def norm(self, pre: str) -> Tuple[torch.Tensor, torch.Tensor]:
         g = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
@@ -94,6 +107,25 @@ def fold_upsample() -> bool:
     with folded weights (2.25x fewer MFMAs; differs from the 27-tap form only by one rounding of each folded weight).
     CVVAE_FOLD_UPSAMPLE=0 selects the 27-tap gather form (bit-for-bit the reference's summation terms)."""
     return os.environ.get("CVVAE_FOLD_UPSAMPLE", "1") != "0"
+
+
+def fuse_shortcut() -> bool:
+    """ResnetBlock3D with a channel change: conv2 and the 1x1 shortcut accumulate in the same MFMA registers (one launch;
+    the shortcut tensor never goes through HBM).  CVVAE_FUSE_SHORTCUT=0 runs the shortcut as its own 1x1 conv launch."""
+    return os.environ.get("CVVAE_FUSE_SHORTCUT", "1") != "0"
+
+
+def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
+    """conv2 (per-frame 3x3 over GN+SiLU(h), zero pad) + shortcut(x) + add -- vae_blocks3d_sd3.py:559-567, vae_models.py:404-410."""
+    pw2 = wc.conv(pre + ".conv2", (1, 3, 3))
+    kw = dict(pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2, gn_out=G32 if want_stats else 0)
+    if not wc.has(sc_name + ".weight"):
+        y = ops.conv(h, pw2, residual=x, **kw)
+    elif fuse_shortcut():
+        y = ops.conv(h, pw2, shortcut=(x, wc.conv(sc_name, (1, 1, 1))), bias=wc.bias_sum(pre + ".conv2", sc_name), **kw)
+    else:
+        y = ops.conv(h, pw2, residual=conv1x1(wc, x, sc_name), **kw)
+    return y if want_stats else (y, None)
 
 
 def fold_t1() -> bool:
@@ -197,10 +229,7 @@ def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, wan
     h, hp = conv3(wc, x, pre + ".conv1", pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                      prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
-    sc = conv1x1(wc, x, pre + ".conv_shortcut") if wc.has(pre + ".conv_shortcut.weight") else x
-    y = ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
-                 residual=sc, gn_out=G32 if want_stats else 0)
-    return y if want_stats else (y, None)
+    return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
 
 
 def sd3_mid(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, attention: bool):
@@ -274,10 +303,7 @@ def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want
     h, hp = conv3(wc, x, pre + ".conv1", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU,
                      gn=g1, gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-5)
-    sc = conv1x1(wc, x, pre + ".nin_shortcut") if wc.has(pre + ".nin_shortcut.weight") else x
-    y = ops.conv(h, wc.conv(pre + ".conv2", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2,
-                 residual=sc, gn_out=G32 if want_stats else 0)
-    return y if want_stats else (y, None)
+    return resnet_tail(wc, x, h, pre, pre + ".nin_shortcut", g2, want_stats)
 
 
 def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:

@@ -47,6 +47,7 @@ class PackedConv:
     cin_real: int = 0        # channels of the source weight (algorithmic FLOP accounting)
     folded: bool = False     # packed by pack_weight_upfold: only valid with conv(..., upsample2x=2)
     batch_stride: int = 0    # bytes between the packed weights of consecutive batch items (pack_weight_batched)
+    alg_taps: int = 0        # taps of the REFERENCE op when the packed weights are a folded form (0: kT*kH*kW)
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
@@ -117,8 +118,10 @@ def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin
     w = w.contiguous()
     co, ci, _, kh, kw = w.shape
     hw = kh * kw
-    return pack_weight(w, bias, (1, kh, kw), cin_pad=cin_pad, strides=(ci * 3 * hw, 3 * hw, 1), cout=co, cin=ci,
-                       fold=(3, hw) if mode == "sum" else (1, 0), offset=0 if mode == "sum" else hw)
+    pw = pack_weight(w, bias, (1, kh, kw), cin_pad=cin_pad, strides=(ci * 3 * hw, 3 * hw, 1), cout=co, cin=ci,
+                     fold=(3, hw) if mode == "sum" else (1, 0), offset=0 if mode == "sum" else hw)
+    pw.alg_taps = 3 * hw
+    return pw
 
 
 def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int = 0) -> PackedConv:
@@ -138,16 +141,19 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True)
+    return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True, alg_taps=27)
 
 
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
          pad_mode_hw=L.PAD_ZERO, prologue=L.PRO_NONE, gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          gn_per_frame=False, residual: Optional[torch.Tensor] = None, upsample2x=False, out_mode=L.OUT_NDHWC,
+         shortcut: Optional[Tuple[torch.Tensor, "PackedConv"]] = None, bias: Optional[torch.Tensor] = None,
          out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None, gn_out: int = 0):
     """x: [B,T,H,W,Cs] with Cs >= pw.cin.  pad = ((t_front,t_back),(h_front,h_back),(w_front,w_back)).
     Returns [B,To,Ho,Wo,Cout(_pad)] (NDHWC), [B,2To-1,Ho,Wo,Cout/2] (TIME_SHUFFLE) or [B,Cout,To,Ho,Wo] (NCDHW).
-    gn_out = G > 0: also returns the GNPartials of the stored tensor for a following G-group GroupNorm (gn_finalize)."""
+    gn_out = G > 0: also returns the GNPartials of the stored tensor for a following G-group GroupNorm (gn_finalize).
+    shortcut = (x2, pw2): fused 1x1 shortcut -- out = conv(x) + pw2 . x2 + bias, x2 [B,T,H,W,C2] (same pixels as x), pw2 a
+    packed (1,1,1) weight; `bias` then overrides pw.bias (the caller passes b_conv + b_shortcut, fp32, padded to 32)."""
     lib = L.load()
     _need_gpu(x)
     assert x.dim() == 5 and x.is_contiguous()
@@ -178,6 +184,13 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.out_f32 = 1 if out_f32 else 0
     d.alpha = alpha
     d.w_batch_stride = pw.batch_stride
+    if shortcut is not None:
+        x2, pw2 = shortcut
+        assert residual is None and x2.shape[:4] == x.shape[:4] and x2.is_contiguous() and x2.dtype == x.dtype
+        assert pw2.k == (1, 1, 1) and pw2.cout == cout and x2.shape[-1] >= pw2.cin
+        d.sc_Cin, d.sc_in_pix_stride = pw2.cin, x2.shape[-1]
+    bias_t = pw.bias if bias is None else bias
+    assert bias_t.dtype == torch.float32 and bias_t.numel() >= round_up(cout, 32)
     assert pw.batch_stride == 0 or pw.w.shape[0] == B, "batched weights: one packed set per batch item of the input"
     odt = torch.float32 if out_f32 else x.dtype
     if out_mode == L.OUT_NCDHW:
@@ -212,7 +225,15 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
         part = GNPartials(alloc((B, slabs, gn_out, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
 
     def launch():
-        L.check(lib.cvvae_conv_fwd_gn(d, x.data_ptr(), pw.w.data_ptr(), pw.bias.data_ptr(),
+        if shortcut is not None:
+            L.check(lib.cvvae_conv_fwd_gn_sc(d, x.data_ptr(), pw.w.data_ptr(), bias_t.data_ptr(),
+                                             gsc.data_ptr() if gsc is not None else None,
+                                             gsh.data_ptr() if gsh is not None else None, shortcut[0].data_ptr(),
+                                             shortcut[1].w.data_ptr(), out.data_ptr(), gn_out,
+                                             part.buf.data_ptr() if part is not None else None, _stream()),
+                    "cvvae_conv_fwd_gn_sc")
+            return
+        L.check(lib.cvvae_conv_fwd_gn(d, x.data_ptr(), pw.w.data_ptr(), bias_t.data_ptr(),
                                       residual.data_ptr() if residual is not None else None,
                                       gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
                                       out.data_ptr(), gn_out, part.buf.data_ptr() if part is not None else None, _stream()),

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 3
+#define CVVAE_ABI_VERSION 4
 
 enum { CVVAE_F16 = 0, CVVAE_BF16 = 1 };                       /* cvvae dtype */
 enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
@@ -83,6 +83,10 @@ typedef struct cvvae_conv_desc {
   int64_t w_batch_stride;     /* 0: one packed weight set for every batch item; else batch item b uses
                                  w_packed + b*w_batch_stride BYTES (a multiple of 16): per-frame K / V^T of the attention
                                  blocks, so QK^T and PV of all frames are one launch each */
+  /* fused 1x1 shortcut (cvvae_conv_fwd_gn_sc; 1x3x3 stride-1 convolutions): channels and pixel stride of the second input */
+  int32_t sc_Cin;             /* multiple of the instance's K-chunk (32) */
+  int32_t sc_reserved;
+  int64_t sc_in_pix_stride;
 } cvvae_conv_desc;
 
 /* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */
@@ -143,6 +147,16 @@ int64_t cvvae_conv_gn_slabs(const cvvae_conv_desc* d, int32_t out_groups);
 int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                       const void* residual, const float* gn_scale, const float* gn_shift, void* out, int32_t out_groups,
                       float* out_partials, void* stream);
+/*
+ * ResnetBlock3D tail in ONE launch: conv2 (per-frame 3x3 over GroupNorm+SiLU(h)) + conv_shortcut / nin_shortcut (1x1 over the
+ * block input x) + the add (models/vae_blocks3d_sd3.py:559-567, models/vae_models.py:404-410): out = conv2(h) + W_sc x + bias,
+ * where `bias` is the caller's b_conv2 + b_shortcut.  sc_in is NDHWC [B,Ti,Hi,Wi] with d->sc_Cin channels (pixel stride
+ * d->sc_in_pix_stride), sc_w_packed = cvvae_pack_weights of the [Cout][sc_Cin] shortcut weight (taps = 1).  The shortcut
+ * tensor is never written to or read back from HBM.  Requires kT,kH,kW = (1,3,3), stride 1; no residual pointer.
+ */
+int cvvae_conv_fwd_gn_sc(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
+                         const float* gn_scale, const float* gn_shift, const void* sc_in, const void* sc_w_packed, void* out,
+                         int32_t out_groups, float* out_partials, void* stream);
 int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_t C, int32_t groups, float eps,
                       const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 

@@ -229,6 +229,40 @@ def test_conv133_prologue_residual(dtype, Cout):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("Cx,C", [(256, 128), (128, 256), (256, 512)])
+def test_conv133_fused_shortcut(dtype, Cx, C):
+    """ResnetBlock tail in one launch (cvvae_conv_fwd_gn_sc): per-frame 3x3 over GN+SiLU(h) + 1x1 shortcut over x + biases,
+    with fused output statistics; reference = conv2d + 1x1 conv + add on the same rounded inputs."""
+    ops, L = _ops()
+    B, T, H, W = 2, 3, 17, 33
+    h = rnd((B, C, T, H, W), dtype, 1, 1.0)
+    x = rnd((B, Cx, T, H, W), dtype, 2, 1.0)
+    w2 = rnd((C, C, 1, 3, 3), dtype, 3, 1.0 / (C * 9) ** 0.5)
+    ws = rnd((C, Cx, 1, 1, 1), dtype, 4, 1.0 / Cx ** 0.5)
+    b2, bs = rnd((C,), torch.float32, 5, 0.1), rnd((C,), torch.float32, 6, 0.1)
+    gamma, beta = 1.0 + rnd((C,), torch.float32, 7, 0.1), rnd((C,), torch.float32, 8, 0.1)
+    ha = F.group_norm(h.float(), 32, gamma, beta, 1e-6)
+    ha = ha * torch.sigmoid(ha)
+    ref = F.conv3d(F.pad(ha, (1, 1, 1, 1, 0, 0)), w2.float(), b2) + F.conv3d(x.float(), ws.float(), bs)
+    hd, xd = to_ndhwc(h).to(DEV), to_ndhwc(x).to(DEV)
+    pw2 = ops.pack_weight(w2.reshape(C, C, 9).to(DEV), b2.to(DEV), (1, 3, 3))
+    pws = ops.pack_weight(ws.reshape(C, Cx, 1).to(DEV), bs.to(DEV), (1, 1, 1))
+    gn = ops.gn_stats(hd, gamma.to(DEV), beta.to(DEV), 1e-6)
+    out, part = ops.conv(hd, pw2, pad=((0, 0), (1, 1), (1, 1)), prologue=L.PRO_GN_SILU, gn=gn, shortcut=(xd, pws),
+                         bias=pw2.bias + pws.bias, gn_out=32)
+    torch.cuda.synchronize()
+    got = to_ncdhw(out.float().cpu())
+    base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    err = (got - ref).abs().max().item()
+    assert err <= 3 * base * ref.abs().max().item() + 1e-6, err
+    one, zero = torch.ones(C, device=DEV), torch.zeros(C, device=DEV)
+    sc_f, sh_f = ops.gn_finalize(part, one, zero, 1e-6)
+    sc_s, sh_s = ops.gn_stats(out, one, zero, 1e-6)
+    assert (sc_f - sc_s).abs().max().item() <= 2e-5 * sc_s.abs().max().item()
+    assert (sh_f - sh_s).abs().max().item() <= 2e-5 * max(sh_s.abs().max().item(), 1.0)
+
+
+@pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("Cout", [256, 128])
 def test_conv111_shortcut(dtype, Cout):
     run_conv_case(dtype, 128, Cout, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), ZERO, ZERO, (1, 3, 10, 52))

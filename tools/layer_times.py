@@ -18,7 +18,7 @@ rec = []
 def obs(d, pw, launch):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); launch(); e1.record()
-    fl = 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * pw.cin_real * d.kT * d.kH * d.kW
+    fl = 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * (pw.cin_real * (pw.alg_taps or d.kT * d.kH * d.kW) + d.sc_Cin)
     rec.append((ops.conv_kernel_name(d), (d.Ti, d.Hi, d.Wi, d.Cin), (d.To, d.Ho, d.Wo, d.Cout), fl, e0, e1))
 
 
