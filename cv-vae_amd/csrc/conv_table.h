@@ -8,10 +8,12 @@
 // Order inside a family = preference when the cost model ties (first wins).
 #pragma once
 
-// 3x3x3 stride 1, BN = 256 (Cout >= 256): all 8 waves side by side in N
+// 3x3x3 stride 1, BN = 256 (Cout >= 256): all 8 waves side by side in N; the 128-pixel tile is for small frames, where
+// 256-pixel tiles leave the last round of workgroups mostly empty (e.g. 288 workgroups on 256 CUs)
 #define CVVAE_CONV_G1(X) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0) \
-  X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0)
+  X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0)
 // 3x3x3 stride 1, BN = 128 (Cout = 128): 4 N-blocks x 2 K-groups over a 32-channel chunk, reduced through LDS
 #define CVVAE_CONV_G2(X) \
   X(3,3,3, 1,1,1, 1,8,32, 1,4,2, 2, 0,0) \

@@ -1,5 +1,6 @@
 // cvvae_api.hip -- extern "C" entry for the convolution: argument checking, tile/instance selection, launch.
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -34,6 +35,19 @@ static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// compute units of the current device (256 on MI355X); used by the instance cost model only
+static int cu_count() {
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;  // no device visible (CPU-side symbol / argument tests)
+  }
+  return cus;
+}
+
 // pick the instance with the least padded work (tile overhang x inactive N waves); ties -> table order
 static const Instance* select_instance(const cvvae_conv_desc* d) {
   const Instance* best = nullptr;
@@ -65,6 +79,16 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     cost *= 1.0 + 0.04 * halo * 256.0 / (double)bn;
     // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
     cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
+    if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)
+    // round quantisation: a grid of W workgroups runs in ceil(W / #CUs) rounds of one workgroup per CU
+    {
+      // (per batch item, so that the choice -- hence the summation order, hence every bit of the result -- does not
+      //  depend on how many clips are coded together)
+      const double wgs = (double)tiles / (double)d->B * (double)ntn, cus = (double)cu_count();
+      // (half weight: measured, a partly filled last round costs less than its share -- the busy CUs clock higher)
+      static const int quant = getenv("CVVAE_CONV_QUANT") ? atoi(getenv("CVVAE_CONV_QUANT")) : 1;  // tuning aid
+      if (quant) cost *= 1.0 + 0.5 * (ceil(wgs / cus) / (wgs / cus) - 1.0);
+    }
     if (!best || cost < best_cost) {
       best = &e;
       best_cost = cost;

@@ -22,6 +22,7 @@ CASES = {
     "enc128": (128, 128, (3, 3, 3), 17, 512, 512, PC, 1, False),      # 128->128 @17x512^2 (config B)
     "enc256": (256, 256, (3, 3, 3), 9, 256, 256, PC, 1, False),       # 256->256 @9x256^2 (config A)
     "enc512": (512, 512, (3, 3, 3), 9, 128, 128, PC, 1, False),
+    "mid512_64": (512, 512, (3, 3, 3), 9, 64, 64, P1, 1, False),      # vae3d cfg 2: 288 workgroups with 256-pixel tiles
     "dec512s": (512, 512, (3, 3, 3), 5, 64, 64, P1, 1, False),
     "dec256to128": (256, 128, (3, 3, 3), 17, 512, 512, P1, 1, False),
     "up256to512": (256, 512, (3, 3, 3), 9, 256, 256, P1, 0, True),    # the 16.7 TFLOP upsample conv
@@ -75,11 +76,13 @@ def main():
         kw = dict(stride=stride, pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
                   gn=gn, upsample2x=ups, out_mode=L.OUT_NCDHW if cout <= 32 else L.OUT_NDHWC)
         npix = None
-        best = {}
+        best, kname = {}, {}
         for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
             for f in forces:
                 setenv(f)
+                ops.PROFILE = lambda d, pw_, launch, f=f: (kname.__setitem__(f, ops.conv_kernel_name(d)), launch())
                 y = ops.conv(x, pw, **kw)
+                ops.PROFILE = None
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -94,7 +97,7 @@ def main():
         for f in forces:
             ms = sorted(best[f])[len(best[f]) // 2]
             print(f"{name:12s} force={f or '-':22s} median {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  min {min(best[f]):8.3f} ms "
-                  f"({fl / 1e9:.0f} GFLOP)", flush=True)
+                  f"({fl / 1e9:.0f} GFLOP)  {kname.get(f, '')}", flush=True)
     setenv("")
 
 
