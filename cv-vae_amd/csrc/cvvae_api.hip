@@ -259,6 +259,10 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.order = 1;
   if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
   a.alpha = d->alpha;
+  // tuning aid (tools/tune_instances.py re-launches recorded calls under CVVAE_CONV_FORCE: the record table was sized for
+  // the default instance, another one would overrun it)
+  static const bool nostats = getenv("CVVAE_CONV_TUNE_NOSTATS") != nullptr;
+  if (nostats) out_partials = nullptr;
   if (out_partials) {
     const int sh = gn_shift_of(d, out_groups);
     if (sh < 0) return CVVAE_EUNSUPPORTED;
