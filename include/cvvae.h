@@ -36,8 +36,9 @@ enum {
   CVVAE_EUNSUPPORTED = -2 /* shape or option combination with no kernel instance */
 };
 
-/* Kernel families of cvvae_conv_fwd.  The packed-weight layout depends on the family's K-chunk
- * (channels staged per LDS pass): 16 for 3x3x3, 32 for 1x3x3, 128 for 1x1x1. */
+/* Kernel families of cvvae_conv_fwd: the granularity the consumed channel count (Cin, and Cin_pad of the packed weights)
+ * must be a multiple of -- 16 for 3x3x3, 32 for 1x3x3, 128 for 1x1x1.  The packed-weight LAYOUT is the same for every
+ * family: [Cout/32][Cin_pad/16][tap][64 lanes][8]. */
 static inline int cvvae_conv_kchunk(int kT, int kH, int kW) {
   return (kT == 3 && kH == 3 && kW == 3) ? 16 : (kT == 1 && kH == 3 && kW == 3) ? 32 : (kT == 1 && kH == 1 && kW == 1) ? 128 : 0;
 }
@@ -93,7 +94,7 @@ typedef struct cvvae_conv_desc {
 size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps);
 
 /*
- * Pack weights into MFMA-fragment order: [Cout/32][Cin/kchunk][tap][kchunk/16][64 lanes][8].
+ * Pack weights into MFMA-fragment order: [Cout/32][Cin_pad/16][tap][64 lanes][8].
  * src element (co, ci, tap) is read at src[co*s_co + ci*s_ci + tap*s_tap] (dtype elements), so the same entry
  * packs torch conv weights [Cout][Cin][kT*kH*kW] (s_co=Cin_src*taps, s_ci=taps, s_tap=1), nn.Linear weights, and
  * per-frame attention K / V^T matrices produced on the device.  co >= Cout_src or ci >= Cin_src pack as 0.
