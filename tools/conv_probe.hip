@@ -69,9 +69,11 @@ int run() {
   a.tiles_t = (TT_ + TT - 1) / TT; a.tiles_h = HH / TH; a.tiles_w = WW / TW; a.ntiles_n = (COUT + 32 * WN - 1) / (32 * WN);
   a.nchunks = CIN / (16 * KSUB); a.nblk32 = (COUT + 31) / 32; a.order = 1; a.gn_rpb = 1; a.alpha = 1.f;
   const int grid = a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
-  if (getenv("PROBE_RES")) {  // residual add + fused GroupNorm statistics in the epilogue (what a ResnetBlock conv2 does)
-    void* res; hipMalloc(&res, npix * COUT * 2); hipMemcpy(res, in, (npix * COUT * 2 < npix * CIN * 2 ? npix * COUT * 2 : npix * CIN * 2), hipMemcpyDeviceToDevice);
-    a.res = res;
+  if (getenv("PROBE_RES") || getenv("PROBE_STATS")) {  // PROBE_RES: residual add + fused GroupNorm statistics in the epilogue
+    if (getenv("PROBE_RES")) {                          // (what a ResnetBlock conv2 does); PROBE_STATS: statistics only (conv1)
+      void* res; hipMalloc(&res, npix * COUT * 2); hipMemcpy(res, in, (npix * COUT * 2 < npix * CIN * 2 ? npix * COUT * 2 : npix * CIN * 2), hipMemcpyDeviceToDevice);
+      a.res = res;
+    }
     const int cpg = COUT / 32; int sh = 0; while ((1 << sh) < cpg) ++sh;
     a.gn_G = 32; a.gn_sh = sh; a.gn_slabs = a.tiles_t * a.tiles_h * a.tiles_w * WM * KG * (1 << (sh - 2));
     float* gnp; hipMalloc(&gnp, (size_t)a.gn_slabs * 32 * 3 * 4); a.gnp = gnp;
