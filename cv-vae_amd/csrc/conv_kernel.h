@@ -541,26 +541,35 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // Fragments go through the epilogue in batches of RB: first every output offset of the batch is computed and ALL its
   // residual loads are issued (one dependent load -> add -> store chain per fragment cost 25 k cycles per tile on the
   // ResnetBlock conv2 layers), then the math and the stores follow.
-  // linear output pixel of fragment r / channel pair pr for this lane, or -1 when there is nothing to store (recomputed in
-  // both passes: cheaper than 16 live registers).  32-bit: the host checks the pixel count.
-  auto locate = [&](int r, int pr) -> int {
+  // Output pixel of a fragment for this lane, computed ONCE per fragment (it cost ~20 VALU ops per call when it was redone
+  // for every channel pair and pass): the pixel of the n = 0 channel half, or NOPIX when the lane is outside the tensor.
+  // 32-bit: the host checks the pixel count.  Time-shuffle stores: the n = 1 half lands one frame later (+ frame_px), and the
+  // n = 0 half of conv frame 0 is the dropped frame -1.
+  constexpr int NOPIX = -2147483647 - 1;
+  const int frame_px = (UPS == 2 ? 4 : 1) * p.Ho * p.Wo;
+  auto locate = [&](int r, bool& first_frame) -> int {
     const int m = (wave_m * MREP + r) * 32 + (lane_e & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
     const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
-    int tq = to, Tq = p.To;
-    if (p.out_mode == 2) {  // frame 2t+n-1; frame -1 is dropped
-      tq = 2 * to + nshv[pr] - 1;
-      Tq = 2 * p.To - 1;
-    }
-    const bool valid = to < p.To && yo < p.Ho && xo < p.Wo && c8v[pr] < p.Cout && tq >= 0;
+    first_frame = to == 0;
+    const int tq = p.out_mode == 2 ? 2 * to - 1 : to, Tq = p.out_mode == 2 ? 2 * p.To - 1 : p.To;
     const int pix = UPS == 2 ? (((b * Tq + tq) * (2 * p.Ho) + (2 * yo + py)) * (2 * p.Wo) + (2 * xo + px))
                              : (((b * Tq + tq) * p.Ho + yo) * p.Wo + xo);
-    return valid ? pix : -1;
+    return (to < p.To && yo < p.Ho && xo < p.Wo) ? pix : NOPIX;
+  };
+  // pixel of channel pair pr given the fragment's pixel, or -1 when there is nothing to store
+  auto pix_of = [&](int pixr, bool first_frame, int pr) -> int {
+    const bool valid = pixr != NOPIX && c8v[pr] < p.Cout && !(p.out_mode == 2 && first_frame && nshv[pr] == 0);
+    return valid ? pixr + nshv[pr] * frame_px : -1;
   };
   constexpr int RB = MREP >= 4 ? 4 : MREP;  // (a single batch of 8 measured the same and needs 16 more VGPRs)
 #pragma unroll
   for (int r0 = 0; r0 < MREP; r0 += RB) {
     uint4 rres[RB][2];
+    int pixr[RB];
+    bool ff[RB];
+#pragma unroll
+    for (int ri = 0; ri < RB; ++ri) pixr[ri] = locate(r0 + ri, ff[ri]);
     if (p.res) {
 #pragma unroll
       for (int ri = 0; ri < RB; ++ri) {
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          const int pix = locate(r, pr);
+          const int pix = pix_of(pixr[ri], ff[ri], pr);
           // unconditional 16-byte load (pixel 0 for lanes with nothing to store) keeps the loads branch-free
           rres[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) +
                                                          (long long)(pix < 0 ? 0 : pix) * (long long)p.out_ps + ccv[pr]);
@@ -594,7 +603,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
           v[j] = lo;
           v[4 + j] = hi;
         }
-        const int pix = locate(r, pr);
+        const int pix = pix_of(pixr[ri], ff[ri], pr);
         if (pix < 0) continue;
         const long long off = (long long)pix * (long long)p.out_ps + ccv[pr];
 #pragma unroll
