@@ -30,16 +30,18 @@ WORKLOADS = {
     # name: (family, B, T, H, W)            -- BASELINE.json configs; cfg 3 is the one the metric is quoted on (default)
     "cfg3_sd3_T17_512": ("sd3", 1, 17, 512, 512),
     "cfg2_vae3d_T17_256": ("vae3d", 1, 17, 256, 256),
+    # cfg 1: image mode (T = 1) -- the reference's own CPU-runnable case; launch-bound on a GPU (see --hip-graphs)
+    "cfg1_vae3d_T1_256": ("vae3d", 1, 1, 256, 256),
     # cfg 4: ONE long clip, its 8 temporal windows (x 6 spatial tiles each) sharded over the ranks (cv-vae_amd/dist.py):
     # strong scaling, encode + decode of the whole clip, gathered latents
     "cfg4_sd3_T129_720x1280": ("sd3", 1, 129, 720, 1280),
     # cfg 5: batch-8 T=33 encode-only (training-side latent pre-compute); the batch is split over the ranks
     "cfg5_sd3_B8_T33_512_encode": ("sd3", 8, 33, 512, 512),
 }
-ENC_TFLOP = {"cfg3_sd3_T17_512": 22.842, "cfg2_vae3d_T17_256": 5.674}  # encoder share of ALG_TFLOP
+ENC_TFLOP = {"cfg3_sd3_T17_512": 22.842, "cfg2_vae3d_T17_256": 5.674, "cfg1_vae3d_T1_256": 0.533}  # encoder share of ALG_TFLOP
 # algorithmic FLOPs per unit of work (BASELINE.md section 3 / SURVEY 8d: 2*M*N*K of every conv/linear + attention)
 ALG_TFLOP = {"cfg3_sd3_T17_512": 91.41, "cfg2_vae3d_T17_256": 22.79, "cfg4_sd3_T129_720x1280": 3656.0,
-             "cfg5_sd3_B8_T33_512_encode": 365.4}
+             "cfg5_sd3_B8_T33_512_encode": 365.4, "cfg1_vae3d_T1_256": 2.27}
 
 
 def parse():
@@ -50,6 +52,8 @@ def parse():
     ap.add_argument("--workload", default="cfg3_sd3_T17_512", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hip-graphs", action="store_true",
+                    help="replay each encoder/decoder pass as a captured hipGraph (vae.enable_hip_graphs(); for launch-bound inputs)")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
 
@@ -141,6 +145,8 @@ def main():
     torch.manual_seed(0)
     cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
     vae = cls().to(dtype).cuda().eval()  # random-init weights of the named architecture (no checkpoint access)
+    if args.hip_graphs:
+        vae.enable_hip_graphs(True)
     cfg4 = args.workload.startswith("cfg4")
     cfg5 = args.workload.startswith("cfg5")
     if cfg5:
@@ -205,7 +211,7 @@ def main():
         "data": "synthetic uniform[-1,1) clip, random-init weights (seed 0) of the named architecture",
         "config": {"workload": f"{args.workload}: {family} " + ("encode(x).mode()" if cfg5 else "encode(x).mode() + decode(z)") +
                                f", x=[{B},3,{T},{H},{W}] per GPU",
-                   "clips_per_gpu": B,
+                   "clips_per_gpu": B, "hip_graphs": bool(args.hip_graphs),
                    "parallelism": (f"temporal windows sharded x{world}, latents all-gathered" if strong else
                                    f"independent clips x{world} (no collective)")},
         "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * units / elapsed, 1),
@@ -229,6 +235,7 @@ def main():
             out["decode_tflops"] = round((ALG_TFLOP[args.workload] - et) / dec_ms * 1e3, 1)
             out["encode_frac_of_mfma_peak"] = round(et / enc_ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
     if rank == 0 and not args.no_roofline:
+        vae.enable_hip_graphs(False)  # per-launch timing needs the eager launches
         agg = roofline_pass(step)
         name, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = fl / sec / 1e12

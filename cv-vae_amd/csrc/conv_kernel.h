@@ -104,6 +104,8 @@ struct ConvArgs {
   // tuning probe (tools/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
   unsigned long long* dbg;
   int dbg_block;
+  int stagger;   // tuning experiment (CVVAE_CONV_STAGGER): first-round workgroups start up to this many cycles late
+  int stagger_wgs;
 };
 
 #ifdef CVVAE_CONV_PROBE
@@ -196,6 +198,12 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (p.stagger > 0 && (int)blockIdx.x < p.stagger_wgs) {
+    // de-synchronise the CUs: all workgroups of a round otherwise reach their store tail at the same moment
+    const long long wait = (long long)(((int)blockIdx.x >> 3) & 7) * p.stagger / 8;
+    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
+    while ((long long)(__builtin_amdgcn_s_memtime() - t_start) < wait) __builtin_amdgcn_s_sleep(16);
+  }
   const int grp = wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
   const int wave_n = wave % WN;
   const int wave_m = (wave / WN) % WM;

@@ -258,6 +258,10 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.gn_rpb = d->gn_rows_per_batch;
   a.order = 1;
   if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
+  if (const char* f = getenv("CVVAE_CONV_STAGGER")) {                          // tuning experiment
+    a.stagger = atoi(f);
+    a.stagger_wgs = cu_count();
+  }
   a.alpha = d->alpha;
   // tuning aid (tools/tune_instances.py re-launches recorded calls under CVVAE_CONV_FORCE: the record table was sized for
   // the default instance, another one would overrun it)

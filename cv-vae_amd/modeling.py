@@ -64,6 +64,8 @@ class _Net(nn.Module):
         super().__init__()
         self._wc = None
         self._cfg = {}
+        self._graphs = None  # enable_hip_graphs(): {(shape, dtype, device, switches): _GraphEntry}
+        self._graph_cap = 0
 
     def _cache(self) -> engine.WeightCache:
         if self._wc is None:
@@ -77,8 +79,51 @@ class _Net(nn.Module):
         if not x.is_cuda:
             raise RuntimeError("cv-vae_amd runs on an MI355X (ROCm) device only; move the model and the input to 'cuda'. "
                                "There is no CPU fallback.")
+        if self._graphs is not None and not torch.cuda.is_current_stream_capturing():
+            return self._forward_graphed(x)
         out = type(self)._program(self._cache(), x, self._cfg)
         return out
+
+    # ---- hipGraph replay of a whole encoder / decoder pass ------------------------------------------------------------
+    # One pass is 40-110 kernel launches.  On clips the GPU time hides the host's launch work; on images and small tiles
+    # (the T2I pipeline's decode(z, num_frames=1), BASELINE config 1) the pass is launch-bound.  With graphs enabled the
+    # launch sequence of each input shape is captured once (the kernels never synchronise, never allocate and take every
+    # argument by value, so the captured launches are exactly the eager ones) and replayed from then on: same kernels,
+    # same instance choice, bit-identical results.  The reference has no counterpart (plain eager PyTorch).
+    def enable_hip_graphs(self, enabled: bool = True, max_shapes: int = 4):
+        """Capture-and-replay of this network's launch sequence per input shape (static input/output buffers and the pass's
+        activations stay allocated per captured shape: keep `max_shapes` small; the oldest shape is dropped beyond it)."""
+        object.__setattr__(self, "_graphs", {} if enabled else None)
+        object.__setattr__(self, "_graph_cap", max(1, int(max_shapes)))
+        return self
+
+    def _forward_graphed(self, x: torch.Tensor) -> torch.Tensor:
+        sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        key = (tuple(x.shape), x.dtype, x.device.index, engine.fold_upsample(), engine.fold_t1(), engine.fuse_shortcut())
+        ent = self._graphs.get(key)
+        if ent is not None and ent[0] != sig:  # weights were replaced / moved / modified: the captured pointers are stale
+            del self._graphs[key]
+            ent = None
+        if ent is None:
+            while len(self._graphs) >= self._graph_cap:
+                self._graphs.pop(next(iter(self._graphs)))
+            prog, wc, cfg = type(self)._program, self._cache(), self._cfg
+            static_in = x.detach().clone()
+            cur = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):  # warm-up outside the capture: packs the weights, fills the device-query caches
+                prog(wc, static_in, cfg)
+            cur.wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = prog(wc, static_in, cfg)
+            ent = (sig, graph, static_in, static_out)
+            self._graphs[key] = ent
+        _, graph, static_in, static_out = ent
+        static_in.copy_(x)
+        graph.replay()
+        return static_out.clone()
 
     def get_last_layer(self, **kwargs):
         return self.conv_out.weight
@@ -379,6 +424,13 @@ class _CVVAEBase(nn.Module):
         return next(self.parameters()).device
 
     # diffusers no-op toggles some pipelines call
+    def enable_hip_graphs(self, enabled: bool = True, max_shapes: int = 4):
+        """hipGraph capture-and-replay of the encoder / decoder passes per input shape (see _Net.enable_hip_graphs): for
+        launch-bound inputs (images, small tiles).  Results are bit-identical to the eager launches."""
+        self.encoder.enable_hip_graphs(enabled, max_shapes)
+        self.decoder.enable_hip_graphs(enabled, max_shapes)
+        return self
+
     def enable_slicing(self): pass
     def disable_slicing(self): pass
     def enable_tiling(self, *a, **k): pass

@@ -262,3 +262,38 @@ def test_algebraic_folds_agree_with_unfolded_forms(shape, monkeypatch):
     assert (z1 - z0).abs().max() <= TOL[dtype]["moments"] and (y1 - y0).abs().max() <= TOL[dtype]["recon"]
     if shape[2] > 1:
         assert torch.equal(z1, z0)  # the encoder has no upsample and T > 1: untouched by either switch
+
+
+@pytest.mark.parametrize("family", ["sd3", "vae3d"])
+def test_hip_graph_replay_is_bit_identical(family):
+    """enable_hip_graphs(): the captured launch sequence of a pass replays the very kernels of the eager path -- results must be
+    bit-identical, for a clip and for the image mode (T = 1), across repeated replays with new inputs, after the weights
+    change (stale graphs are dropped), and beyond the shape-cache capacity."""
+    m, _ = build(family, {}, torch.bfloat16, 11)
+    zc = 16 if family == "sd3" else 4
+    shapes = [(1, 3, 5, 64, 64), (1, 3, 1, 96, 64), (2, 3, 1, 64, 64)]
+    xs = [seeded_input(s, 100 + i).to(torch.bfloat16).cuda() for i, s in enumerate(shapes)]
+    eager = []
+    for x in xs:
+        mom = m.encode(x).latent_dist.parameters
+        eager.append((mom, m.decode(mom[:, :zc].contiguous()).sample))
+    m.enable_hip_graphs(True, max_shapes=2)  # 3 shapes through 2 slots: eviction + re-capture are exercised too
+    for rep in range(2):
+        for x, (mom_e, rec_e) in zip(xs, eager):
+            mom = m.encode(x).latent_dist.parameters
+            rec = m.decode(mom[:, :zc].contiguous()).sample
+            assert torch.equal(mom, mom_e) and torch.equal(rec, rec_e), f"replay {rep} differs from the eager launches"
+    # a replay must read the NEW input, not the captured one
+    x2 = seeded_input(shapes[0], 999).to(torch.bfloat16).cuda()
+    mom2 = m.encode(x2).latent_dist.parameters
+    m.enable_hip_graphs(False)
+    assert torch.equal(mom2, m.encode(x2).latent_dist.parameters)
+    # weights modified in place -> graphs captured over the old packed weights must not be replayed
+    m.enable_hip_graphs(True)
+    before = m.encode(xs[0]).latent_dist.parameters
+    with torch.no_grad():
+        m.encoder.conv_out.bias.add_(0.5)
+    after = m.encode(xs[0]).latent_dist.parameters
+    assert not torch.equal(before, after)
+    m.enable_hip_graphs(False)
+    assert torch.equal(after, m.encode(xs[0]).latent_dist.parameters)

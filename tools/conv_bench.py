@@ -34,12 +34,21 @@ CASES = {
     "c2d128": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
     "c2d512": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
     "out128to3": (128, 3, (3, 3, 3), 17, 512, 512, P1, 1, False),
+    # ResnetBlock tails: per-frame conv2 + residual add + fused GroupNorm statistics of the sum (name suffix "res")
+    "c2d128res": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
+    "c2d256res": (256, 256, (1, 3, 3), 9, 256, 256, P2D, 1, False),
+    "c2d512res": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
 }
 
 
 def setenv(f):
-    """f = "FORCE" or "FORCE@ORDER" (CVVAE_CONV_FORCE / CVVAE_CONV_ORDER tuning knobs of libcvvae_hip.so)"""
+    """f = "FORCE", "FORCE@ORDER" or "FORCE@ORDER@STAGGER" (CVVAE_CONV_FORCE / _ORDER / _STAGGER tuning knobs of libcvvae_hip.so)"""
     force, _, order = f.partition("@")
+    order, _, stagger = order.partition("@")
+    if stagger:
+        os.environ["CVVAE_CONV_STAGGER"] = stagger
+    else:
+        os.environ.pop("CVVAE_CONV_STAGGER", None)
     os.environ["CVVAE_CONV_FORCE"] = force
     if order:
         os.environ["CVVAE_CONV_ORDER"] = order
@@ -75,6 +84,9 @@ def main():
             stride = (1, 1, 1)
         kw = dict(stride=stride, pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
                   gn=gn, upsample2x=ups, out_mode=L.OUT_NCDHW if cout <= 32 else L.OUT_NDHWC)
+        if name.endswith("res"):
+            kw["residual"] = (torch.rand((1, T, H, W, cout), device="cuda") * 2 - 1).to(dt)
+            kw["gn_out"] = 32
         npix = None
         best, kname = {}, {}
         for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
@@ -82,6 +94,8 @@ def main():
                 setenv(f)
                 ops.PROFILE = lambda d, pw_, launch, f=f: (kname.__setitem__(f, ops.conv_kernel_name(d)), launch())
                 y = ops.conv(x, pw, **kw)
+                if isinstance(y, tuple):
+                    y = y[0]
                 ops.PROFILE = None
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
