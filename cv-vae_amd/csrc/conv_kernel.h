@@ -104,6 +104,7 @@ struct ConvArgs {
   // tuning probe (tools/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
   unsigned long long* dbg;
   int dbg_block;
+  int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
   int stagger;   // tuning experiment (CVVAE_CONV_STAGGER): first-round workgroups start up to this many cycles late
   int stagger_wgs;
 };
@@ -368,6 +369,15 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
 
+  // ---- residual pre-accumulation (per-frame convs = the ResnetBlock tails).  The residual add in the store tail is a chain
+  //      of 16 latency-bound 16-byte loads per lane with nothing to overlap.  Instead, K chunk c (c < MREP/2) requests the
+  //      residual of fragments 2c, 2c+1 before its MFMAs (16 VGPRs) and adds it to those accumulators afterwards: the loads
+  //      fly under ~150 MFMAs.  The 16-byte runs are brought into accumulator layout by the same v_permlane32_swap the
+  //      store tail uses (it is its own inverse).  Measured: +1.3 % (128 ch) ... +2.7 % (512 ch) on the conv2 layers.
+  constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0);
+  const bool res_pre = RES_PRE && p.res != nullptr && p.res_pre != 0 && p.nchunks >= MREP / 2;
+  uint4 rpre[2][2];
+
   // ---- pipeline
   CVVAE_PROBE_MARK();
   stage(0, 0);
@@ -387,6 +397,24 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
       v8 ab[2][MREP];
 #pragma unroll
       for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r]]);
+      if constexpr (RES_PRE) {
+        if (res_pre && c < MREP / 2) {
+          int lane_p = lane;  // opaque copy: keeps the address math inside this branch (not hoisted into loop-long VGPRs)
+          asm volatile("" : "+v"(lane_p));
+#pragma unroll
+          for (int ri = 0; ri < 2; ++ri) {
+            const int m = (wave_m * MREP + 2 * c + ri) * 32 + (lane_p & 31);
+            const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
+            const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
+            const bool in = to < p.To && yo < p.Ho && xo < p.Wo;  // lanes outside read pixel 0; their sums are never stored
+            const long long pix = in ? (((long long)b * p.To + to) * p.Ho + yo) * p.Wo + xo : 0;
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr)
+              rpre[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + pix * (long long)p.out_ps +
+                                                             (nb * 32 + pr * 16 + (lane_p >> 5) * 8));
+          }
+        }
+      }
 #pragma unroll
       for (int st = 0; st < STEPS_W; ++st) {
         const v8 wv = wf[st % PF];
@@ -405,6 +433,28 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         // (measured on MI355X: 1158 -> 1240 TFLOP/s on 256->256 @9x256^2; pinning a strict MFMA/ds_read
         // alternation with sched_group_barrier instead was 4 % slower than letting hipcc order the step).
         __builtin_amdgcn_sched_barrier(0);
+      }
+      if constexpr (RES_PRE) {
+        if (res_pre && c < MREP / 2) {
+#pragma unroll
+          for (int cc = 0; cc < MREP / 2; ++cc) {  // static accumulator indices (a runtime-indexed array would go to scratch)
+            if (c != cc) continue;
+#pragma unroll
+            for (int ri = 0; ri < 2; ++ri)
+#pragma unroll
+              for (int pr = 0; pr < 2; ++pr) {
+                float rf[8];
+                unpack8<T>(rpre[ri][pr], rf);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                  float lo = rf[j], hi = rf[4 + j];
+                  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                  acc[2 * cc + ri][(2 * pr) * 4 + j] += lo;
+                  acc[2 * cc + ri][(2 * pr + 1) * 4 + j] += hi;
+                }
+              }
+          }
+        }
       }
     }
     CVVAE_PROBE_MARK();
@@ -578,7 +628,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     bool ff[RB];
 #pragma unroll
     for (int ri = 0; ri < RB; ++ri) pixr[ri] = locate(r0 + ri, ff[ri]);
-    if (p.res) {
+    if (p.res && !res_pre) {
 #pragma unroll
       for (int ri = 0; ri < RB; ++ri) {
         const int r = r0 + ri;
@@ -616,7 +666,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         const long long off = (long long)pix * (long long)p.out_ps + ccv[pr];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] += bia[pr][j];
-        if (p.res) {
+        if (p.res && !res_pre) {
           float rf[8];
           unpack8<T>(rres[ri][pr], rf);
 #pragma unroll

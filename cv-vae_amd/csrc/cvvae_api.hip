@@ -263,6 +263,8 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
     a.stagger_wgs = cu_count();
   }
   a.alpha = d->alpha;
+  static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid
+  a.res_pre = (residual && d->alpha == 1.0f && !d->out_f32 && !res_pre_off) ? 1 : 0;
   // tuning aid (tools/tune_instances.py re-launches recorded calls under CVVAE_CONV_FORCE: the record table was sized for
   // the default instance, another one would overrun it)
   static const bool nostats = getenv("CVVAE_CONV_TUNE_NOSTATS") != nullptr;
