@@ -363,11 +363,24 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
   for (int i = 0; i < PF; ++i) wf[i] = *reinterpret_cast<const v8*>(wq + i * 512);
 
+  // The accumulators start from the BIAS (alpha == 1, i.e. every layer but the attention score product): 128 v_add per lane
+  // leave the store tail -- which is VALU-issue bound -- for nothing (the zero fill cost the same moves).  K-group 1 of a
+  // K-group split starts from zero (the halves are summed).  Register quad g of a lane = channels nb*32 + 8g + 4*(lane>>5) + j.
+  const bool bias_pre = p.alpha == 1.0f;
   f32x16 acc[MREP];
+  {
+    float bq[16];
 #pragma unroll
-  for (int r = 0; r < MREP; ++r)
+    for (int g = 0; g < 4; ++g) {
+      float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (bias_pre && active && kgrp == 0) bv = *reinterpret_cast<const float4*>(p.bias + nb * 32 + g * 8 + (lane >> 5) * 4);
+      bq[g * 4] = bv.x; bq[g * 4 + 1] = bv.y; bq[g * 4 + 2] = bv.z; bq[g * 4 + 3] = bv.w;
+    }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    for (int r = 0; r < MREP; ++r)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[r][i] = bq[i];
+  }
 
   // ---- residual pre-accumulation (per-frame convs = the ResnetBlock tails).  The residual add in the store tail is a chain
   //      of 16 latency-bound 16-byte loads per lane with nothing to overlap.  Instead, K chunk c (c < MREP/2) requests the
@@ -568,7 +581,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         for (int j = 0; j < 4; ++j)
           if (cb + j < p.Cout)
             o[((((size_t)b * p.Cout + (cb + j)) * p.To + to) * p.Ho + yo) * (size_t)p.Wo + xo] =
-                (T)(acc[r][g * 4 + j] * p.alpha + bb[j]);
+                (T)(bias_pre ? acc[r][g * 4 + j] : acc[r][g * 4 + j] * p.alpha + bb[j]);
       }
     }
     CVVAE_PROBE_MARK();
@@ -620,6 +633,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     const bool valid = pixr != NOPIX && c8v[pr] < p.Cout && !(p.out_mode == 2 && first_frame && nshv[pr] == 0);
     return valid ? pixr + nshv[pr] * frame_px : -1;
   };
+  // The swaps below read accumulator registers straight from the last MFMAs inside an asm statement, where hipcc pads no
+  // hazards: 32 wait states cover the MFMA-result -> VALU-read distance (the K loop also ended on a barrier).
+  asm volatile("s_nop 15\n\ts_nop 15");
   constexpr int RB = MREP >= 4 ? 4 : MREP;  // (a single batch of 8 measured the same and needs 16 more VGPRs)
 #pragma unroll
   for (int r0 = 0; r0 < MREP; r0 += RB) {
@@ -653,10 +669,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         for (int j = 0; j < 4; ++j) {
           // vdst = quad 2*pr (its upper-half lanes are exchanged), src = quad 2*pr+1 (its lower-half lanes).
           // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) aliases the builtin's two results when
-          // they are scattered into an unrolled array (both halves came back as result 0).  The alpha multiply in front is
-          // the compiler's own VALU op, so the MFMA-result -> VALU hazard is padded by hipcc; `s_nop 1` covers the
-          // VALU-write -> v_permlane read hazard, which hipcc does not pad inside an asm statement.
-          float lo = acc[r][(2 * pr) * 4 + j] * p.alpha, hi = acc[r][(2 * pr + 1) * 4 + j] * p.alpha;
+          // they are scattered into an unrolled array (both halves came back as result 0).  `s_nop 1` covers the
+          // VALU-write -> v_permlane read hazard (a copy or the alpha scaling may precede), which hipcc does not pad inside
+          // an asm statement; the MFMA-result -> VALU distance is covered by the s_nop pair above.
+          float lo = acc[r][(2 * pr) * 4 + j], hi = acc[r][(2 * pr + 1) * 4 + j];
           asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
           v[j] = lo;
           v[4 + j] = hi;
@@ -664,8 +680,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
         const int pix = pix_of(pixr[ri], ff[ri], pr);
         if (pix < 0) continue;
         const long long off = (long long)pix * (long long)p.out_ps + ccv[pr];
+        if (!bias_pre) {  // alpha != 1 (the attention score product): scale and add the bias here
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += bia[pr][j];
+          for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bia[pr][j];
+        }
         if (p.res && !res_pre) {
           float rf[8];
           unpack8<T>(rres[ri][pr], rf);
