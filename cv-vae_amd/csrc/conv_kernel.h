@@ -14,8 +14,9 @@
 //     wave streams its own 32-output-channel slice straight HBM/L2 -> VGPR (1 KiB per wave per k16 step,
 //     contiguous, software-prefetched PF steps ahead).
 //   * MFMA is v_mfma_f32_32x32x16 with SWAPPED operands (A = weights, B = activations): the accumulator
-//     lane then holds, for ONE pixel, 4 consecutive output channels per register quad; the epilogue pairs the
-//     half-waves with v_permlane32_swap so every lane stores 16 bytes (8 channels) at a time.
+//     lane then holds, for ONE pixel, 4 consecutive output channels per register quad.  The packers store output
+//     channel sigma(i) in MFMA row i (sigma swaps bits 2 and 3 of i), which makes quads 2p, 2p+1 of a lane 8
+//     CONSECUTIVE channels: every lane stores 16 bytes at a time with no cross-lane exchange.
 //   * WM x WN x KG = 8 waves: WM pixel slabs x WN 32-channel blocks x KG K-groups (KG = 2: the two wave groups
 //     split the chunk's channels and reduce their accumulators through LDS).
 //   * UPS = 1: nearest-2x gather fused into the staging; UPS = 2: the upsample folded into four 3x2x2 phase
@@ -365,7 +366,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 
   // The accumulators start from the BIAS (alpha == 1, i.e. every layer but the attention score product): 128 v_add per lane
   // leave the store tail -- which is VALU-issue bound -- for nothing (the zero fill cost the same moves).  K-group 1 of a
-  // K-group split starts from zero (the halves are summed).  Register quad g of a lane = channels nb*32 + 8g + 4*(lane>>5) + j.
+  // K-group split starts from zero (the halves are summed).
+  // Register quad g of a lane holds channels nb*32 + 16(g>>1) + 8(lane>>5) + 4(g&1) + j: the weight packers put output channel
+  // sigma(i) into MFMA row i (sigma swaps bits 2 and 3 of the index inside the 32-channel block), so quads 2p and 2p+1 of a
+  // lane are 8 CONSECUTIVE channels and the store tail writes 16-byte runs without any cross-lane exchange.
   const bool bias_pre = p.alpha == 1.0f;
   f32x16 acc[MREP];
   {
@@ -373,7 +377,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (bias_pre && active && kgrp == 0) bv = *reinterpret_cast<const float4*>(p.bias + nb * 32 + g * 8 + (lane >> 5) * 4);
+      if (bias_pre && active && kgrp == 0)
+        bv = *reinterpret_cast<const float4*>(p.bias + nb * 32 + (g >> 1) * 16 + (lane >> 5) * 8 + (g & 1) * 4);
       bq[g * 4] = bv.x; bq[g * 4 + 1] = bv.y; bq[g * 4 + 2] = bv.z; bq[g * 4 + 3] = bv.w;
     }
 #pragma unroll
@@ -385,8 +390,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // ---- residual pre-accumulation (per-frame convs = the ResnetBlock tails).  The residual add in the store tail is a chain
   //      of 16 latency-bound 16-byte loads per lane with nothing to overlap.  Instead, K chunk c (c < MREP/2) requests the
   //      residual of fragments 2c, 2c+1 before its MFMAs (16 VGPRs) and adds it to those accumulators afterwards: the loads
-  //      fly under ~150 MFMAs.  The 16-byte runs are brought into accumulator layout by the same v_permlane32_swap the
-  //      store tail uses (it is its own inverse).  Measured: +1.3 % (128 ch) ... +2.7 % (512 ch) on the conv2 layers.
+  //      fly under ~150 MFMAs (a 16-byte run = quads 2pr, 2pr+1 of the lane).  Measured: +1.3 % (128 ch) ... +2.7 %
+  //      (512 ch) on the conv2 layers.
   constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0);
   const bool res_pre = RES_PRE && p.res != nullptr && p.res_pre != 0 && p.nchunks >= MREP / 2;
   uint4 rpre[2][2];
@@ -460,10 +465,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
                 unpack8<T>(rpre[ri][pr], rf);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                  float lo = rf[j], hi = rf[4 + j];
-                  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-                  acc[2 * cc + ri][(2 * pr) * 4 + j] += lo;
-                  acc[2 * cc + ri][(2 * pr + 1) * 4 + j] += hi;
+                  acc[2 * cc + ri][(2 * pr) * 4 + j] += rf[j];
+                  acc[2 * cc + ri][(2 * pr + 1) * 4 + j] += rf[4 + j];
                 }
               }
           }
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
       if (to >= p.To || yo >= p.Ho || xo >= p.Wo) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int cb = nb * 32 + g * 8 + (lane_e >> 5) * 4;
+        const int cb = nb * 32 + (g >> 1) * 16 + (lane_e >> 5) * 8 + (g & 1) * 4;
         if (cb >= p.Cout) continue;
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb);
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
@@ -587,10 +590,11 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     CVVAE_PROBE_MARK();
     return;
   }
-  // NDHWC / time-shuffle: the store tail is store-ISSUE bound (8-byte pieces of 32 different lines per instruction), so
-  // the two half-waves first exchange register quads with v_permlane32_swap: for each PAIR of quads (g, g+1) the lower
-  // half-wave ends up with channels 16*pair..+7 and the upper one with 16*pair+8..+15 of its pixel -- 8 consecutive
-  // channels per lane -> ONE 16-byte store (and one 16-byte residual load) instead of two 8-byte ones.
+  // NDHWC / time-shuffle: for each PAIR of quads (2pr, 2pr+1) the lower half-wave holds channels 16*pr..+7 and the upper
+  // one 16*pr+8..+15 of its pixel (sigma row order of the packed weights) -- 8 consecutive channels per lane -> ONE 16-byte
+  // store (and one 16-byte residual load) per pair.  (An earlier revision kept natural row order and exchanged quads
+  // between the half-waves with v_permlane32_swap in the tail: 64 swaps + hazard nops + copies per lane, ~1.3 k cycles per
+  // tile and 3 % of a per-frame conv.)
   // fused GroupNorm statistics of what is stored (the ROUNDED values, as the reference's GroupNorm sees them): per lane
   // 4 slots (pr, q) of 4 consecutive channels each: sum, sum of squares; valid-pixel count per pr
   float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gc[2] = {0.f, 0.f};
@@ -633,96 +637,189 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     const bool valid = pixr != NOPIX && c8v[pr] < p.Cout && !(p.out_mode == 2 && first_frame && nshv[pr] == 0);
     return valid ? pixr + nshv[pr] * frame_px : -1;
   };
-  // The swaps below read accumulator registers straight from the last MFMAs inside an asm statement, where hipcc pads no
-  // hazards: 32 wait states cover the MFMA-result -> VALU-read distance (the K loop also ended on a barrier).
-  asm volatile("s_nop 15\n\ts_nop 15");
   constexpr int RB = MREP >= 4 ? 4 : MREP;  // (a single batch of 8 measured the same and needs 16 more VGPRs)
+  // ---- fast store tail (every lane of the tile stores full 8-channel runs: all interior tiles of the layers that matter).
+  // The general tail below is per-lane code: validity masks, exec-mask branches and 64-bit per-lane address products
+  // (quarter-rate integer multiplies) -- measured 9.5 k cycles per 128 accumulators with or WITHOUT the stores themselves,
+  // i.e. bound by its own VALU/SALU stream.  Here a lane's address is  uniform(fragment, channel pair) + lane part, the lane
+  // part (a 32-bit element offset) is computed once, the uniform part lives in SGPRs, and nothing diverges.
+  constexpr int TWm = TW < 32 ? TW : 32;
+  static_assert(TW % 32 == 0 || (32 % TW == 0 && TH % (32 / TW) == 0), "fragment rows must tile the workgroup tile");
+  const bool tile_full = (t0 + TT <= p.To) && (y0 + TH <= p.Ho) && (x0 + TW <= p.Wo) && ((nb + 1) * 32 <= p.Cout) &&
+                         !p.out_f32 && (p.out_mode != 2 || (C2 & 31) == 0);
+  if (tile_full) {
+    const int l31 = lane_e & 31;
+    const int Wst = (UPS == 2 ? 2 : 1) * p.Wo, Hst = (UPS == 2 ? 2 : 1) * p.Ho;  // stored frame size
+    const unsigned voff = (unsigned)((UPS == 2 ? 2 : 1) * ((l31 / TWm) * Wst + (l31 % TWm)) * p.out_ps + (lane_e >> 5) * 8);
+    const int n_sh = (p.out_mode == 2 && nb * 32 >= C2) ? 1 : 0;  // time shuffle: my 32 channels land one frame later
+    const int Tq = p.out_mode == 2 ? 2 * p.To - 1 : p.To;
+    const int chan0 = nb * 32 - n_sh * C2;
+    T* __restrict__ outp = reinterpret_cast<T*>(p.out);
+    const T* __restrict__ resp = reinterpret_cast<const T*>(p.res);
+    // element offset of fragment r (its lane 0, my channel block), wave-uniform; drop = the discarded frame -1
+    auto row_of = [&](int r, bool& drop) -> long long {
+      const int f = wave_m * MREP + r;
+      const int utx = (f * 32) % TW, uty = ((f * 32) / TW) % TH, utt = (f * 32) / (TW * TH);
+      const int to = t0 + utt;
+      const int tq = (p.out_mode == 2 ? 2 * to - 1 : to) + n_sh;
+      drop = tq < 0;
+      const long long fr = (long long)b * Tq + (drop ? 0 : tq);
+      const long long S = UPS == 2 ? ((fr * Hst + 2 * (y0 + uty) + py) * Wst + 2 * (x0 + utx) + px)
+                                   : ((fr * Hst + (y0 + uty)) * Wst + (x0 + utx));
+      return S * (long long)p.out_ps + chan0;
+    };
 #pragma unroll
-  for (int r0 = 0; r0 < MREP; r0 += RB) {
-    uint4 rres[RB][2];
-    int pixr[RB];
-    bool ff[RB];
+    for (int r0 = 0; r0 < MREP; r0 += RB) {
+      uint4 rres[RB][2];
+      long long rowe[RB];
+      bool drop[RB];
 #pragma unroll
-    for (int ri = 0; ri < RB; ++ri) pixr[ri] = locate(r0 + ri, ff[ri]);
-    if (p.res && !res_pre) {
+      for (int ri = 0; ri < RB; ++ri) rowe[ri] = row_of(r0 + ri, drop[ri]);
+      if (p.res && !res_pre) {
+#pragma unroll
+        for (int ri = 0; ri < RB; ++ri) {
+          if (KG == 2 && (((r0 + ri) < MREP / 2) != (kgrp == 0))) continue;
+#pragma unroll
+          for (int pr = 0; pr < 2; ++pr) rres[ri][pr] = *reinterpret_cast<const uint4*>(resp + rowe[ri] + pr * 16 + voff);
+        }
+      }
 #pragma unroll
       for (int ri = 0; ri < RB; ++ri) {
         const int r = r0 + ri;
         if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
 #pragma unroll
         for (int pr = 0; pr < 2; ++pr) {
-          const int pix = pix_of(pixr[ri], ff[ri], pr);
-          // unconditional 16-byte load (pixel 0 for lanes with nothing to store) keeps the loads branch-free
-          rres[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) +
-                                                         (long long)(pix < 0 ? 0 : pix) * (long long)p.out_ps + ccv[pr]);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {  // quads 2pr, 2pr+1 = my 8 consecutive channels
+            float lo = acc[r][(2 * pr) * 4 + j], hi = acc[r][(2 * pr + 1) * 4 + j];
+            asm volatile("" : "+v"(lo), "+v"(hi));  // (pins the reads to this point: see the general tail)
+            v[j] = lo;
+            v[4 + j] = hi;
+          }
+          if (drop[ri]) continue;  // wave-uniform
+          if (!bias_pre) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bia[pr][j];
+          }
+          if (p.res && !res_pre) {
+            float rf[8];
+            unpack8<T>(rres[ri][pr], rf);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rf[j];
+          }
+          const uint4 pk = pack8<T>(v);
+#ifdef CVVAE_CONV_PROBE
+          if (p.stagger != -1)
+#endif
+          *reinterpret_cast<uint4*>(outp + rowe[ri] + pr * 16 + voff) = pk;
+          if (p.gnp) {
+            float rv[8];
+            uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
+            asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
+            unpack8<T>(pq, rv);
+            gc[pr] += 1.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+              for (int j = 0; j < 4; ++j) {
+                gs[pr][q] += rv[q * 4 + j];
+                gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
+              }
+          }
         }
       }
     }
-#pragma unroll
-    for (int ri = 0; ri < RB; ++ri) {
-      const int r = r0 + ri;
-      if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;
-#pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          // vdst = quad 2*pr (its upper-half lanes are exchanged), src = quad 2*pr+1 (its lower-half lanes).
-          // Inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) aliases the builtin's two results when
-          // they are scattered into an unrolled array (both halves came back as result 0).  `s_nop 1` covers the
-          // VALU-write -> v_permlane read hazard (a copy or the alpha scaling may precede), which hipcc does not pad inside
-          // an asm statement; the MFMA-result -> VALU distance is covered by the s_nop pair above.
-          float lo = acc[r][(2 * pr) * 4 + j], hi = acc[r][(2 * pr + 1) * 4 + j];
-          asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
-          v[j] = lo;
-          v[4 + j] = hi;
-        }
-        const int pix = pix_of(pixr[ri], ff[ri], pr);
-        if (pix < 0) continue;
-        const long long off = (long long)pix * (long long)p.out_ps + ccv[pr];
-        if (!bias_pre) {  // alpha != 1 (the attention score product): scale and add the bias here
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bia[pr][j];
-        }
-        if (p.res && !res_pre) {
-          float rf[8];
-          unpack8<T>(rres[ri][pr], rf);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] += rf[j];
-        }
-        const int c8 = c8v[pr];
-        const bool full = (c8 + 7 < p.Cout);
-        if (p.out_f32) {
-          float* o = reinterpret_cast<float*>(p.out) + off;
-          if (full) {
-            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (c8 + j < p.Cout) o[j] = v[j];
+  } else {
+  #pragma unroll
+    for (int r0 = 0; r0 < MREP; r0 += RB) {
+      uint4 rres[RB][2];
+      int pixr[RB];
+      bool ff[RB];
+  #pragma unroll
+      for (int ri = 0; ri < RB; ++ri) pixr[ri] = locate(r0 + ri, ff[ri]);
+      if (p.res && !res_pre) {
+  #pragma unroll
+        for (int ri = 0; ri < RB; ++ri) {
+          const int r = r0 + ri;
+          if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
+  #pragma unroll
+          for (int pr = 0; pr < 2; ++pr) {
+            const int pix = pix_of(pixr[ri], ff[ri], pr);
+            // unconditional 16-byte load (pixel 0 for lanes with nothing to store) keeps the loads branch-free
+            rres[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) +
+                                                           (long long)(pix < 0 ? 0 : pix) * (long long)p.out_ps + ccv[pr]);
           }
-        } else {
-          T* o = reinterpret_cast<T*>(p.out) + off;
-          if (full) {
-            const uint4 pk = pack8<T>(v);
-            *reinterpret_cast<uint4*>(o) = pk;
-            if (p.gnp) {
-              float rv[8];
-              unpack8<T>(pk, rv);
-              gc[pr] += 1.f;
-#pragma unroll
-              for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  gs[pr][q] += rv[q * 4 + j];
-                  gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
-                }
+        }
+      }
+  #pragma unroll
+      for (int ri = 0; ri < RB; ++ri) {
+        const int r = r0 + ri;
+        if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;
+  #pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+          float v[8];
+  #pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            // (the empty asm pins the accumulator reads to this point of the tail: with plain reads hipcc keeps 128 more
+            // values alive across the tails and spills 500+ VGPRs on most instances; an input-only constraint is not enough)
+            float lo = acc[r][(2 * pr) * 4 + j], hi = acc[r][(2 * pr + 1) * 4 + j];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            v[j] = lo;
+            v[4 + j] = hi;
+          }
+          const int pix = pix_of(pixr[ri], ff[ri], pr);
+          if (pix < 0) continue;
+          const long long off = (long long)pix * (long long)p.out_ps + ccv[pr];
+          if (!bias_pre) {  // alpha != 1 (the attention score product): scale and add the bias here
+  #pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bia[pr][j];
+          }
+          if (p.res && !res_pre) {
+            float rf[8];
+            unpack8<T>(rres[ri][pr], rf);
+  #pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += rf[j];
+          }
+          const int c8 = c8v[pr];
+          const bool full = (c8 + 7 < p.Cout);
+          if (p.out_f32) {
+            float* o = reinterpret_cast<float*>(p.out) + off;
+            if (full) {
+              *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+              *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+  #pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (c8 + j < p.Cout) o[j] = v[j];
             }
           } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j)
-              if (c8 + j < p.Cout) o[j] = (T)v[j];
+            T* o = reinterpret_cast<T*>(p.out) + off;
+            if (full) {
+              const uint4 pk = pack8<T>(v);
+  #ifdef CVVAE_CONV_PROBE
+              if (p.stagger != -1)  // probe: PROBE_NOSTORE runs the store tail without its stores
+  #endif
+              *reinterpret_cast<uint4*>(o) = pk;
+              if (p.gnp) {
+                float rv[8];
+                uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
+                asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
+                unpack8<T>(pq, rv);
+                gc[pr] += 1.f;
+  #pragma unroll
+                for (int q = 0; q < 2; ++q)
+  #pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    gs[pr][q] += rv[q * 4 + j];
+                    gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
+                  }
+              }
+            } else {
+  #pragma unroll
+              for (int j = 0; j < 8; ++j)
+                if (c8 + j < p.Cout) o[j] = (T)v[j];
+            }
           }
         }
       }

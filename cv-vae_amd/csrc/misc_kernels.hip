@@ -10,8 +10,13 @@ namespace cvvae {
 
 // ---------------------------------------------------------------------------------------------------------
 // weight packing: dst[(((nb*nchunks + chunk)*taps + tap)*KSUB + ks)*512 + lane*8 + j]
-//   = src(co = nb*32 + (lane&31), ci = chunk*CK + ks*16 + (lane>>5)*8 + j, tap)
+//   = src(co = nb*32 + sigma(lane&31), ci = chunk*CK + ks*16 + (lane>>5)*8 + j, tap)
 // ---------------------------------------------------------------------------------------------------------
+// MFMA row i of a 32-output-channel block carries output channel sigma(i) = i with bits 2 and 3 swapped: the accumulator
+// quads 2p, 2p+1 of a lane are then 8 consecutive channels (conv_kernel.h, store tail) -- the order is private to the
+// packed format (cvvae_pack_weights* write it, conv_fwd_kernel reads it).
+__device__ __forceinline__ int sigma_row(int i) { return (i & ~12) | ((i & 4) << 1) | ((i & 8) >> 1); }
+
 template <typename T>
 __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
                                     long long s_ci, long long s_tap, int nchunks, int ksub, T* __restrict__ dst,
@@ -29,7 +34,7 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
   f /= taps;
   const int chunk = (int)(f % nchunks);
   const int nb = (int)(f / nchunks);
-  const int co = nb * 32 + (lane & 31);
+  const int co = nb * 32 + sigma_row(lane & 31);
   const int ci0 = chunk * (16 * ksub) + ks * 16 + (lane >> 5) * 8;
   typename Tr<T>::v8 v;
 #pragma unroll
@@ -78,7 +83,7 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
   // folded tap sets [lo, hi] along y and x
   const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
   const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
-  const int co = nb * 32 + (lane & 31);
+  const int co = nb * 32 + sigma_row(lane & 31);
   const int ci0 = chunk * 16 + (lane >> 5) * 8;
   typename Tr<T>::v8 v;
 #pragma unroll

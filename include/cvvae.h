@@ -94,7 +94,9 @@ typedef struct cvvae_conv_desc {
 size_t cvvae_packed_weight_bytes(int32_t Cout, int32_t Cin, int32_t taps);
 
 /*
- * Pack weights into MFMA-fragment order: [Cout/32][Cin_pad/16][tap][64 lanes][8].
+ * Pack weights into MFMA-fragment order: [Cout/32][Cin_pad/16][tap][64 lanes][8].  (Lane l of a record holds the 8 input
+ * channels (l>>5)*8.. of output channel block*32 + sigma(l&31), sigma = l&31 with bits 2 and 3 swapped; the format is
+ * private to the library: only cvvae_pack_weights* write it and only cvvae_conv_fwd* read it.)
  * src element (co, ci, tap) is read at src[co*s_co + ci*s_ci + tap*s_tap] (dtype elements), so the same entry
  * packs torch conv weights [Cout][Cin][kT*kH*kW] (s_co=Cin_src*taps, s_ci=taps, s_tap=1), nn.Linear weights, and
  * per-frame attention K / V^T matrices produced on the device.  co >= Cout_src or ci >= Cin_src pack as 0.

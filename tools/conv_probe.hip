@@ -78,6 +78,7 @@ int run() {
     a.gn_G = 32; a.gn_sh = sh; a.gn_slabs = a.tiles_t * a.tiles_h * a.tiles_w * WM * KG * (1 << (sh - 2));
     float* gnp; hipMalloc(&gnp, (size_t)a.gn_slabs * 32 * 3 * 4); a.gnp = gnp;
   }
+  if (getenv("PROBE_NOSTORE")) a.stagger = -1;  // the store tail without its stores: what is left is VALU + addressing
   a.dbg = dbg; a.dbg_block = getenv("PROBE_BLOCK") ? atoi(getenv("PROBE_BLOCK")) : grid / 2 + 3;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) {
