@@ -12,7 +12,7 @@ F16, BF16, F32 = 0, 1, 2
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class ConvDesc(ctypes.Structure):
@@ -36,7 +36,7 @@ class ConvDesc(ctypes.Structure):
         ("out_pix_stride", ctypes.c_int64),
         ("alpha", ctypes.c_float),
         ("w_batch_stride", ctypes.c_int64),
-        ("sc_Cin", ctypes.c_int32), ("sc_reserved", ctypes.c_int32),
+        ("sc_Cin", ctypes.c_int32), ("w_time_folds", ctypes.c_int32),
         ("sc_in_pix_stride", ctypes.c_int64),
     ]
 
@@ -49,6 +49,8 @@ PROTOTYPES = {
     "cvvae_packed_weight_bytes": (ctypes.c_size_t, [_i32, _i32, _i32]),
     "cvvae_pack_weights": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "cvvae_pack_weights_upfold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_pack_weights_tfolds": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "cvvae_pack_weights_upfold_tfolds": (_i32, [_i32, _vp, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_pack_weights_batched": (_i32, [_i32, _vp, _i32, _i64, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i32, _vp, _i64, _vp]),
     "cvvae_pack_weights_fold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _vp]),
     "cvvae_conv_fwd": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -105,6 +105,7 @@ struct ConvArgs {
   // tuning probe (tools/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
   unsigned long long* dbg;
   int dbg_block;
+  int w_taps;    // taps per k16 record group of the packed weights: NTAPS, or 2*NTAPS with the time-fold slots (KT == 3)
   int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
   int stagger;   // tuning experiment (CVVAE_CONV_STAGGER): first-round workgroups start up to this many cycles late
   int stagger_wgs;
@@ -252,13 +253,70 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // is done before it starts (the host zero-fills the GroupNorm records, so the missing ones read as empty)
   if (UPS != 1 && TT == 1 && p.out_mode == 2 && t0 == 0 && (ntile + 1) * G::BN <= (p.Cout >> 1)) return;
 
-  // ---- staging plan (chunk independent): which stored pixel feeds each of my halo slots
+  // ---- time folds (KT == 3).  At a clip boundary two or three time taps of an output frame read the SAME stored frame
+  //      (replicate padding) or a zero frame (zero padding).  The chunk's steps are therefore walked as up to three TIME GROUPS
+  //      of KH*KW*KSUB steps, each with a weight slot and an LDS frame chosen per wave (a wave's fragments lie in one output
+  //      frame): distinct frames -> slots W0, W1, W2 on frames 0, 1, 2; frames 0 = 1 -> (W0+W1 on frame 1), W2; frames 1 = 2 ->
+  //      W0, (W1+W2 on frame 1); all equal -> W0+W1+W2 on frame 1 (the summed slots come from cvvae_pack_weights_tfolds:
+  //      p.w_taps == 2*NTAPS); zero frames are simply skipped.  Halo frames no wave of the workgroup reads are not staged
+  //      either.  cfg 3: 6-20 % fewer MFMAs on the causal encoder convs, 4-13 % on the decoder's.
+  constexpr bool TFOLD = (KT == 3 && KG == 1);
+  constexpr int NSP = KH * KW, GS = NSP * KSUB;  // steps of one time group
+  static_assert(!TFOLD || (GS % PF == 0 && (TT == 1 || (TH * TW) % (MREP * 32) == 0)), "time-group plan");
+  const long long w_ks = (long long)(TFOLD ? p.w_taps : NTAPS) * 512;  // elements between consecutive k16 record groups
+  const long long w_cs = w_ks * KSUB;                                   // ... between consecutive K chunks
+  int tf_ng = 3;
+  long long tf_w0 = 0, tf_w1 = NSP * 512, tf_w2 = 2 * NSP * 512;  // weight slot of each time group (element offsets)
+  unsigned tf_l0 = 0, tf_l1 = G::FH * G::FW * PIXB, tf_l2 = 2 * G::FH * G::FW * PIXB;  // LDS frame of each time group
+  int hf_a = 0, hf_b = G::FT - 1;  // halo frames [hf_a, hf_b] some wave of this workgroup reads
+  if constexpr (TFOLD) {
+    // plan of output frame `to`: number of time groups, (weight slot, tap frame) of groups 0 and 1 (group 2 is always W2 on 2)
+    auto tf_variant = [&](int to, int& ng, int& slot0, int& slot1, int& dt0, int& dt1) {
+      const int f0 = to * ST - p.pt;  // input frame of time tap 0 before padding
+      auto clampT = [&](int v) { return v < 0 ? 0 : (v >= p.Tl ? p.Tl - 1 : v); };
+      ng = 3; slot0 = 0; slot1 = 1; dt0 = 0; dt1 = 1;
+      if (p.mode_t != 0) {  // replicate
+        if (p.w_taps == 2 * NTAPS) {
+          const bool eq01 = clampT(f0) == clampT(f0 + 1), eq12 = clampT(f0 + 1) == clampT(f0 + 2);
+          if (eq01 && eq12) { ng = 1; slot0 = 5; dt0 = 1; }
+          else if (eq01) { ng = 2; slot0 = 3; dt0 = 1; slot1 = 2; dt1 = 2; }
+          else if (eq12) { ng = 2; slot0 = 0; dt0 = 0; slot1 = 4; dt1 = 1; }
+        }
+      } else {  // zero padding: a tap on a padding frame contributes exactly nothing
+        const bool z0 = f0 < 0 || f0 >= p.Tl, z2 = f0 + 2 < 0 || f0 + 2 >= p.Tl;
+        if (z0 && z2) { ng = 1; slot0 = 1; dt0 = 1; }
+        else if (z0) { ng = 2; slot0 = 1; dt0 = 1; slot1 = 2; dt1 = 2; }
+        else if (z2) { ng = 2; slot0 = 0; dt0 = 0; slot1 = 1; dt1 = 1; }
+      }
+    };
+    int slot0, slot1, dt0, dt1;
+    tf_variant(t0 + (TT > 1 ? (wave_m * MREP * 32) / (TH * TW) : 0), tf_ng, slot0, slot1, dt0, dt1);
+    tf_w0 = (long long)slot0 * (NSP * 512);
+    tf_w1 = (long long)slot1 * (NSP * 512);
+    tf_l0 = (unsigned)dt0 * (G::FH * G::FW * PIXB);
+    tf_l1 = (unsigned)dt1 * (G::FH * G::FW * PIXB);
+    hf_a = G::FT;
+    hf_b = -1;
+#pragma unroll
+    for (int tt = 0; tt < TT; ++tt) {  // union over the output frames of the tile
+      int ng, s0_, s1_, d0_, d1_;
+      tf_variant(t0 + tt, ng, s0_, s1_, d0_, d1_);
+      const int lo = tt * ST + d0_, hi = tt * ST + (ng == 3 ? 2 : (ng == 2 ? d1_ : d0_));
+      hf_a = lo < hf_a ? lo : hf_a;
+      hf_b = hi > hf_b ? hi : hf_b;
+    }
+  }
+  // ---- staging plan (chunk independent): which stored pixel feeds each of my halo slots (the halo pixels of the frames
+  //      [hf_a, hf_b] are split between the two wave groups)
   const int tl = tid & 255;
   const int sq = tl % G::IPP;  // my 16-byte slice (8 channels) inside the chunk -- fixed for the whole kernel
   const int spl = tl / G::IPP;
-  const int pstart = grp ? G::NPH : 0;
-  const int pend = grp ? G::NPIX : (G::NPH < G::NPIX ? G::NPH : G::NPIX);
+  const int hbase = hf_a * (G::FH * G::FW), hcnt = (hf_b - hf_a + 1) * (G::FH * G::FW);
+  const int nph_x = TFOLD ? (((hcnt + 1) / 2 + G::PPP - 1) / G::PPP * G::PPP) : G::NPH;  // pixels staged by group X
+  const int pstart = hbase + (grp ? nph_x : 0);
+  const int pend = hbase + (grp ? hcnt : (nph_x < hcnt ? nph_x : hcnt));
   int srcpix[NPASS];
+  unsigned passmask = 0;  // wave-uniform: passes in which some lane of this wave has a slot
 #pragma unroll
   for (int k = 0; k < NPASS; ++k) {
     const int hp = pstart + spl + k * G::PPP;
@@ -280,6 +338,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
       sp = zero ? -1 : ((b * p.Ti + ts) * p.Hi + ys) * p.Wi + xs;
     }
     srcpix[k] = sp;
+    if (__builtin_amdgcn_ballot_w64(sp != -2) != 0) passmask |= 1u << k;
   }
   const int lds_w0 = (pstart + spl) * PIXB + sq * 16;
   const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
@@ -307,7 +366,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
-        if (k < NPASS) {
+        if (k < NPASS && ((passmask >> k) & 1)) {
           // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
           const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
           raw[kk] = *reinterpret_cast<const uint4*>(src + (size_t)sp * src_ps + c0);
@@ -323,7 +382,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
-        if (k < NPASS) {
+        if (k < NPASS && ((passmask >> k) & 1)) {
           if (srcpix[k] == -2) continue;
           uint4 o = raw[kk];
           if (PRO_ != 0) {
@@ -357,12 +416,16 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16 +
                          kgrp * (KSUB / KG) * 32);
   }
+  // step i of a time group: k16 sub-chunk i / NSP, spatial tap i % NSP
+  auto tf_rec = [&](int i) -> long long { return (long long)(i / NSP) * w_ks + (i % NSP) * 512; };
   const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
                 (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
-                (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512) + lane * 8;
+                (TFOLD ? (size_t)(active ? nb : 0) * (size_t)p.nchunks * (size_t)w_cs
+                       : (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512)) + lane * 8;
   v8 wf[PF];
 #pragma unroll
-  for (int i = 0; i < PF; ++i) wf[i] = *reinterpret_cast<const v8*>(wq + i * 512);
+  for (int i = 0; i < PF; ++i)
+    wf[i] = *reinterpret_cast<const v8*>(TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512);
 
   // The accumulators start from the BIAS (alpha == 1, i.e. every layer but the attention score product): 128 v_add per lane
   // leave the store tail -- which is VALU-issue bound -- for nothing (the zero fill cost the same moves).  K-group 1 of a
@@ -407,7 +470,40 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     CVVAE_PROBE_MARK();
     if (grp == 0 && more) stage(c + 1, cur ^ 1);
     CVVAE_PROBE_MARK();
-    if (active) {
+    if constexpr (TFOLD) {
+      if (active) {
+        const unsigned lb = (unsigned)(cur * G::BUFB);
+        const T* wcb = wq + (size_t)c * (size_t)w_cs;
+        const T* wnx = more ? wcb + w_cs : wcb;  // the last chunk's read-ahead re-reads its own records (never past the buffer)
+        v8 ab[2][MREP];
+#pragma unroll
+        for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + tf_l0 + aoff[r]]);
+        for (int g = 0; g < tf_ng; ++g) {
+          const unsigned lbg = lb + (g == 0 ? tf_l0 : (g == 1 ? tf_l1 : tf_l2));
+          const T* wg = wcb + (g == 0 ? tf_w0 : (g == 1 ? tf_w1 : tf_w2));
+          const bool lastg = g + 1 == tf_ng;
+          const T* wn = lastg ? wnx + tf_w0 : wcb + (g == 0 ? tf_w1 : tf_w2);  // where the weight ring continues
+          const unsigned lbn = lb + (g == 0 ? tf_l1 : tf_l2);                   // LDS frame of the next group
+#pragma unroll
+          for (int i = 0; i < GS; ++i) {
+            const v8 wv = wf[i % PF];
+            const int nsp = (i + 1) % NSP, nks = (i + 1) / NSP;
+            const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * 32;
+#pragma unroll
+            for (int r = 0; r < MREP; ++r) {
+              acc[r] = Tr<T>::mfma(wv, ab[i & 1][r], acc[r]);
+              if (i + 1 < GS) ab[(i + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + (unsigned)noff]);
+            }
+            if (i + 1 == GS && !lastg) {  // first fragments of the next time group (set 0: its step 0)
+#pragma unroll
+              for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
+            }
+            wf[i % PF] = *reinterpret_cast<const v8*>(i + PF < GS ? wg + tf_rec(i + PF) : wn + tf_rec(i + PF - GS));
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    } else if (active) {
       const unsigned lb = (unsigned)(cur * G::BUFB);  // 32-bit LDS offsets throughout (no 64-bit address math)
       const T* wc = wq + (size_t)c * (STEPS * 512);
       // software-pipelined LDS reads: the activation fragments of step st+1 are requested while the MFMAs of

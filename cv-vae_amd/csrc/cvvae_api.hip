@@ -67,6 +67,7 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     if (e.pro != d->prologue || e.ups != d->upsample2x) continue;
     if (d->Cin % (16 * e.ksub)) continue;  // the instance's K-chunk must divide the consumed channels
     if (d->sc_Cin && (e.kg != 1 || e.ups != 0 || d->sc_Cin % (16 * e.ksub))) continue;  // fused shortcut: KG = 1 instances
+    if (d->w_time_folds && e.kg != 1) continue;  // the time-fold record layout is walked by the KG = 1 kernels only
     const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
     // per-phase output grid for the folded upsample (4 phases of Ho/2 x Wo/2), the output grid otherwise
     const long long tiles = fold ? cdiv(d->To, e.tt) * cdiv(d->Ho / 2, e.th) * cdiv(d->Wo / 2, e.tw) * d->B * 4
@@ -136,6 +137,7 @@ static int check_desc(const cvvae_conv_desc* d) {
   if (d->prologue < 0 || d->prologue > 2) return CVVAE_EINVAL;
   if (d->upsample2x < 0 || d->upsample2x > 2) return CVVAE_EINVAL;
   if (d->w_batch_stride < 0 || d->w_batch_stride % 16) return CVVAE_EINVAL;
+  if (d->w_time_folds != 0 && (d->w_time_folds != 1 || d->kT != 3 || d->w_batch_stride != 0)) return CVVAE_EINVAL;
   if (d->sc_Cin < 0 || (d->sc_Cin && (d->sc_in_pix_stride < d->sc_Cin || d->sc_in_pix_stride % 8))) return CVVAE_EINVAL;
   if (d->sc_Cin && (d->kT != 1 || d->kH != 3 || d->kW != 3 || d->sT != 1 || d->sH != 1 || d->sW != 1 || d->upsample2x))
     return CVVAE_EUNSUPPORTED;
@@ -242,7 +244,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
     a.in2_ps = d->sc_in_pix_stride;
     a.nchunks2 = d->sc_Cin / (16 * e->ksub);
   }
-  a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT) / 2) : 0;
+  a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT * (d->w_time_folds ? 2 : 1)) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;
   a.mode_t = d->pad_mode_t; a.mode_hw = d->pad_mode_hw;
@@ -263,6 +265,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
     a.stagger_wgs = cu_count();
   }
   a.alpha = d->alpha;
+  a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1);
   static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid
   a.res_pre = (residual && d->alpha == 1.0f && !d->out_f32 && !res_pre_off) ? 1 : 0;
   // tuning aid (tools/tune_instances.py re-launches recorded calls under CVVAE_CONV_FORCE: the record table was sized for

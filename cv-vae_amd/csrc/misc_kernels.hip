@@ -21,7 +21,7 @@ template <typename T>
 __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
                                     long long s_ci, long long s_tap, int nchunks, int ksub, T* __restrict__ dst,
                                     long long nfrag_lanes, int fold_n, long long s_fold, long long s_batch,
-                                    long long d_batch) {
+                                    long long d_batch, int dst_taps, int dst_tap0) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nfrag_lanes) return;
   src += (long long)blockIdx.y * s_batch;  // batch item (grid.y)
@@ -53,7 +53,10 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
     }
     v[j] = x;
   }
-  *reinterpret_cast<typename Tr<T>::v8*>(dst + gid * 8) = v;
+  // dst_taps / dst_tap0: this launch fills taps [dst_tap0, dst_tap0 + taps) of a layout with dst_taps taps per k16 record
+  // group (the time-fold slots of cvvae_pack_weights_tfolds); the plain packers pass dst_taps = taps, dst_tap0 = 0
+  const long long rec = ((long long)nb * nchunks + chunk) * dst_taps + dst_tap0 + tap;
+  *reinterpret_cast<typename Tr<T>::v8*>(dst + (rec * ksub + ks) * 512 + lane * 8) = v;
 }
 
 // Nearest-2x upsample folded into the conv weights (Upsample3D: F.interpolate(scale (1,2,2)) then a 3x3x3 conv,
@@ -65,7 +68,8 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
 // taps = 12, tap = (kt*2 + a)*2 + b.
 template <typename T>
 __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin, int nchunks, T* __restrict__ dst,
-                                   long long per_phase_lanes, long long phase_stride_elems, int tfold) {
+                                   long long per_phase_lanes, long long phase_stride_elems, int tfold, int dst_taps,
+                                   int dst_tap0) {
   const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid0 >= 4 * per_phase_lanes) return;
   const int phase = (int)(gid0 / per_phase_lanes);
@@ -73,13 +77,15 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
   const int py = phase >> 1, px = phase & 1;
   const int lane = (int)(gid & 63);
   long long f = gid >> 6;
-  const int ntap = tfold ? 4 : 12;  // tfold: the three time taps read the same (single) frame -> one 1x2x2 kernel per phase
+  // tfold: 0 = the three time taps kept (12 taps per phase); 1 = all three summed, 2 = centre tap only (single-frame inputs);
+  // 3 = taps {0,1} summed, 4 = taps {1,2} summed (the boundary-frame slots of cvvae_pack_weights_upfold_tfolds): 4 taps each
+  const int ntap = tfold ? 4 : 12;
   const int tap = (int)(f % ntap);
   f /= ntap;
   const int chunk = (int)(f % nchunks);
   const int nb = (int)(f / nchunks);
   const int kt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
-  const int kt_lo = tfold == 1 ? 0 : (tfold == 2 ? 1 : kt), kt_hi = tfold == 1 ? 2 : (tfold == 2 ? 1 : kt);
+  const int kt_lo = tfold == 0 ? kt : (tfold == 1 || tfold == 3 ? 0 : 1), kt_hi = tfold == 0 ? kt : (tfold == 2 || tfold == 3 ? 1 : 2);
   // folded tap sets [lo, hi] along y and x
   const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
   const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
@@ -98,7 +104,8 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
     }
     v[j] = (T)acc;
   }
-  *reinterpret_cast<typename Tr<T>::v8*>(dst + (long long)phase * phase_stride_elems + gid * 8) = v;
+  const long long rec = ((long long)nb * nchunks + chunk) * dst_taps + dst_tap0 + tap;
+  *reinterpret_cast<typename Tr<T>::v8*>(dst + (long long)phase * phase_stride_elems + rec * 512 + lane * 8) = v;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -599,7 +606,7 @@ int cvvae_pack_weights(int32_t dtype, const void* src, int32_t Cout_src, int32_t
 
 static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src, int32_t Cin_src,
                      int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad,
-                     int32_t kchunk, void* dst, int64_t d_batch_bytes, void* stream);
+                     int32_t kchunk, void* dst, int64_t d_batch_bytes, void* stream, int32_t dst_taps = 0, int32_t dst_tap0 = 0);
 
 int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t taps, int64_t s_co,
                             int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad, int32_t kchunk,
@@ -618,7 +625,8 @@ int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, in
 
 static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src, int32_t Cin_src,
                      int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t fold_n, int64_t s_fold, int32_t Cin_pad,
-                     int32_t kchunk, void* dst, int64_t d_batch_bytes, void* stream) {
+                     int32_t kchunk, void* dst, int64_t d_batch_bytes, void* stream, int32_t dst_taps, int32_t dst_tap0) {
+  if (dst_taps <= 0) dst_taps = taps;
   if (!src || !dst || Cout_src <= 0 || Cin_src <= 0 || taps <= 0 || kchunk <= 0 || kchunk % 16 || Cin_pad % kchunk ||
       Cin_pad < Cin_src || fold_n < 1)
     return CVVAE_EINVAL;
@@ -631,33 +639,70 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
   if (dtype == CVVAE_BF16)
     hipLaunchKernelGGL(pack_weights_kernel<__bf16>, dim3(grid, batch), dim3(256), 0, s, (const __bf16*)src, Cout_src, Cin_src,
                        taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (__bf16*)dst, n, fold_n,
-                       (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2));
+                       (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid, batch), dim3(256), 0, s, (const _Float16*)src, Cout_src,
                        Cin_src, taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n,
-                       fold_n, (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2));
+                       fold_n, (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
 }
 
-int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t tfold,
-                              void* dst, void* stream) {
-  if (!src || !dst || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cin_pad % 16 || tfold < 0 || tfold > 2) return CVVAE_EINVAL;
+// Time-fold slots.  A 3-tap time kernel at a clip boundary reads the SAME stored frame through two or three of its taps
+// (replicate padding: CausalConv3d front 2, Conv3d(padding_mode="replicate") 1+1 -- vae_blocks3d_sd3.py:16-104,
+// vae_models.py:266-328): W0.x + W1.x = (W0+W1).x.  The packed buffer therefore carries, after the 3 original time slots
+// (taps [0, 3*nsp)), the slots W0+W1, W1+W2 and W0+W1+W2 (fp32 sums, rounded once), nsp taps each: 6*nsp taps per record
+// group.  conv_fwd_kernel picks, per output frame, the slots whose input frames are distinct (conv_kernel.h, "time folds").
+int cvvae_pack_weights_tfolds(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t nsp, int64_t s_co,
+                              int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream) {
+  if (nsp <= 0) return CVVAE_EINVAL;
+  const int es = 2;  // bytes per element (fp16 / bf16)
+  const char* sp = (const char*)src;
+  int rc = pack_impl(dtype, src, 1, 0, Cout_src, Cin_src, 3 * nsp, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst, 0, stream, 6 * nsp, 0);
+  if (rc) return rc;
+  rc = pack_impl(dtype, sp, 1, 0, Cout_src, Cin_src, nsp, s_co, s_ci, s_tap, 2, nsp * s_tap, Cin_pad, kchunk, dst, 0, stream, 6 * nsp, 3 * nsp);
+  if (rc) return rc;
+  rc = pack_impl(dtype, sp + (long long)nsp * s_tap * es, 1, 0, Cout_src, Cin_src, nsp, s_co, s_ci, s_tap, 2, nsp * s_tap, Cin_pad, kchunk,
+                 dst, 0, stream, 6 * nsp, 4 * nsp);
+  if (rc) return rc;
+  return pack_impl(dtype, sp, 1, 0, Cout_src, Cin_src, nsp, s_co, s_ci, s_tap, 3, nsp * s_tap, Cin_pad, kchunk, dst, 0, stream, 6 * nsp,
+                   5 * nsp);
+}
+
+static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t tfold, void* dst,
+                         int32_t dst_taps, int32_t dst_tap0, void* stream) {
   const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16, ntap = tfold ? 4 : 12;
   const long long per_phase = (long long)nb * nchunks * ntap * 64;
-  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, ntap) / 2);
+  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, dst_taps) / 2);
   const int grid = (int)((4 * per_phase + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
     hipLaunchKernelGGL(pack_upfold_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)src, Cout, Cin, nchunks,
-                       (__bf16*)dst, per_phase, stride, tfold);
+                       (__bf16*)dst, per_phase, stride, tfold, dst_taps, dst_tap0);
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_upfold_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout, Cin, nchunks,
-                       (_Float16*)dst, per_phase, stride, tfold);
+                       (_Float16*)dst, per_phase, stride, tfold, dst_taps, dst_tap0);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
+}
+
+// the four folded 3x2x2 phase kernels of cvvae_pack_weights_upfold with the time-fold slots appended: 24 taps per phase
+int cvvae_pack_weights_upfold_tfolds(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, void* dst,
+                                     void* stream) {
+  if (!src || !dst || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cin_pad % 16) return CVVAE_EINVAL;
+  int rc = upfold_launch(dtype, src, Cout, Cin, Cin_pad, 0, dst, 24, 0, stream);
+  if (!rc) rc = upfold_launch(dtype, src, Cout, Cin, Cin_pad, 3, dst, 24, 12, stream);
+  if (!rc) rc = upfold_launch(dtype, src, Cout, Cin, Cin_pad, 4, dst, 24, 16, stream);
+  if (!rc) rc = upfold_launch(dtype, src, Cout, Cin, Cin_pad, 1, dst, 24, 20, stream);
+  return rc;
+}
+
+int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t tfold,
+                              void* dst, void* stream) {
+  if (!src || !dst || Cout <= 0 || Cin <= 0 || Cin_pad < Cin || Cin_pad % 16 || tfold < 0 || tfold > 2) return CVVAE_EINVAL;
+  return upfold_launch(dtype, src, Cout, Cin, Cin_pad, tfold, dst, tfold ? 4 : 12, 0, stream);
 }
 
 static int gn_nsplit(int64_t S) {

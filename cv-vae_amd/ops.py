@@ -48,6 +48,7 @@ class PackedConv:
     folded: bool = False     # packed by pack_weight_upfold: only valid with conv(..., upsample2x=2)
     batch_stride: int = 0    # bytes between the packed weights of consecutive batch items (pack_weight_batched)
     alg_taps: int = 0        # taps of the REFERENCE op when the packed weights are a folded form (0: kT*kH*kW)
+    time_folds: bool = False  # packed with the time-fold slots (pack_weight_tfolds / pack_weight_upfold(time_folds=True))
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
@@ -111,6 +112,28 @@ def pack_weight_batched(w: torch.Tensor, k: Tuple[int, int, int], cin_pad: int, 
     return PackedConv(out, b, cout, cin_pad, tuple(k), cin, batch_stride=per)
 
 
+def pack_weight_tfolds(w: torch.Tensor, bias: Optional[torch.Tensor], cin_pad: Optional[int] = None) -> PackedConv:
+    """[Cout, Cin, 3, kH, kW] weight -> packed weights with the three time-fold slots appended (cvvae_pack_weights_tfolds):
+    for convs with REPLICATE time padding, where boundary frames read one stored frame through two or three time taps."""
+    lib = L.load()
+    _need_gpu(w)
+    dt = _dt(w.dtype)
+    assert w.dim() == 5 and w.shape[2] == 3
+    w = w.contiguous()
+    co, ci, _, kh, kw = w.shape
+    nsp = kh * kw
+    k = (3, kh, kw)
+    ck = kchunk(k)
+    cin_pad = round_up(ci, ck) if cin_pad is None else cin_pad
+    out = torch.zeros(lib.cvvae_packed_weight_bytes(co, cin_pad, 6 * nsp), dtype=torch.uint8, device=w.device)
+    L.check(lib.cvvae_pack_weights_tfolds(dt, w.data_ptr(), co, ci, nsp, ci * 3 * nsp, 3 * nsp, 1, cin_pad, ck, out.data_ptr(),
+                                          _stream()), "cvvae_pack_weights_tfolds")
+    b = torch.zeros(round_up(co, 32), dtype=torch.float32, device=w.device)
+    if bias is not None:
+        b[:co] = bias.detach().to(torch.float32)
+    return PackedConv(out, b, co, cin_pad, k, ci, time_folds=True)
+
+
 def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin_pad: Optional[int] = None) -> PackedConv:
     """[Cout, Cin, 3, kH, kW] weight -> the 1 x kH x kW weight a single-frame input sees: mode 'sum' (replicate time padding:
     all three time taps read the one frame) or 'center' (zero time padding: only the centre tap reads data)."""
@@ -124,7 +147,7 @@ def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin
     return pw
 
 
-def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int = 0) -> PackedConv:
+def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int = 0, time_folds: bool = False) -> PackedConv:
     """Upsample3D's conv weight [Cout, Cin, 3, 3, 3] -> the four folded 3x2x2 phase weights (cvvae_pack_weights_upfold) for
     conv(..., upsample2x=2).  tfold 1 / 2 (single-frame input: time taps summed / centre tap only): 1x2x2 phases."""
     lib = L.load()
@@ -134,14 +157,20 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int
     cout_, cin_ = w.shape[0], w.shape[1]
     assert w.numel() == cout_ * cin_ * 27
     cin_pad = round_up(cin_, 32)
-    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 4 if tfold else 12)
+    assert not (tfold and time_folds)
+    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 24 if time_folds else (4 if tfold else 12))
     out = torch.zeros(4 * per, dtype=torch.uint8, device=w.device)
-    L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, tfold, out.data_ptr(), _stream()),
-            "cvvae_pack_weights_upfold")
+    if time_folds:  # 12 taps per phase + the time-fold slots (replicate time padding)
+        L.check(lib.cvvae_pack_weights_upfold_tfolds(dt, w.data_ptr(), cout_, cin_, cin_pad, out.data_ptr(), _stream()),
+                "cvvae_pack_weights_upfold_tfolds")
+    else:
+        L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, tfold, out.data_ptr(), _stream()),
+                "cvvae_pack_weights_upfold")
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True, alg_taps=27)
+    return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True, alg_taps=27,
+                      time_folds=time_folds)
 
 
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
@@ -184,6 +213,7 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.out_f32 = 1 if out_f32 else 0
     d.alpha = alpha
     d.w_batch_stride = pw.batch_stride
+    d.w_time_folds = 1 if pw.time_folds else 0
     if shortcut is not None:
         x2, pw2 = shortcut
         assert residual is None and x2.shape[:4] == x.shape[:4] and x2.is_contiguous() and x2.dtype == x.dtype

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 4
+#define CVVAE_ABI_VERSION 5
 
 enum { CVVAE_F16 = 0, CVVAE_BF16 = 1 };                       /* cvvae dtype */
 enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
@@ -86,7 +86,7 @@ typedef struct cvvae_conv_desc {
                                  blocks, so QK^T and PV of all frames are one launch each */
   /* fused 1x1 shortcut (cvvae_conv_fwd_gn_sc; 1x3x3 stride-1 convolutions): channels and pixel stride of the second input */
   int32_t sc_Cin;             /* multiple of the instance's K-chunk (32) */
-  int32_t sc_reserved;
+  int32_t w_time_folds;       /* 1: w_packed carries the time-fold slots (cvvae_pack_weights_tfolds / _upfold_tfolds; kT == 3 only) */
   int64_t sc_in_pix_stride;
 } cvvae_conv_desc;
 
@@ -124,6 +124,15 @@ int cvvae_pack_weights_upfold(int32_t dtype, const void* src, int32_t Cout, int3
  */
 /* batch of `batch` packings in one launch: item i reads src + i*s_batch elements and writes dst + i*dst_batch_stride bytes
  * (dst_batch_stride >= cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps), multiple of 16) */
+/* Time-fold slots (kT == 3, replicate time padding).  src taps are ordered tap = kt*nsp + sp (nsp = kH*kW spatial taps).  The
+ * packed buffer holds 6*nsp taps per record group: the 3 original time slots, then W0+W1, W1+W2, W0+W1+W2 (fp32 sums rounded
+ * once): at a clip boundary, where two or three time taps of an output frame read the same stored frame, cvvae_conv_fwd
+ * (desc.w_time_folds = 1) multiplies that frame once with the summed slot.  Size: cvvae_packed_weight_bytes(Cout, Cin_pad,
+ * 6*nsp).  _upfold_tfolds: the same for the four folded-upsample phase kernels (24 taps per phase). */
+int cvvae_pack_weights_tfolds(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t nsp, int64_t s_co,
+                              int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream);
+int cvvae_pack_weights_upfold_tfolds(int32_t dtype, const void* src, int32_t Cout, int32_t Cin, int32_t Cin_pad, void* dst,
+                                     void* stream);
 int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src,
                                int32_t Cin_src, int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad,
                                int32_t kchunk, void* dst, int64_t dst_batch_stride, void* stream);

@@ -38,7 +38,7 @@ def ref_pad(x, pad, mode_t, mode_hw):
 
 
 def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prologue=0, ups=False, out_mode=0,
-                  residual=False, seed=0, tol=None):
+                  residual=False, seed=0, tol=None, time_folds=False):
     ops, L = _ops()
     B, T, H, W = shape
     x = rnd((B, Cin, T, H, W), dtype, seed, 1.0)
@@ -72,7 +72,10 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         xp = torch.zeros(xd.shape[:-1] + (cin_pad,), dtype=dtype, device=DEV)
         xp[..., :Cin] = xd
         xd = xp
-    pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k, cin_pad=cin_pad)
+    if time_folds:  # packed with the summed time slots for boundary frames (cvvae_pack_weights_tfolds)
+        pw = ops.pack_weight_tfolds(w.to(DEV), bias.to(DEV), cin_pad=cin_pad)
+    else:
+        pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k, cin_pad=cin_pad)
     gn = None
     if prologue:
         g = torch.zeros(cin_pad); g[:Cin] = gamma
@@ -80,7 +83,7 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         assert cin_pad == Cin, "prologue cases use channel counts that need no padding"
         gn = ops.gn_stats(xd, g.to(DEV), bb.to(DEV), 1e-6)
     if ups == 2:
-        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV))
+        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), time_folds=time_folds)
     out = ops.conv(xd, pw, stride=stride, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=prologue, gn=gn,
                    residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode)
     torch.cuda.synchronize()
@@ -171,6 +174,56 @@ def test_conv333_upsample_folded(dtype, mode_hw, shuffle):
     base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
     run_conv_case(dtype, 256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, mode_hw, (1, 3, 9, 19), ups=2,
                   out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC, tol=2 * base)
+
+
+TIME_FOLD_CASES = {
+    # name: (Cin, Cout, stride, time pad, mode_hw, (B,T,H,W), prologue, ups, shuffle)   -- replicate time padding throughout
+    "causal_128_T5": (128, 128, (1, 1, 1), (2, 0), REP, (1, 5, 16, 32), 1, False, False),   # two-frame tiles + odd-frame split
+    "causal_128_T2": (128, 128, (1, 1, 1), (2, 0), REP, (2, 2, 9, 33), 1, False, False),    # frames 0 (one slot) and 1 (two)
+    "causal_256_T3": (256, 256, (1, 1, 1), (2, 0), REP, (1, 3, 16, 32), 1, False, False),
+    "sym_256_T4": (256, 256, (1, 1, 1), (1, 1), REP, (1, 4, 9, 19), 1, False, False),       # first AND last frame fold
+    "sym_128_T2": (128, 128, (1, 1, 1), (1, 1), REP, (1, 2, 16, 32), 0, False, False),      # both frames of one two-frame tile
+    "sym_512_T1": (512, 512, (1, 1, 1), (1, 1), REP, (1, 1, 8, 32), 0, False, False),       # all three taps on one frame
+    "down222_T5": (256, 256, (2, 2, 2), (2, 0), REP, (1, 5, 16, 32), 0, False, False),
+    "down122_T4": (128, 128, (1, 2, 2), (2, 0), REP, (1, 4, 16, 32), 0, False, False),
+    "out3_T5": (128, 3, (1, 1, 1), (1, 1), REP, (1, 5, 16, 32), 1, False, False),           # conv_out: NCDHW stores
+    "upfold_T3": (256, 512, (1, 1, 1), (1, 1), REP, (1, 3, 9, 19), 0, 2, True),
+    "upfold_T2_zero_hw": (256, 512, (1, 1, 1), (1, 1), ZERO, (1, 2, 8, 16), 0, 2, False),
+}
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", sorted(TIME_FOLD_CASES))
+def test_conv333_time_folds(dtype, case):
+    # Boundary frames of a clip read one stored frame through two or three time taps (replicate time padding): with the
+    # summed weight slots (pack_weight_tfolds) the kernel multiplies that frame once.  Against conv3d on the padded input;
+    # one extra rounding of each summed weight: tolerance 2x the plain conv's (x3 with the fused GN+SiLU prologue).
+    L = _ops()[1]
+    Cin, Cout, stride, tpad, mode_hw, shape, pro, ups, shuffle = TIME_FOLD_CASES[case]
+    base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    om = L.OUT_TIME_SHUFFLE if shuffle else (L.OUT_NCDHW if Cout <= 32 else L.OUT_NDHWC)
+    run_conv_case(dtype, Cin, Cout, (3, 3, 3), stride, (tpad, (1, 1), (1, 1)), REP, mode_hw, shape, prologue=pro, ups=ups,
+                  out_mode=om, tol=2 * base * (3.0 if pro else 1.0), time_folds=True)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_conv333_zero_time_padding_skips_are_exact(dtype, T):
+    # zero time padding (vae3d decoder convs): the kernel skips the taps that read a padding frame -- the result must be
+    # BIT-identical whether or not the packed weights carry the (unused) time-fold slots, and match conv3d
+    ops, L = _ops()
+    x = rnd((1, 128, T, 16, 32), dtype, 21, 1.0)
+    w = rnd((256, 128, 3, 3, 3), dtype, 22, 1.0 / (128 * 27) ** 0.5)
+    bias = rnd((256,), torch.float32, 23, 0.1)
+    xd = to_ndhwc(x).to(DEV)
+    kw = dict(pad=((1, 1), (1, 1), (1, 1)), pad_mode_t=ZERO, pad_mode_hw=ZERO)
+    a = ops.conv(xd, ops.pack_weight(w.to(DEV), bias.to(DEV), (3, 3, 3)), **kw)
+    b = ops.conv(xd, ops.pack_weight_tfolds(w.to(DEV), bias.to(DEV)), **kw)
+    assert torch.equal(a, b)
+    ref = F.conv3d(F.pad(x.float(), (1, 1, 1, 1, 1, 1)), w.float(), bias)
+    got = to_ncdhw(a.float().cpu())
+    base = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    assert (got - ref).abs().max().item() <= base * ref.abs().max().item() + 1e-6
 
 
 @pytest.mark.parametrize("dtype", DT)

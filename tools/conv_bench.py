@@ -35,6 +35,12 @@ CASES = {
     "c2d512": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
     "out128to3": (128, 3, (3, 3, 3), 17, 512, 512, P1, 1, False),
     # ResnetBlock tails: per-frame conv2 + residual add + fused GroupNorm statistics of the sum (name suffix "res")
+    # boundary-frame probes for the time folds (--tfolds): T = 1 causal = every tile multiplies ONE frame (W0+W1+W2), T = 2 adds
+    # the two-slot frame; the ratio to the plain weights is the realised cost of such tiles
+    "enc256T1": (256, 256, (3, 3, 3), 1, 256, 256, PC, 1, False),
+    "enc256T2": (256, 256, (3, 3, 3), 2, 256, 256, PC, 1, False),
+    "enc128T2": (128, 128, (3, 3, 3), 2, 512, 512, PC, 1, False),
+    "upfoldT2": (256, 512, (3, 3, 3), 2, 256, 256, P1, 0, 2),
     "c2d128res": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
     "c2d256res": (256, 256, (1, 3, 3), 9, 256, 256, P2D, 1, False),
     "c2d512res": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
@@ -64,6 +70,7 @@ def main():
     ap.add_argument("--force", action="append", default=None,
                     help='CVVAE_CONV_FORCE values to A/B ("" = library default), e.g. --force "" --force 1x8x32:2x4x1:1')
     ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--tfolds", action="store_true", help="also time every 3x3x3 case with the time-fold weight slots (force label +tf)")
     a = ap.parse_args()
     forces = a.force or [""]
     dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
@@ -89,9 +96,15 @@ def main():
             kw["gn_out"] = 32
         npix = None
         best, kname = {}, {}
+        pws = {f: pw for f in forces}
+        if a.tfolds and k[0] == 3:
+            pwt = ops.pack_weight_upfold(w, pw.bias[:cout], time_folds=True) if ups == 2 else ops.pack_weight_tfolds(w, pw.bias[:cout])
+            pws.update({f + "+tf": pwt for f in forces})
+        forces_c = list(pws)
         for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
-            for f in forces:
-                setenv(f)
+            for f in forces_c:
+                pw = pws[f]
+                setenv(f.replace("+tf", ""))
                 ops.PROFILE = lambda d, pw_, launch, f=f: (kname.__setitem__(f, ops.conv_kernel_name(d)), launch())
                 y = ops.conv(x, pw, **kw)
                 if isinstance(y, tuple):
@@ -108,7 +121,7 @@ def main():
                 best.setdefault(f, []).append(ms)
                 npix = y.numel() // cout
         fl = 2.0 * npix * cout * cin * k[0] * k[1] * k[2]
-        for f in forces:
+        for f in forces_c:
             ms = sorted(best[f])[len(best[f]) // 2]
             print(f"{name:12s} force={f or '-':22s} median {ms:8.3f} ms  {fl / ms / 1e9:8.1f} TFLOP/s  min {min(best[f]):8.3f} ms "
                   f"({fl / 1e9:.0f} GFLOP)  {kname.get(f, '')}", flush=True)
