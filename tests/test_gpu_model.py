@@ -243,25 +243,27 @@ def test_spatial_tiles_full_size_720p():
 @pytest.mark.parametrize("shape", [(1, 3, 5, 64, 64), (1, 3, 1, 64, 64)])
 def test_algebraic_folds_agree_with_unfolded_forms(shape, monkeypatch):
     """The folded forms (nearest-2x upsample as four 3x2x2 phase convs; on single frames the three time taps summed into
-    the weights) must reproduce the unfolded 27-tap forms up to the rounding of the folded weights -- both stay inside the
-    golden tolerances; here they are compared with each other on the same model and input."""
+    the weights; on clips the boundary frames' coinciding time taps summed) must reproduce the unfolded 27-tap forms up to the
+    rounding of the folded weights -- both stay inside the golden tolerances; here they are compared with each other on the
+    same model and input."""
     dtype = torch.float16
     m, _ = build("sd3", {}, dtype, 0)
     x = seeded_input(shape, 7).to(dtype).cuda()
 
-    def run():
+    def run(up, t1, tf):
+        monkeypatch.setenv("CVVAE_FOLD_UPSAMPLE", up)
+        monkeypatch.setenv("CVVAE_FOLD_T1", t1)
+        monkeypatch.setenv("CVVAE_FOLD_TIME", tf)
         z = m.encode(x).latent_dist.parameters
         return z.float().cpu(), m.decode(z[:, :16]).sample.float().cpu()
 
-    monkeypatch.setenv("CVVAE_FOLD_UPSAMPLE", "1")
-    monkeypatch.setenv("CVVAE_FOLD_T1", "1")
-    z1, y1 = run()
-    monkeypatch.setenv("CVVAE_FOLD_UPSAMPLE", "0")
-    monkeypatch.setenv("CVVAE_FOLD_T1", "0")
-    z0, y0 = run()
+    z1, y1 = run("1", "1", "1")
+    z0, y0 = run("0", "0", "0")
     assert (z1 - z0).abs().max() <= TOL[dtype]["moments"] and (y1 - y0).abs().max() <= TOL[dtype]["recon"]
     if shape[2] > 1:
-        assert torch.equal(z1, z0)  # the encoder has no upsample and T > 1: untouched by either switch
+        zt, _ = run("1", "1", "0")
+        assert torch.equal(zt, z0)  # T > 1: the encoder (no upsample) is touched by the time folds only
+        assert not torch.equal(z1, z0)  # ... and they are in effect
 
 
 @pytest.mark.parametrize("family", ["sd3", "vae3d"])
