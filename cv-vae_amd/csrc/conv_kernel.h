@@ -107,8 +107,7 @@ struct ConvArgs {
   int dbg_block;
   int w_taps;    // taps per k16 record group of the packed weights: NTAPS, or 2*NTAPS with the time-fold slots (KT == 3)
   int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
-  int stagger;   // tuning experiment (CVVAE_CONV_STAGGER): first-round workgroups start up to this many cycles late
-  int stagger_wgs;
+  int probe_nostore;  // probe builds (-DCVVAE_CONV_PROBE) only: run the store tail without its stores
 };
 
 #ifdef CVVAE_CONV_PROBE
@@ -201,12 +200,6 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (p.stagger > 0 && (int)blockIdx.x < p.stagger_wgs) {
-    // de-synchronise the CUs: all workgroups of a round otherwise reach their store tail at the same moment
-    const long long wait = (long long)(((int)blockIdx.x >> 3) & 7) * p.stagger / 8;
-    const unsigned long long t_start = __builtin_amdgcn_s_memtime();
-    while ((long long)(__builtin_amdgcn_s_memtime() - t_start) < wait) __builtin_amdgcn_s_sleep(16);
-  }
   const int grp = wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
   const int wave_n = wave % WN;
   const int wave_m = (wave / WN) % WM;
@@ -806,7 +799,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
           }
           const uint4 pk = pack8<T>(v);
 #ifdef CVVAE_CONV_PROBE
-          if (p.stagger != -1)
+          if (!p.probe_nostore)
 #endif
           *reinterpret_cast<uint4*>(outp + rowe[ri] + pr * 16 + voff) = pk;
           if (p.gnp) {
@@ -894,7 +887,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
             if (full) {
               const uint4 pk = pack8<T>(v);
   #ifdef CVVAE_CONV_PROBE
-              if (p.stagger != -1)  // probe: PROBE_NOSTORE runs the store tail without its stores
+              if (!p.probe_nostore)  // probe: PROBE_NOSTORE runs the store tail without its stores
   #endif
               *reinterpret_cast<uint4*>(o) = pk;
               if (p.gnp) {

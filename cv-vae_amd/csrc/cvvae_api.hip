@@ -260,10 +260,6 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.gn_rpb = d->gn_rows_per_batch;
   a.order = 1;
   if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
-  if (const char* f = getenv("CVVAE_CONV_STAGGER")) {                          // tuning experiment
-    a.stagger = atoi(f);
-    a.stagger_wgs = cu_count();
-  }
   a.alpha = d->alpha;
   a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1);
   static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid

@@ -48,13 +48,8 @@ CASES = {
 
 
 def setenv(f):
-    """f = "FORCE", "FORCE@ORDER" or "FORCE@ORDER@STAGGER" (CVVAE_CONV_FORCE / _ORDER / _STAGGER tuning knobs of libcvvae_hip.so)"""
+    """f = "FORCE" or "FORCE@ORDER" (CVVAE_CONV_FORCE / CVVAE_CONV_ORDER tuning knobs of libcvvae_hip.so)"""
     force, _, order = f.partition("@")
-    order, _, stagger = order.partition("@")
-    if stagger:
-        os.environ["CVVAE_CONV_STAGGER"] = stagger
-    else:
-        os.environ.pop("CVVAE_CONV_STAGGER", None)
     os.environ["CVVAE_CONV_FORCE"] = force
     if order:
         os.environ["CVVAE_CONV_ORDER"] = order

@@ -68,17 +68,19 @@ int run() {
   a.pt = PT; a.ph = 1; a.pw = 1; a.mode_t = 1; a.mode_hw = KT == 3 ? 1 : 0;
   a.tiles_t = (TT_ + TT - 1) / TT; a.tiles_h = HH / TH; a.tiles_w = WW / TW; a.ntiles_n = (COUT + 32 * WN - 1) / (32 * WN);
   a.nchunks = CIN / (16 * KSUB); a.nblk32 = (COUT + 31) / 32; a.order = 1; a.gn_rpb = 1; a.alpha = 1.f;
+  a.w_taps = taps;  // plain packed layout (no time-fold slots)
   const int grid = a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
   if (getenv("PROBE_RES") || getenv("PROBE_STATS")) {  // PROBE_RES: residual add + fused GroupNorm statistics in the epilogue
     if (getenv("PROBE_RES")) {                          // (what a ResnetBlock conv2 does); PROBE_STATS: statistics only (conv1)
       void* res; hipMalloc(&res, npix * COUT * 2); hipMemcpy(res, in, (npix * COUT * 2 < npix * CIN * 2 ? npix * COUT * 2 : npix * CIN * 2), hipMemcpyDeviceToDevice);
       a.res = res;
+      a.res_pre = getenv("PROBE_RES_TAIL") ? 0 : 1;  // default: residual pre-accumulated in the K loop (as the library does)
     }
     const int cpg = COUT / 32; int sh = 0; while ((1 << sh) < cpg) ++sh;
     a.gn_G = 32; a.gn_sh = sh; a.gn_slabs = a.tiles_t * a.tiles_h * a.tiles_w * WM * KG * (1 << (sh - 2));
     float* gnp; hipMalloc(&gnp, (size_t)a.gn_slabs * 32 * 3 * 4); a.gnp = gnp;
   }
-  if (getenv("PROBE_NOSTORE")) a.stagger = -1;  // the store tail without its stores: what is left is VALU + addressing
+  if (getenv("PROBE_NOSTORE")) a.probe_nostore = 1;  // the store tail without its stores: what is left is VALU + addressing
   a.dbg = dbg; a.dbg_block = getenv("PROBE_BLOCK") ? atoi(getenv("PROBE_BLOCK")) : grid / 2 + 3;
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) {
