@@ -210,6 +210,39 @@ int cvvae_conv_fwd_gn_sc(const cvvae_conv_desc* d, const void* in, const void* w
   return conv_impl(d, in, w_packed, bias, nullptr, gn_scale, gn_shift, sc_in, sc_w_packed, out, out_groups, out_partials, stream);
 }
 
+// Time tiles whose frames take a time fold (conv_kernel.h: fewer time groups) are SHORT.  Mixed tile durations leave the CUs
+// finishing at different moments, and the launch ends ~0.7 tile times after its work is done; scheduling the short tiles LAST
+// (longest-processing-time-first) bounds that tail by a short tile.  The kernel's block -> tile map places the leading
+// t_short_lo and trailing t_short_hi time tiles of every spatial tile after all the long ones (per XCD); this mirrors the
+// kernel's per-frame plan (tf_variant).
+static void short_time_tiles(const cvvae_conv_desc* d, int TT, int KG, cvvae::ConvArgs& a, int phases) {
+  a.t_short_lo = a.t_short_hi = 0;
+  static const bool off = getenv("CVVAE_CONV_LPT") && atoi(getenv("CVVAE_CONV_LPT")) == 0;  // tuning aid
+  if (off || d->kT != 3 || KG != 1 || a.order != 1 || a.tiles_t < 2) return;
+  if (d->pad_mode_t == CVVAE_PAD_REPLICATE && !d->w_time_folds) return;
+  auto clampT = [&](int v) { return v < 0 ? 0 : (v >= d->Ti ? d->Ti - 1 : v); };
+  auto folded = [&](int to) {
+    const int f0 = to * d->sT - d->pad_t;
+    if (d->pad_mode_t == CVVAE_PAD_REPLICATE) return clampT(f0) == clampT(f0 + 1) || clampT(f0 + 1) == clampT(f0 + 2);
+    return f0 < 0 || f0 + 2 >= d->Ti;
+  };
+  auto tile_short = [&](int i) {
+    for (int tt = 0; tt < TT; ++tt) {
+      const int to = a.t_begin + i * TT + tt;
+      if (to < d->To && folded(to)) return true;
+    }
+    return false;
+  };
+  int lo = 0, hi = 0;
+  while (lo < a.tiles_t && tile_short(lo)) ++lo;
+  while (hi < a.tiles_t - lo && tile_short(a.tiles_t - 1 - hi)) ++hi;
+  const long long inner = (long long)a.ntiles_n * phases;
+  const long long size2 = (long long)d->B * a.tiles_h * a.tiles_w * (lo + hi) * inner;
+  if (lo + hi == 0 || lo + hi >= a.tiles_t || size2 < 8) return;
+  a.t_short_lo = lo;
+  a.t_short_hi = hi;
+}
+
 static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias, const void* residual,
                      const float* gn_scale, const float* gn_shift, const void* sc_in, const void* sc_w, void* out,
                      int32_t out_groups, float* out_partials, void* stream) {
@@ -279,12 +312,14 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   }
   const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n * (fold ? 4 : 1);
   if (grid <= 0 || grid >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
+  short_time_tiles(d, e->tt, e->kg, a, (fold ? 4 : 1));
   rc = e->fn[d->dtype](a, (int)grid, (hipStream_t)stream);
   if (rc != 0 || !e2) return rc;
   // the last (odd) frame, one-frame tiles
   a.t_begin = d->To - 1;
   a.tile_base = a.tiles_t * a.tiles_h * a.tiles_w;
   a.tiles_t = 1;
+  short_time_tiles(d, 1, e2->kg, a, (fold ? 4 : 1));
   return e2->fn[d->dtype](a, (int)((long long)d->B * a.tiles_h * a.tiles_w * a.ntiles_n), (hipStream_t)stream);
 }
 

@@ -41,6 +41,8 @@ CASES = {
     "enc256T2": (256, 256, (3, 3, 3), 2, 256, 256, PC, 1, False),
     "enc128T2": (128, 128, (3, 3, 3), 2, 512, 512, PC, 1, False),
     "upfoldT2": (256, 512, (3, 3, 3), 2, 256, 256, P1, 0, 2),
+    "enc256q": (256, 256, (3, 3, 3), 9, 248, 256, PC, 1, False),   # 2232 workgroups = 8.72 rounds (enc256: exactly 9)
+    "enc256r": (256, 256, (3, 3, 3), 9, 264, 256, PC, 1, False),   # 2376 workgroups = 9.28 rounds
     "c2d128res": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
     "c2d256res": (256, 256, (1, 3, 3), 9, 256, 256, P2D, 1, False),
     "c2d512res": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
