@@ -33,6 +33,8 @@
 
 #include <type_traits>
 
+#include "tile_map.h"
+
 namespace cvvae {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -206,42 +208,10 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const int wave_m = (wave / WN) % WM;
   const int kgrp = KG == 2 ? grp : 0;  // K-group: which half of the chunk's k16 sub-chunks this wave multiplies
 
-  // ---- XCD-aware, bijective block remap: each XCD (bid % 8) gets a contiguous run of logical tiles, so
-  //      neighbouring halo tiles and all N-tiles of one M-tile share one L2.
-  int logical;
-  {
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    const int pre = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;  // logical tiles of the XCDs before mine
-    logical = pre + (bid >> 3);
-    // Short time tiles last (host: short_time_tiles).  The logical space is split in PART 1 = (spatial tile, long time tile) and
-    // PART 2 = (spatial tile, short time tile), each in the usual order; every XCD takes a contiguous share of part 1, then
-    // a contiguous share of part 2 (its workgroup count is fixed by the hardware: part-2 shares make up the difference).
-    const int ns = p.t_short_lo + p.t_short_hi;
-    if (ns > 0) {
-      const int inner = p.ntiles_n * (UPS == 2 ? 4 : 1);
-      const int nsp = nwg / (inner * p.tiles_t);  // spatial tiles x batch
-      const int tl = p.tiles_t - ns;
-      const int size1 = nsp * tl * inner;
-      const int q1 = size1 >> 3, r1 = size1 & 7;
-      const int n1 = q1 + (xcd < r1 ? 1 : 0);
-      const int pre1 = xcd < r1 ? xcd * (q1 + 1) : r1 * (q1 + 1) + (xcd - r1) * q1;
-      const int j = bid >> 3;
-      int idx, tt_sel, per;
-      if (j < n1) {
-        idx = pre1 + j;
-        per = tl;
-      } else {
-        idx = (pre - pre1) + (j - n1);
-        per = ns;
-      }
-      const int w = idx % inner, v = idx / inner;
-      const int ts = v % per, sp = v / per;
-      if (j < n1) tt_sel = p.t_short_lo + ts;
-      else tt_sel = ts < p.t_short_lo ? ts : p.tiles_t - p.t_short_hi + (ts - p.t_short_lo);
-      logical = (sp * p.tiles_t + tt_sel) * inner + w;  // back to the plain (spatial, time, phase, ntile) numbering
-    }
-  }
+  // ---- XCD-aware, bijective block -> tile map (tile_map.h): each XCD (bid % 8) gets a contiguous run of logical tiles, so
+  //      neighbouring halo tiles and all N-tiles of one M-tile share one L2; short (time-folded) tiles run last on every XCD
+  const int logical = logical_tile_of_block((int)gridDim.x, (int)blockIdx.x, p.ntiles_n * (UPS == 2 ? 4 : 1), p.tiles_t,
+                                            p.t_short_lo, p.t_short_hi);
   // logical order: N-tile fastest (the N-tiles of one pixel tile re-use its halo from L2), then TIME, then x, y, b.
   // Time-adjacent tiles share 2 of their 3 halo frames; with time next-fastest they run at the same moment on CUs of
   // the same XCD, so the K-chunk passes over the halo stay inside that XCD's 4 MiB L2 instead of thrashing it.

@@ -1,0 +1,44 @@
+// tile_map.h -- blockIdx -> logical tile of conv_fwd_kernel.  Plain C++ (no HIP types) so that the index arithmetic is
+// testable on the host (tests/c/tile_map_test.cpp, tests/test_tile_map.py): it must be a BIJECTION of [0, nwg) for
+// every grid the host can launch.
+#pragma once
+#if defined(__HIPCC__)
+#define CVVAE_HD __host__ __device__ __forceinline__
+#else
+#define CVVAE_HD inline
+#endif
+
+namespace cvvae {
+
+// Logical tile numbering: ((spatial tile * tiles_t + time tile) * phases + phase) * ntiles_n + ntile, i.e. N-tile (and upsample
+// phase) fastest -- the `inner` = phases * ntiles_n workgroups of one pixel tile re-use its halo from L2 -- then TIME, then x, y,
+// batch.  Hardware deals workgroups to the 8 XCDs round-robin (bid % 8), each XCD with its own L2:
+//   * XCD-aware remap: XCD x owns a contiguous run of logical tiles, so neighbouring halo tiles share one L2;
+//   * short tiles last (short_lo / short_hi leading / trailing time tiles of every spatial tile are SHORT: their frames take a
+//     time fold, see conv_kernel.h): the logical space is split in PART 1 = (spatial tile, long time tile) and PART 2 =
+//     (spatial tile, short time tile), each in the usual order; every XCD runs a contiguous share of part 1, then a contiguous
+//     share of part 2 (longest-processing-time-first: the launch tail is bounded by a short tile).  The XCD's workgroup count
+//     is fixed by the hardware, so its part-2 share is what remains after its part-1 share.  Requires part 2 to hold >= 8
+//     tiles (the host checks), which keeps every XCD's part-1 share within its workgroup count.
+CVVAE_HD int logical_tile_of_block(int nwg, int bid, int inner, int tiles_t, int short_lo, int short_hi) {
+  const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+  const int pre = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;  // logical tiles of the XCDs before mine
+  const int j = bid >> 3;                                                 // my index inside my XCD's run
+  const int ns = short_lo + short_hi;
+  if (ns <= 0) return pre + j;
+  const int nsp = nwg / (inner * tiles_t);  // spatial tiles x batch
+  const int tl = tiles_t - ns;
+  const int size1 = nsp * tl * inner;
+  const int q1 = size1 >> 3, r1 = size1 & 7;
+  const int n1 = q1 + (xcd < r1 ? 1 : 0);
+  const int pre1 = xcd < r1 ? xcd * (q1 + 1) : r1 * (q1 + 1) + (xcd - r1) * q1;
+  const bool part1 = j < n1;
+  const int idx = part1 ? pre1 + j : (pre - pre1) + (j - n1);
+  const int per = part1 ? tl : ns;
+  const int w = idx % inner, v = idx / inner;
+  const int ts = v % per, sp = v / per;
+  const int tt = part1 ? short_lo + ts : (ts < short_lo ? ts : tiles_t - short_hi + (ts - short_lo));
+  return (sp * tiles_t + tt) * inner + w;
+}
+
+}  // namespace cvvae
