@@ -456,3 +456,53 @@ def test_layout_and_blend(dtype):
         got = ops.blend_(a.to(DEV), b.to(DEV).clone(), o, axis).cpu()
         # same fp32 formula; an FMA contraction can move one value by one 16-bit ulp
         assert (got.float() - ref.float()).abs().max() <= (2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10) * 4
+
+
+def test_full_size_conv_properties(monkeypatch):
+    """BASELINE config 3's largest layer shape (128 -> 128, 3x3x3 causal, [1,17,512,512]): size-independent properties instead
+    of an oracle.  (a) two different tilings of the same launch (the library's choice: two-frame tiles, odd-frame split, short
+    tiles last -- and a forced one-frame tile) accumulate every output in the same order, so they must agree BIT FOR BIT: any
+    error in the block -> tile map, the halo addressing or the time-fold plan of either shows up; (b) linearity: conv(2x) ==
+    2 conv(x) exactly (scaling by 2 commutes with every rounding); (c) the fused GroupNorm statistics of the stored tensor
+    agree with a statistics pass over it."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = (torch.rand((1, 17, 512, 512, 128), generator=g) * 2 - 1).to(dtype).to(DEV)
+    w = ((torch.rand((128, 128, 3, 3, 3), generator=g) * 2 - 1) / (128 * 27) ** 0.5).to(dtype).to(DEV)
+    pw = ops.pack_weight_tfolds(w, None)
+    kw = dict(pad=((2, 0), (1, 1), (1, 1)), pad_mode_t=REP, pad_mode_hw=REP)
+    y, part = ops.conv(x, pw, gn_out=32, **kw)
+    name = {}
+    ops.PROFILE = lambda d, pw_, launch: (name.setdefault("k", ops.conv_kernel_name(d)), launch())
+    monkeypatch.setenv("CVVAE_CONV_FORCE", "1x8x32:2x4x1:1")
+    y1 = ops.conv(x, pw, **kw)
+    ops.PROFILE = None
+    monkeypatch.delenv("CVVAE_CONV_FORCE")
+    assert "t1x8x32" in name["k"], name
+    assert torch.equal(y, y1), "two tilings of the same conv differ"
+    y2 = ops.conv(x * 2, pw, **kw)
+    assert torch.equal(y2, y * 2), "conv(2x) != 2 conv(x)"
+    ones, zeros = torch.ones(128, device=DEV), torch.zeros(128, device=DEV)
+    sc_f, sh_f = ops.gn_finalize(part, ones, zeros, 1e-6)
+    sc_s, sh_s = ops.gn_stats(y, ones, zeros, 1e-6)
+    assert torch.allclose(sc_f, sc_s, rtol=2e-4, atol=1e-6) and torch.allclose(sh_f, sh_s, rtol=2e-4, atol=2e-5)
+
+
+def test_full_size_upsample_conv_properties():
+    """The 16.7-TFLOP Upsample3D conv of BASELINE config 3 (256 -> 512 at [1,9,256,256], nearest-2x + 3x3x3 + channel->time
+    shuffle, as four folded phase convs with time folds): (a) linearity, bit-exact; (b) translation: the same conv over a crop
+    of the input rows reproduces the corresponding output rows bit for bit away from the crop's padding -- every output is
+    accumulated in the same order wherever its tile lies, so a wrong tile / phase / halo address shows up."""
+    ops, L = _ops()
+    dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(6)
+    x = (torch.rand((1, 9, 256, 256, 256), generator=g) * 2 - 1).to(dtype).to(DEV)
+    w = ((torch.rand((512, 256, 3, 3, 3), generator=g) * 2 - 1) / (256 * 27) ** 0.5).to(dtype).to(DEV)
+    pw = ops.pack_weight_upfold(w, None, time_folds=True)
+    kw = dict(pad=((1, 1), (1, 1), (1, 1)), pad_mode_t=REP, pad_mode_hw=REP, upsample2x=2, out_mode=L.OUT_TIME_SHUFFLE)
+    y = ops.conv(x, pw, **kw)
+    assert tuple(y.shape) == (1, 17, 512, 512, 256)
+    assert torch.equal(ops.conv(x * 2, pw, **kw), y * 2), "conv(2x) != 2 conv(x)"
+    yc = ops.conv(x[:, :, 64:192].contiguous(), pw, **kw)  # stored rows [64, 192) -> output rows [128, 384)
+    assert torch.equal(yc[:, :, 2:-2], y[:, :, 130:382]), "a crop of the input does not reproduce the rows of the full output"
