@@ -62,6 +62,25 @@ class WeightCache:
         self._c[tag] = (key, pw)
         return pw
 
+    def conv_upfold2d(self, pre: str) -> ops.PackedConv:
+        """Upsample2D conv weights [Cout, Cin, 3, 3] as the four folded 1x2x2 phase kernels: the 2-D weight is the centre time tap
+        of an otherwise zero 3x3x3 weight (pack_weight_upfold tfold 2 = centre tap only)."""
+        w = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(w, b)
+        tag = f"{pre}#upfold2d"
+        hit = self._c.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        co, ci, kh, kw = w.shape
+        assert (kh, kw) == (3, 3), f"{pre}: weight {tuple(w.shape)} is not a 3x3 kernel"
+        w3 = torch.zeros((co, ci, 3, 3, 3), dtype=w.dtype, device=w.device)
+        w3[:, :, 1] = w.detach()
+        pw = ops.pack_weight_upfold(w3, b.detach(), 2)
+        pw.alg_taps = 9
+        self._c[tag] = (key, pw)
+        return pw
+
     def conv_t1(self, pre: str, mode: str, cin_pad: Optional[int] = None) -> ops.PackedConv:
         """3 x kH x kW weights as the single-frame (T = 1) input sees them: time taps summed ('sum') or centre tap ('center')."""
         w = self.m.get_parameter(pre + ".weight")
@@ -300,6 +319,49 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
     return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
+
+
+# --------------------------------------------------------------------------------------------------------
+# the frozen 2-D "constraint" decoder of the training path (SD3 image VAE decoder per frame)
+# --------------------------------------------------------------------------------------------------------
+def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool = True):
+    """ResnetBlock2D.forward, lvdm/modules/diffusionmodules/vae_blocks_sd3.py:368-421, on [frames,1,H,W,C]: GN(eps 1e-6)+SiLU
+    fused into conv1 and conv2 (per-frame 3x3, zero pad), 1x1 shortcut and residual add in conv2's launch."""
+    g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
+    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g1,
+                     gn_out=G32)
+    g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
+    return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
+
+
+def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """DecoderWith3DWrapper.forward over Decoder.forward (lvdm/modules/diffusionmodules/vae_models_sd3.py:297-362, 390-398):
+    z NCDHW [b,c,t,h,w] -> pixels [b,3,t,8h,8w], every frame decoded on its own ("b c t h w -> (b t) c h w": frames are the
+    batch rows here, so every GroupNorm is per frame as in the reference)."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    boc = cfg["block_out_channels"]
+    B, zin, T = z.shape[0], z.shape[1], z.shape[2]
+    cpad = ops.round_up(zin, 32)
+    h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
+    h = h.view(B * T, 1, h.shape[2], h.shape[3], cpad)
+    h, hp = ops.conv(h, wc.conv("conv_in", (1, 3, 3), cin_pad=cpad), pad=P2D, pad_mode_hw=ZERO, gn_out=G32)
+    attn = cfg["mid_block_add_attention"]
+    h, hp = c2d_resnet(wc, h, hp, "mid_block.resnets.0", want_stats=not attn)  # UNetMidBlock2D.forward, vae_blocks_sd3.py:669-681
+    if attn:
+        a = "mid_block.attentions.0"
+        h, hp = spatial_attention(wc, h, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True,
+                                  gn_out=G32)
+    h, hp = c2d_resnet(wc, h, hp, "mid_block.resnets.1")
+    for i in range(len(boc)):  # UpDecoderBlock2D.forward, vae_blocks_sd3.py:536-547
+        for j in range(cfg["layers_per_block"] + 1):
+            h, hp = c2d_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}")
+        if i != len(boc) - 1:  # Upsample2D.forward :178-230: nearest x2 + conv 3x3 (zero pad), as four folded 1x2x2 phase convs
+            h, hp = ops.conv(h, wc.conv_upfold2d(f"up_blocks.{i}.upsamplers.0.conv"), pad=P2D, pad_mode_hw=ZERO, upsample2x=2,
+                             gn_out=G32)
+    g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
+    y = ops.conv(h, wc.conv("conv_out", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g,
+                 out_mode=L.OUT_NCDHW)                      # [b*t, 3, 1, H, W]
+    return y.view(B, T, y.shape[1], y.shape[3], y.shape[4]).transpose(1, 2).contiguous()
 
 
 # --------------------------------------------------------------------------------------------------------

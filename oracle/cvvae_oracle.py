@@ -387,3 +387,47 @@ def decode_sample(z, sd: SD, cfg: dict, family: str, num_frames: Optional[int] =
 def posterior_mode(moments):
     """DiagonalGaussianDistribution.mode (lvdm/modules/distributions/distributions.py:72-73)."""
     return torch.chunk(moments, 2, dim=1)[0]
+
+
+# --------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) rank 4: the frozen 2-D "constraint" decoder of the training path (the SD3 image VAE decoder applied per frame
+# to the 3-D VAE's latents: lvdm/models/autoencoder.py:1057-1069, configs/cvvae_sd3_constraint_training.yaml:40-51)
+# --------------------------------------------------------------------------------------------------------
+def c2d_resnet(x, sd: SD, pre: str):
+    """ResnetBlock2D.forward, lvdm/modules/diffusionmodules/vae_blocks_sd3.py:368-421 (temb None, eps 1e-6, scale factor 1)."""
+    h = _swish(_gn(x, sd, pre + ".norm1", 1e-6))
+    h = F.conv2d(h, sd[pre + ".conv1.weight"], sd[pre + ".conv1.bias"], padding=1)
+    h = _swish(_gn(h, sd, pre + ".norm2", 1e-6))
+    h = F.conv2d(h, sd[pre + ".conv2.weight"], sd[pre + ".conv2.bias"], padding=1)
+    if (pre + ".conv_shortcut.weight") in sd:
+        x = F.conv2d(x, sd[pre + ".conv_shortcut.weight"], sd[pre + ".conv_shortcut.bias"])
+    return (x + h) / 1.0
+
+
+def constraint_decoder(z, sd: SD, cfg: dict):
+    """DecoderWith3DWrapper.forward (vae_models_sd3.py:390-398) over Decoder.forward (:297-362, eval path): 5-D latents
+    [b,c,t,h,w] are decoded frame by frame ("b c t h w -> (b t) c h w"), 4-D ones directly."""
+    five = z.dim() == 5
+    if five:
+        b, c, t, hh, ww = z.shape
+        z = z.permute(0, 2, 1, 3, 4).reshape(b * t, c, hh, ww)
+    boc = list(cfg.get("block_out_channels", [128, 256, 512, 512]))
+    lpb = cfg.get("layers_per_block", 2)
+    x = F.conv2d(z, sd["conv_in.weight"], sd["conv_in.bias"], padding=1)
+    x = c2d_resnet(x, sd, "mid_block.resnets.0")  # UNetMidBlock2D.forward, vae_blocks_sd3.py:669-681
+    if cfg.get("mid_block_add_attention", True):
+        x = sd3_attention(x.unsqueeze(2), sd, "mid_block.attentions.0").squeeze(2)  # same diffusers Attention, frames = batch
+    x = c2d_resnet(x, sd, "mid_block.resnets.1")
+    for i in range(len(boc)):  # UpDecoderBlock2D.forward, vae_blocks_sd3.py:536-547
+        for j in range(lpb + 1):
+            x = c2d_resnet(x, sd, f"up_blocks.{i}.resnets.{j}")
+        if i != len(boc) - 1:  # Upsample2D.forward, vae_blocks_sd3.py:178-230: nearest x2, conv 3x3 zero pad
+            x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+            pre = f"up_blocks.{i}.upsamplers.0.conv"
+            x = F.conv2d(x, sd[pre + ".weight"], sd[pre + ".bias"], padding=1)
+    x = _swish(_gn(x, sd, "conv_norm_out", 1e-6))
+    x = F.conv2d(x, sd["conv_out.weight"], sd["conv_out.bias"], padding=1)
+    if five:
+        x = x.reshape(b, t, *x.shape[1:]).permute(0, 2, 1, 3, 4)
+    return x
+

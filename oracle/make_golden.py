@@ -45,5 +45,29 @@ def main():
         print(f"{name}: moments {tuple(moments.shape)} recon {tuple(recon.shape)} wsum {wsum:.6f}")
 
 
+def main_constraint():
+    """fixtures of the frozen 2-D constraint decoder, from the reference's own DecoderWith3DWrapper"""
+    from oracle.golden_cases import CONSTRAINT_CASES
+    from oracle.ref_loader import load_reference_constraint
+
+    ref = load_reference_constraint()
+    torch.set_grad_enabled(False)
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, (cfg, zshape, wseed, zseed) in CONSTRAINT_CASES.items():
+        model = ref.DecoderWith3DWrapper(**cfg).eval()
+        sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+        model.load_state_dict(sd, strict=True)
+        z = seeded_input(zshape, zseed)
+        recon = model(z)
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), recon=recon.numpy().astype(np.float32),
+                            weight_abs_sum=np.float64(wsum), n_tensors=np.int64(len(sd)))
+        print(f"{name}: latents {tuple(zshape)} recon {tuple(recon.shape)} wsum {wsum:.6f}")
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "constraint":
+        main_constraint()
+    else:
+        main()
+        main_constraint()

@@ -33,3 +33,24 @@ def load_reference():
     sys.modules["cvvae_ref_models"] = pkg
     spec.loader.exec_module(pkg)
     return importlib.import_module("cvvae_ref_models.modeling_vae")
+
+
+def load_reference_constraint():
+    """returns the reference module lvdm/modules/diffusionmodules/vae_models_sd3.py (classes Decoder, DecoderWith3DWrapper)
+    with its sibling vae_blocks_sd3.py, loaded as the synthetic package `cvvae_ref_constraint` (the real package __init__
+    chain of lvdm pulls in the training stack)."""
+    name = "cvvae_ref_constraint.vae_models_sd3"
+    if name in sys.modules:
+        return sys.modules[name]
+    d = os.path.join(REF_ROOT, "lvdm", "modules", "diffusionmodules")
+    if not os.path.isfile(os.path.join(d, "vae_models_sd3.py")):
+        raise FileNotFoundError(f"reference not found under {REF_ROOT}")
+    if _SHIMS not in sys.path:
+        sys.path.insert(0, _SHIMS)
+    import types
+
+    pkg = types.ModuleType("cvvae_ref_constraint")
+    pkg.__path__ = [d]
+    sys.modules["cvvae_ref_constraint"] = pkg
+    return importlib.import_module(name)
+

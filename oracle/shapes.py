@@ -140,3 +140,42 @@ def vae3d_shapes(cfg):
 def state_dict_shapes(family, cfg=None):
     cfg = cfg or {}
     return sd3_shapes(cfg) if family == "sd3" else vae3d_shapes(cfg)
+
+
+def constraint2d_shapes(cfg):
+    """DecoderWith3DWrapper / Decoder (2-D, lvdm/modules/diffusionmodules/vae_models_sd3.py:196-398; blocks
+    lvdm/modules/diffusionmodules/vae_blocks_sd3.py): the frozen SD3 image decoder of the training path."""
+    boc = list(cfg.get("block_out_channels", [128, 256, 512, 512]))
+    lpb = cfg.get("layers_per_block", 2)
+    zin = cfg.get("in_channels", 16)
+    cout = cfg.get("out_channels", 3)
+    attn = cfg.get("mid_block_add_attention", True)
+    d = {}
+    top = boc[-1]
+    _conv(d, "conv_in", top, zin, (3, 3))
+    for j in range(2):
+        pre = f"mid_block.resnets.{j}"
+        _norm(d, pre + ".norm1", top); _conv(d, pre + ".conv1", top, top, (3, 3))
+        _norm(d, pre + ".norm2", top); _conv(d, pre + ".conv2", top, top, (3, 3))
+    if attn:
+        a = "mid_block.attentions.0"
+        _norm(d, a + ".group_norm", top)
+        for n in ("to_q", "to_k", "to_v", "to_out.0"):
+            _lin(d, f"{a}.{n}", top, top)
+    rev = list(reversed(boc))
+    prev = rev[0]
+    for i, c in enumerate(rev):
+        for j in range(lpb + 1):
+            pre = f"up_blocks.{i}.resnets.{j}"
+            ci = prev if j == 0 else c
+            _norm(d, pre + ".norm1", ci); _conv(d, pre + ".conv1", c, ci, (3, 3))
+            _norm(d, pre + ".norm2", c); _conv(d, pre + ".conv2", c, c, (3, 3))
+            if ci != c:
+                _conv(d, pre + ".conv_shortcut", c, ci, (1, 1))
+        if i != len(rev) - 1:
+            _conv(d, f"up_blocks.{i}.upsamplers.0.conv", c, c, (3, 3))
+        prev = c
+    _norm(d, "conv_norm_out", boc[0])
+    _conv(d, "conv_out", cout, boc[0], (3, 3))
+    return d
+

@@ -299,3 +299,30 @@ def test_hip_graph_replay_is_bit_identical(family):
     assert not torch.equal(before, after)
     m.enable_hip_graphs(False)
     assert torch.equal(after, m.encode(xs[0]).latent_dist.parameters)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("name", ["constraint2d_t3_8", "constraint2d_4d_12x8"])
+def test_constraint_decoder_golden(name, dtype, golden_dir):
+    """the frozen 2-D constraint decoder of the training path (DecoderWith3DWrapper, imported through the
+    reference's own module path) against fixtures produced by the reference's module; same tolerance bands as the 3-D
+    decoder.  5-D latents must decode exactly as their frames decoded one by one (every GroupNorm is per frame)."""
+    from lvdm.modules.diffusionmodules.vae_models_sd3 import DecoderWith3DWrapper
+    from oracle.golden_cases import CONSTRAINT_CASES
+
+    cfg, zshape, wseed, zseed = CONSTRAINT_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = DecoderWith3DWrapper(**cfg)
+    m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, wseed), strict=True)
+    m = m.to(dtype).cuda().eval().requires_grad_(False)  # lvdm/models/autoencoder.py:1057-1058
+    z = seeded_input(zshape, zseed).to(dtype).cuda()
+    rec = m(z)
+    assert rec.dtype == dtype and tuple(rec.shape) == gold["recon"].shape
+    r = rec.float().cpu().numpy()
+    e = np.abs(r - gold["recon"]).max()
+    psnr = 10 * np.log10(4.0 / max(float(((r - gold["recon"]) ** 2).mean()), 1e-20))
+    print(f"\n[{name} {str(dtype)[6:]}] recon max|d| {e:.3e} PSNR {psnr:.1f} dB")
+    assert e <= TOL[dtype]["recon"] and psnr >= TOL[dtype]["psnr"]
+    if z.dim() == 5:
+        for t in range(z.shape[2]):
+            assert torch.equal(m(z[:, :, t].contiguous()), rec[:, :, t]), "a frame decoded alone differs from the clip"

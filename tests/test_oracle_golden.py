@@ -32,3 +32,23 @@ def test_oracle_matches_reference_golden(name, golden_dir):
     assert tuple(mom.shape) == gold["moments"].shape and tuple(rec.shape) == gold["recon"].shape
     assert np.abs(mom.numpy() - gold["moments"]).max() <= TOL_MOMENTS
     assert np.abs(rec.numpy() - gold["recon"]).max() <= TOL_RECON
+
+
+from oracle.golden_cases import CONSTRAINT_CASES  # noqa: E402
+from oracle.shapes import constraint2d_shapes  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(CONSTRAINT_CASES))
+def test_oracle_constraint_decoder_matches_reference_golden(name, golden_dir):
+    """the frozen 2-D constraint decoder (DecoderWith3DWrapper) -- the oracle restatement against fixtures
+    produced by the reference's own module (oracle/make_golden.py constraint)."""
+    cfg, zshape, wseed, zseed = CONSTRAINT_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    sd = seeded_state_dict(constraint2d_shapes(cfg), wseed)
+    assert len(sd) == int(gold["n_tensors"])
+    wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(wsum - float(gold["weight_abs_sum"])) < 1e-6 * wsum
+    with torch.no_grad():
+        rec = O.constraint_decoder(seeded_input(zshape, zseed), sd, cfg)
+    assert tuple(rec.shape) == gold["recon"].shape
+    assert np.abs(rec.numpy() - gold["recon"]).max() <= TOL_RECON

@@ -55,3 +55,25 @@ def test_no_cpu_fallback():
     m = cvvae_amd.CVVAESD3Model()
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.encoder(torch.zeros(1, 3, 1, 32, 32))
+
+
+def test_constraint_decoder_keys_match_table_and_reference():
+    """the frozen 2-D constraint decoder, instantiated through the reference's module path with the yaml's
+    params (configs/cvvae_sd3_constraint_training.yaml:40-51): same state-dict keys and shapes as the table, and -- when the
+    reference is mounted -- as the reference's own DecoderWith3DWrapper; unsupported configurations fail at construction."""
+    from lvdm.modules.diffusionmodules.vae_models_sd3 import DecoderWith3DWrapper
+    from oracle.golden_cases import CONSTRAINT_CFG
+    from oracle.ref_loader import load_reference_constraint
+    from oracle.shapes import constraint2d_shapes
+
+    m = DecoderWith3DWrapper(**CONSTRAINT_CFG)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == constraint2d_shapes(CONSTRAINT_CFG) and len(got) == 138
+    if reference_available():
+        with torch.device("meta"):
+            r = load_reference_constraint().DecoderWith3DWrapper(**CONSTRAINT_CFG)
+        assert {k: tuple(v.shape) for k, v in r.state_dict().items()} == got
+    with pytest.raises(NotImplementedError):
+        DecoderWith3DWrapper(**dict(CONSTRAINT_CFG, norm_type="spatial"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m(torch.zeros(1, 16, 2, 8, 8))
