@@ -40,11 +40,14 @@
 #define CVVAE_CONV_G10(X) \
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
   X(1,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
+// (the 64-pixel tile also with 32-channel K-chunks: the 128-pixel one would need 2 x 134 KiB of LDS)
 #define CVVAE_CONV_G5(X) \
   X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0) \
   X(3,3,3, 2,2,2, 1,8,16, 1,8,1, 1, 0,0) \
-  X(3,3,3, 1,2,2, 1,8,16, 1,8,1, 1, 0,0)
+  X(3,3,3, 1,2,2, 1,8,16, 1,8,1, 1, 0,0) \
+  X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 2, 0,0) \
+  X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0)
 // 1x3x3 per-frame conv (ResnetBlock conv2), K-chunk 32 channels
 #define CVVAE_CONV_G6(X) \
   X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 0,0) \
