@@ -194,7 +194,6 @@ template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, in
 __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB>;
   using v8 = typename Tr<T>::v8;
-  using v4 = typename Tr<T>::v4;
   constexpr int MREP = G::MREP, PIXB = G::PIXB, NPASS = G::NPASS, STEPS = G::STEPS, STEPS_W = G::STEPS_W, PF = G::PF,
                 CK = G::CK, NTAPS = G::NTAPS;
 
