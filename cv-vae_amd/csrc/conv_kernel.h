@@ -262,6 +262,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   int hf_a = 0, hf_b = G::FT - 1;  // halo frames [hf_a, hf_b] some wave of this workgroup reads
   if constexpr (TFOLD) {
     // plan of output frame `to`: number of time groups, (weight slot, tap frame) of groups 0 and 1 (group 2 is always W2 on 2)
+    // (the same table as time_fold_plan() in tile_map.h, which the host uses and tests/c/tile_map_test.cpp checks against the
+    //  27-tap sum for every clip length, stride and padding)
     auto tf_variant = [&](int to, int& ng, int& slot0, int& slot1, int& dt0, int& dt1) {
       const int f0 = to * ST - p.pt;  // input frame of time tap 0 before padding
       auto clampT = [&](int v) { return v < 0 ? 0 : (v >= p.Tl ? p.Tl - 1 : v); };

@@ -224,11 +224,8 @@ static void short_time_tiles(const cvvae_conv_desc* d, int TT, int KG, cvvae::Co
   static const bool off = getenv("CVVAE_CONV_LPT") && atoi(getenv("CVVAE_CONV_LPT")) == 0;  // tuning aid
   if (off || d->kT != 3 || KG != 1 || a.order != 1 || a.tiles_t < 2) return;
   if (d->pad_mode_t == CVVAE_PAD_REPLICATE && !d->w_time_folds) return;
-  auto clampT = [&](int v) { return v < 0 ? 0 : (v >= d->Ti ? d->Ti - 1 : v); };
-  auto folded = [&](int to) {
-    const int f0 = to * d->sT - d->pad_t;
-    if (d->pad_mode_t == CVVAE_PAD_REPLICATE) return clampT(f0) == clampT(f0 + 1) || clampT(f0 + 1) == clampT(f0 + 2);
-    return f0 < 0 || f0 + 2 >= d->Ti;
+  auto folded = [&](int to) {  // the frame's plan has fewer than three time groups (tile_map.h)
+    return cvvae::time_fold_plan(to, d->sT, d->pad_t, d->Ti, d->pad_mode_t == CVVAE_PAD_REPLICATE, d->w_time_folds != 0).ng != 3;
   };
   auto tile_short = [&](int i) {
     for (int tt = 0; tt < TT; ++tt) {

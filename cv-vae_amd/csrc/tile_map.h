@@ -1,6 +1,6 @@
-// tile_map.h -- blockIdx -> logical tile of conv_fwd_kernel.  Plain C++ (no HIP types) so that the index arithmetic is
-// testable on the host (tests/c/tile_map_test.cpp, tests/test_tile_map.py): it must be a BIJECTION of [0, nwg) for
-// every grid the host can launch.
+// tile_map.h -- index logic of conv_fwd_kernel that is plain C++ (no HIP types), so that it is testable on the host
+// (tests/c/tile_map_test.cpp, tests/test_tile_map.py): the blockIdx -> logical tile map (a BIJECTION of [0, nwg) for every grid
+// the host can launch) and the per-frame time-fold plan.
 #pragma once
 #if defined(__HIPCC__)
 #define CVVAE_HD __host__ __device__ __forceinline__
@@ -39,6 +39,38 @@ CVVAE_HD int logical_tile_of_block(int nwg, int bid, int inner, int tiles_t, int
   const int ts = v % per, sp = v / per;
   const int tt = part1 ? short_lo + ts : (ts < short_lo ? ts : tiles_t - short_hi + (ts - short_lo));
   return (sp * tiles_t + tt) * inner + w;
+}
+
+// Time-fold plan of ONE output frame `to` of a 3-tap time kernel (conv_kernel.h, "time folds"): input frames f0 + {0,1,2},
+// f0 = to*ST - pad_front, mapped into [0, Tl) by the padding mode.  The frame's taps are walked as `ng` TIME GROUPS; group g
+// multiplies LDS halo frame dt_g (relative to the frame's first tap) with weight slot slot_g, where slots 0,1,2 = W0,W1,W2 and
+// 3,4,5 = W0+W1, W1+W2, W0+W1+W2 (cvvae_pack_weights_tfolds; `has_sum_slots`).  Group 2, when present, is always (W2, 2).
+//   replicate padding: taps that read the same stored frame are merged (needs the summed slots);
+//   zero padding: taps on a padding frame are dropped (exact; needs no extra slots).
+// Host-tested: the plan reproduces  sum_dt W_dt * frame(f0 + dt)  for every (Tl, stride, pad, to)  (tests/c/tile_map_test.cpp).
+struct TimeFoldPlan {
+  int ng, slot0, slot1, dt0, dt1;
+};
+CVVAE_HD TimeFoldPlan time_fold_plan(int to, int ST, int pad_front, int Tl, bool replicate, bool has_sum_slots) {
+  const int f0 = to * ST - pad_front;
+  TimeFoldPlan q = {3, 0, 1, 0, 1};
+  if (replicate) {
+    if (has_sum_slots) {
+      const int c0 = f0 < 0 ? 0 : (f0 >= Tl ? Tl - 1 : f0);
+      const int c1 = f0 + 1 < 0 ? 0 : (f0 + 1 >= Tl ? Tl - 1 : f0 + 1);
+      const int c2 = f0 + 2 < 0 ? 0 : (f0 + 2 >= Tl ? Tl - 1 : f0 + 2);
+      const bool eq01 = c0 == c1, eq12 = c1 == c2;
+      if (eq01 && eq12) q = {1, 5, 1, 1, 1};
+      else if (eq01) q = {2, 3, 2, 1, 2};
+      else if (eq12) q = {2, 0, 4, 0, 1};
+    }
+  } else {
+    const bool z0 = f0 < 0 || f0 >= Tl, z2 = f0 + 2 < 0 || f0 + 2 >= Tl;
+    if (z0 && z2) q = {1, 1, 1, 1, 1};
+    else if (z0) q = {2, 1, 2, 1, 2};
+    else if (z2) q = {2, 0, 1, 0, 1};
+  }
+  return q;
 }
 
 }  // namespace cvvae

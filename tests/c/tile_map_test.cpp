@@ -1,6 +1,7 @@
-// Host-side check of conv_fwd_kernel's blockIdx -> logical tile map (cv-vae_amd/csrc/tile_map.h): for every grid shape the
-// host can launch it must be a bijection of [0, nwg); with short tiles, every XCD must run all its long tiles before its
-// short ones.  Built with g++ by tests/test_tile_map.py (no GPU, no HIP).
+// Host-side checks of cv-vae_amd/csrc/tile_map.h: (1) conv_fwd_kernel's blockIdx -> logical tile map must be a bijection of
+// [0, nwg) for every grid shape the host can launch, and with short tiles every XCD must run all its long tiles before its
+// short ones; (2) the per-frame time-fold plan must reproduce the 3-tap sum under both padding modes.  Built with g++ by
+// tests/test_tile_map.py (no GPU, no HIP).
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -36,7 +37,57 @@ static int check(int nsp, int tiles_t, int inner, int lo, int hi) {
   return 0;
 }
 
+// The time-fold plan of an output frame must reproduce the 3-tap sum: for every stored frame s, the total weight the plan
+// applies to s (slot 3 = W0+W1, 4 = W1+W2, 5 = W0+W1+W2) must equal the weight the taps apply to it under the padding mode.
+static int check_time_folds() {
+  long n = 0;
+  for (int Tl = 1; Tl <= 9; ++Tl)
+    for (int ST = 1; ST <= 2; ++ST)
+      for (int pad = 0; pad <= 2; ++pad)
+        for (int rep = 0; rep <= 1; ++rep)
+          for (int sums = 0; sums <= 1; ++sums)
+            for (int to = 0; to * ST - pad + 2 - (2 - pad) < Tl + 2 && to < Tl + 2; ++to) {
+              const int f0 = to * ST - pad;
+              if (!rep && (f0 + 1 < 0 || f0 + 1 >= Tl)) continue;  // zero padding never pads by more than one frame per side
+              const cvvae::TimeFoldPlan q = cvvae::time_fold_plan(to, ST, pad, Tl, rep != 0, sums != 0);
+              // expected[s][k]: coefficient of W_k on stored frame s
+              int expect[16][3] = {}, got[16][3] = {};
+              for (int dt = 0; dt < 3; ++dt) {
+                int s = f0 + dt;
+                if (rep) s = s < 0 ? 0 : (s >= Tl ? Tl - 1 : s);
+                else if (s < 0 || s >= Tl) continue;
+                expect[s][dt] += 1;
+              }
+              const int slots[3] = {q.slot0, q.slot1, 2}, dts[3] = {q.dt0, q.dt1, 2};
+              for (int g = 0; g < q.ng; ++g) {
+                int s = f0 + dts[g];  // the LDS halo frame holds the padded view: clamp / zero as the staging does
+                if (rep) s = s < 0 ? 0 : (s >= Tl ? Tl - 1 : s);
+                else if (s < 0 || s >= Tl) continue;
+                const int sl = slots[g];
+                if (sl >= 3 && !sums) {
+                  std::printf("summed slot without summed weights\n");
+                  return 1;
+                }
+                const bool w0 = sl == 0 || sl == 3 || sl == 5, w1 = sl == 1 || sl == 3 || sl == 4 || sl == 5,
+                           w2 = sl == 2 || sl == 4 || sl == 5;
+                got[s][0] += w0; got[s][1] += w1; got[s][2] += w2;
+              }
+              for (int s = 0; s < Tl; ++s)
+                for (int k = 0; k < 3; ++k)
+                  if (expect[s][k] != got[s][k]) {
+                    std::printf("time-fold plan wrong: Tl %d ST %d pad %d rep %d sums %d to %d (ng %d slots %d %d dts %d %d): frame %d W%d "
+                                "expect %d got %d\n", Tl, ST, pad, rep, sums, to, q.ng, q.slot0, q.slot1, q.dt0, q.dt1, s, k,
+                                expect[s][k], got[s][k]);
+                    return 1;
+                  }
+              ++n;
+            }
+  std::printf("time-fold plan ok: %ld frames\n", n);
+  return 0;
+}
+
 int main() {
+  if (check_time_folds()) return 1;
   long cases = 0;
   // plain map (no short tiles): any grid
   for (int nwg = 1; nwg <= 600; ++nwg) {

@@ -15,4 +15,4 @@ def test_block_to_tile_map_is_a_bijection(tmp_path):
     subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "cv-vae_amd", "csrc"),
                     os.path.join(ROOT, "tests", "c", "tile_map_test.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
-    assert "tile map ok" in out, out
+    assert "tile map ok" in out and "time-fold plan ok" in out, out
