@@ -336,6 +336,23 @@ class _Config(SimpleNamespace):
         return dict(self.__dict__)
 
 
+def _convert_deprecated_attention_keys(sd: dict) -> dict:
+    """diffusers' ModelMixin.from_pretrained renames the parameters of attention blocks saved by its pre-0.18 `AttentionBlock`
+    (`_convert_deprecated_attention_blocks`: query / key / value / proj_attn -> to_q / to_k / to_v / to_out.0) before the strict
+    load; the sd3-family mid blocks (`Attention(..., _from_deprecated_attn_block=True)`, vae_blocks3d_sd3.py:806-822) are such
+    blocks, so a checkpoint written by an older diffusers loads through the reference -- and through this loader -- unchanged."""
+    ren = {".query.": ".to_q.", ".key.": ".to_k.", ".value.": ".to_v.", ".proj_attn.": ".to_out.0."}
+    out = {}
+    for k, v in sd.items():
+        if ".attentions." in k:
+            for old, new in ren.items():
+                if old in k:
+                    k = k.replace(old, new)
+                    break
+        out[k] = v
+    return out
+
+
 class _CVVAEBase(nn.Module):
     config_name = "config.json"
     _defaults: dict = {}
@@ -396,7 +413,7 @@ class _CVVAEBase(nn.Module):
             if not os.path.isfile(binp):
                 raise OSError(f"no diffusion_pytorch_model.safetensors/.bin under {root}")
             sd = torch.load(binp, map_location="cpu", weights_only=True)
-        model.load_state_dict(sd, strict=True)
+        model.load_state_dict(_convert_deprecated_attention_keys(sd), strict=True)
         if torch_dtype is not None:
             model = model.to(torch_dtype)
         model.eval()

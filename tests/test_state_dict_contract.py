@@ -77,3 +77,31 @@ def test_constraint_decoder_keys_match_table_and_reference():
         DecoderWith3DWrapper(**dict(CONSTRAINT_CFG, norm_type="spatial"))
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m(torch.zeros(1, 16, 2, 8, 8))
+
+
+def test_from_pretrained_accepts_deprecated_attention_keys(tmp_path):
+    """A checkpoint whose mid-block attention parameters carry diffusers' pre-0.18 names (query / key / value / proj_attn) loads
+    like through diffusers' ModelMixin.from_pretrained (which renames them before its strict load)."""
+    import json
+
+    from safetensors.torch import save_file
+
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model()
+    d = tmp_path / "ckpt" / "vae3d_sd3"
+    d.mkdir(parents=True)
+    ren = {".to_q.": ".query.", ".to_k.": ".key.", ".to_v.": ".value.", ".to_out.0.": ".proj_attn."}
+    sd, n = {}, 0
+    for k, v in m.state_dict().items():
+        for new, old in ren.items():
+            if ".attentions." in k and new in k:
+                k = k.replace(new, old)
+                n += 1
+                break
+        sd[k] = v.detach().clone()
+    assert n == 16  # 2 mid blocks x 4 projections x (weight, bias)
+    save_file(sd, str(d / "diffusion_pytorch_model.safetensors"))
+    (d / "config.json").write_text(json.dumps(dict(m.config.to_dict(), _class_name="CVVAESD3Model")))
+    m2 = cvvae_amd.CVVAESD3Model.from_pretrained(str(tmp_path / "ckpt"), subfolder="vae3d_sd3")
+    for (k1, v1), (k2, v2) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert k1 == k2 and torch.equal(v1, v2)
