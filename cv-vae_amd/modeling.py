@@ -404,14 +404,16 @@ class _CVVAEBase(nn.Module):
             cfg = json.load(f)
         cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
         model = cls(**cfg)
-        st = os.path.join(root, "diffusion_pytorch_model.safetensors")
+        variant = kwargs.get("variant")  # diffusers: diffusion_pytorch_model.<variant>.safetensors (e.g. "fp16")
+        stem = "diffusion_pytorch_model" + (f".{variant}" if variant else "")
+        st = os.path.join(root, stem + ".safetensors")
         if os.path.isfile(st):
             from safetensors.torch import load_file
             sd = load_file(st)
         else:
-            binp = os.path.join(root, "diffusion_pytorch_model.bin")
+            binp = os.path.join(root, stem + ".bin")
             if not os.path.isfile(binp):
-                raise OSError(f"no diffusion_pytorch_model.safetensors/.bin under {root}")
+                raise OSError(f"no {stem}.safetensors/.bin under {root}")
             sd = torch.load(binp, map_location="cpu", weights_only=True)
         model.load_state_dict(_convert_deprecated_attention_keys(sd), strict=True)
         if torch_dtype is not None:
