@@ -3,18 +3,30 @@
 
 One "step" = one pass of the hot path over one clip: `vae.encode(x).latent_dist.mode()` then `vae.decode(z).sample`
 for a synthetic [1,3,17,512,512] clip (config.workload = BASELINE cfg 3: vae3d_sd3, bf16).  Inputs are resident in
-HBM before the timed region.  N>1 (launched by torch.distributed.run): one process per GPU, every rank codes its own
-clip (the path partitions into independent 17-frame windows -- SURVEY.md 8e -- so there is no data-path collective;
-weak scaling); value = clips of all ranks * 17 frames / max-over-ranks time.
+HBM before the timed region.
+
+N > 1: one process per GPU over RCCL.  `python bench.py --gpus N` launches the N ranks itself (it re-executes under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started by an external launcher
+(RANK / WORLD_SIZE in the environment) it simply is one of the ranks.  cfg 3 / 2 / 5: every rank codes its own clip(s)
+(the path partitions into independent 17-frame windows -- SURVEY.md 8e -- so there is no data-path collective; weak
+scaling); cfg 4: ONE clip, its temporal windows sharded over the ranks (cvvae_amd/dist.py; strong scaling).
+value = frames of all ranks / max-over-ranks time.
 
 Besides the contract line, the JSON carries
   roofline     -- the dominant kernel's algorithmic FLOPs / its HIP-event time, measured live in a separate pass
+                  (+ the EXECUTED MFMA FLOPs of the same launches: the algebraic folds remove work)
+  parity       -- latent max / mean |delta| and recon PSNR of THIS build against the reference-generated fixture of the
+                  workload (tests/golden/cfg3_sd3_t17_512.npz), in the bench dtype, next to the reference's own noise
+  hbm          -- algorithmic GB/s of the step and the PMC-counted traffic of the committed profile (profiles/)
+  mfma_busy    -- SQ counter ratio of the dominant kernel from the committed PMC pass (profiles/pmc_sq.json)
   cpu_baseline -- the CPU oracle (oracle/cvvae_oracle.py, a PyTorch-CPU restatement of the reference: "port") on a
                   bounded sample of the same workload, on this box's host cores (rank 0, N=1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -22,9 +34,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 MFMA_PEAK_TFLOPS = 2500.0  # dense bf16/fp16 MFMA peak of MI355X (/opt/skills/guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBPS = 8000.0     # HBM3E, same guide
 
 WORKLOADS = {
     # name: (family, B, T, H, W)            -- BASELINE.json configs; cfg 3 is the one the metric is quoted on (default)
@@ -32,7 +43,7 @@ WORKLOADS = {
     "cfg2_vae3d_T17_256": ("vae3d", 1, 17, 256, 256),
     # cfg 1: image mode (T = 1) -- the reference's own CPU-runnable case; launch-bound on a GPU (see --hip-graphs)
     "cfg1_vae3d_T1_256": ("vae3d", 1, 1, 256, 256),
-    # cfg 4: ONE long clip, its 8 temporal windows (x 6 spatial tiles each) sharded over the ranks (cv-vae_amd/dist.py):
+    # cfg 4: ONE long clip, its 8 temporal windows (x 6 spatial tiles each) sharded over the ranks (cvvae_amd/dist.py):
     # strong scaling, encode + decode of the whole clip, gathered latents
     "cfg4_sd3_T129_720x1280": ("sd3", 1, 129, 720, 1280),
     # cfg 5: batch-8 T=33 encode-only (training-side latent pre-compute); the batch is split over the ranks
@@ -42,6 +53,11 @@ ENC_TFLOP = {"cfg3_sd3_T17_512": 22.842, "cfg2_vae3d_T17_256": 5.674, "cfg1_vae3
 # algorithmic FLOPs per unit of work (BASELINE.md section 3 / SURVEY 8d: 2*M*N*K of every conv/linear + attention)
 ALG_TFLOP = {"cfg3_sd3_T17_512": 91.41, "cfg2_vae3d_T17_256": 22.79, "cfg4_sd3_T129_720x1280": 3656.0,
              "cfg5_sd3_B8_T33_512_encode": 365.4, "cfg1_vae3d_T1_256": 2.27}
+# algorithmic HBM bytes per unit (every conv/linear reads its input once, writes its output once)
+ALG_GB = {"cfg3_sd3_T17_512": 48.9, "cfg2_vae3d_T17_256": 12.7, "cfg4_sd3_T129_720x1280": 1945.0,
+          "cfg5_sd3_B8_T33_512_encode": 268.0, "cfg1_vae3d_T1_256": 1.5}
+GOLDEN_OF = {"cfg3_sd3_T17_512": "cfg3_sd3_t17_512", "cfg2_vae3d_T17_256": "cfg2_vae3d_t17_256",
+             "cfg1_vae3d_T1_256": "cfg1_vae3d_t1_256"}
 
 
 def parse():
@@ -50,12 +66,41 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="cfg3_sd3_T17_512", choices=sorted(WORKLOADS))
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true",
+                    help="time the oracle on the FULL workload shape with all host cores (minutes) instead of the bounded sample")
     ap.add_argument("--hip-graphs", action="store_true",
                     help="replay each encoder/decoder pass as a captured hipGraph (vae.enable_hip_graphs(); for launch-bound inputs)")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="cfg 4, N > 1: skip the sharded == single-process latent check")
     return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start the N ranks under torch.distributed.run and relay rank 0's line."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this host driver (RCCL needs it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def time_groups(to, sT, pad_t, Ti, replicate, has_slots):
+    """number of time groups the kernel walks for output frame `to` of a 3-tap time kernel (tile_map.h time_fold_plan)"""
+    f0 = to * sT - pad_t
+    if replicate:
+        if not has_slots:
+            return 3
+        c = [min(max(f0 + i, 0), Ti - 1) for i in range(3)]
+        return 1 if c[0] == c[1] == c[2] else (2 if (c[0] == c[1] or c[1] == c[2]) else 3)
+    z0, z2 = not (0 <= f0 < Ti), not (0 <= f0 + 2 < Ti)
+    return 1 if (z0 and z2) else (2 if (z0 or z2) else 3)
 
 
 def conv_flops(d, pw):
@@ -64,9 +109,22 @@ def conv_flops(d, pw):
     return 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * (pw.cin_real * taps + d.sc_Cin)
 
 
+def conv_flops_executed(d, pw):
+    """MFMA FLOPs the launch really issues on useful rows/columns: the kernel's own taps (12 per phase pixel for the folded
+    upsample, kH*kW for a single-frame fold) over the padded channel counts, minus the time groups the time folds skip."""
+    sp = 4 if d.upsample2x == 2 else d.kH * d.kW  # spatial taps per output pixel as executed
+    if d.kT == 3:
+        rep = d.pad_mode_t == 1
+        tg = sum(time_groups(to, d.sT, d.pad_t, d.Ti, rep, bool(d.w_time_folds)) for to in range(d.To))
+    else:
+        tg = d.To
+    return 2.0 * d.B * tg * d.Ho * d.Wo * d.Cout * (d.Cin * sp) + 2.0 * d.B * d.To * d.Ho * d.Wo * d.Cout * d.sc_Cin
+
+
 def roofline_pass(step_fn):
     """Re-run one step with a HIP event pair around every conv launch (on the stream it is launched on) and
     aggregate per kernel instance."""
+    import torch
     from cvvae_amd import ops
 
     rec = []
@@ -77,7 +135,7 @@ def roofline_pass(step_fn):
         e0.record()
         launch()
         e1.record()
-        rec.append((name, conv_flops(d, pw), e0, e1))
+        rec.append((name, conv_flops(d, pw), conv_flops_executed(d, pw), e0, e1))
 
     ops.PROFILE = observer
     try:
@@ -86,48 +144,84 @@ def roofline_pass(step_fn):
     finally:
         ops.PROFILE = None
     agg = {}
-    for name, fl, e0, e1 in rec:
-        a = agg.setdefault(name, [0.0, 0.0, 0])
+    for name, fl, fx, e0, e1 in rec:
+        a = agg.setdefault(name, [0.0, 0.0, 0, 0.0])
         a[0] += fl
         a[1] += e0.elapsed_time(e1) * 1e-3
         a[2] += 1
+        a[3] += fx
     return agg
 
 
-def cpu_baseline(family, H=512, W=512):
+def cpu_baseline(family, T=17, H=512, W=512, full=False):
     """CPU oracle on a bounded sample: the same network on a 17-frame window at 192x192 (0.14 of the 512x512 frame
-    area; one temporal window, no spatial tiling -- like the workload), scaled by pixel count to the workload's frame size."""
+    area; one temporal window, no spatial tiling -- like the workload), scaled by pixel count to the workload's frame size.
+    full=True: the workload's own shape, every host core, no extrapolation."""
+    import torch
     from oracle import cvvae_oracle as O
     from oracle.seeded import seeded_input, seeded_state_dict
     from oracle.shapes import state_dict_shapes
 
-    cores = min(os.cpu_count() or 1, 32)  # oneDNN conv at this size stops scaling (and regresses) beyond ~32 threads
+    # oneDNN conv at the sample size stops scaling (and regresses) beyond ~32 threads; the full shape takes every core
+    cores = (os.cpu_count() or 1) if full else min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
     sd = seeded_state_dict(state_dict_shapes(family), 0)
-    hw = 192  # ~10 s of CPU work on the GPU box's host cores
-    x = seeded_input((1, 3, 17, hw, hw), 0)
+    hh, ww = (H, W) if full else (min(H, 192), min(W, 192))  # sample: ~10 s of CPU work on the GPU box's host cores
+    x = seeded_input((1, 3, T, hh, ww), 0)
     with torch.no_grad():
         t0 = time.time()
         mom = O.encode_moments(x, sd, {}, family)
+        t1 = time.time()
         rec = O.decode_sample(O.posterior_mode(mom), sd, {}, family)
         dt = time.time() - t0
     assert rec.shape == x.shape
-    area_scale = (H * W) / float(hw * hw)
-    return {
-        "value": round(17.0 / (dt * area_scale), 5),
+    area_scale = (H * W) / float(hh * ww)
+    cpu_model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        pass
+    out = {
+        "value": round(T / (dt * area_scale), 5),
         "unit": "frames/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"oracle (PyTorch-CPU fp32 restatement) encode+decode of 1x3x17x{hw}x{hw} in {dt:.1f}s; value = 17 frames "
-                  f"/ (t * {area_scale:.1f}) i.e. scaled by pixel count to the {H}x{W} workload",
+        "extrapolated": area_scale != 1.0,
+        "cpu_model": cpu_model,
+        "encode_s": round(t1 - t0, 2), "decode_s": round(dt - (t1 - t0), 2),
+        "sample": (f"oracle (PyTorch-CPU fp32 restatement) encode+decode of the full 1x3x{T}x{hh}x{ww} workload in {dt:.1f}s"
+                   if area_scale == 1.0 else
+                   f"oracle (PyTorch-CPU fp32 restatement) encode+decode of 1x3x{T}x{hh}x{ww} in {dt:.1f}s; value = {T} frames "
+                   f"/ (t * {area_scale:.1f}) i.e. scaled by pixel count to the {H}x{W} workload"),
     }
+    # the one-off FULL-size timing kept from this round's GPU box (bench.py --cpu-baseline-full), when the default sample ran
+    kept = os.path.join(ROOT, "profiles", "cpu_baseline_full.json")
+    if not full and os.path.isfile(kept):
+        with open(kept) as f:
+            out["full_size_measured"] = json.load(f)
+    return out
+
+
+def profile_json(name):
+    p = os.path.join(ROOT, "profiles", name)
+    if os.path.isfile(p):
+        with open(p) as f:
+            return json.load(f)
+    return None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    import torch
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; running {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
@@ -139,12 +233,14 @@ def main():
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     import cvvae_amd
+    from oracle import parity as P  # checker only: seeded weights + the fixture comparison (never inside the timed region)
 
     family, B, T, H, W = WORKLOADS[args.workload]
-    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float16
-    torch.manual_seed(0)
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
-    vae = cls().to(dtype).cuda().eval()  # random-init weights of the named architecture (no checkpoint access)
+    vae = cls()
+    P.load_seeded(vae, 0)  # random weights of the named architecture with PyTorch's default-init statistics (no checkpoint access)
+    vae = vae.to(dtype).cuda().eval()
     if args.hip_graphs:
         vae.enable_hip_graphs(True)
     cfg4 = args.workload.startswith("cfg4")
@@ -166,7 +262,7 @@ def main():
             return D.decode_windows_sharded(vae, z, gather=False)      # pixels stay sharded (713 MB if gathered)
     elif cfg5:
         def step():
-            return vae.encode(x).latent_dist.mode()
+            return vae.encode_latents(x, sample=False)                 # the latent pre-compute API
     else:
         def step():
             z = vae.encode(x).latent_dist.mode()
@@ -208,14 +304,29 @@ def main():
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": args.dtype,
-        "data": "synthetic uniform[-1,1) clip, random-init weights (seed 0) of the named architecture",
+        "data": "synthetic uniform[-1,1) clip, seeded random weights with default-init statistics of the named architecture",
         "config": {"workload": f"{args.workload}: {family} " + ("encode(x).mode()" if cfg5 else "encode(x).mode() + decode(z)") +
                                f", x=[{B},3,{T},{H},{W}] per GPU",
                    "clips_per_gpu": B, "hip_graphs": bool(args.hip_graphs),
                    "parallelism": (f"temporal windows sharded x{world}, latents all-gathered" if strong else
                                    f"independent clips x{world} (no collective)")},
         "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * units / elapsed, 1),
+        "hbm": {"algorithmic_gbps": round(ALG_GB[args.workload] * units / elapsed, 1), "peak_gbps": HBM_PEAK_GBPS,
+                "note": "algorithmic bytes (BASELINE.md section 3) / step time; the path is MFMA-bound (AI ~1900 FLOP/B)"},
     }
+
+    if cfg4 and dist is not None and not args.no_check:
+        # the sharded run must reproduce the single-process wrapper bit for bit (windows are independent network calls)
+        from cvvae_amd import dist as D
+        mom = D.encode_windows_sharded(vae, x)
+        ok = True
+        if rank == 0:
+            ref = vae.encode(x).latent_dist.parameters
+            ok = bool(torch.equal(mom, ref))
+            out["sharded_equals_single_process"] = ok
+        okt = torch.tensor([1 if ok else 0], device="cuda")
+        dist.broadcast(okt, 0)
+        assert int(okt.item()) == 1, "cfg 4: window-sharded latents differ from the single-process result"
 
     if rank == 0 and not (cfg5 or (cfg4 and dist is not None)):
         # encode / decode split of one step (separate, untimed pass; events on the launch stream)
@@ -234,29 +345,50 @@ def main():
             out["encode_tflops"] = round(et / enc_ms * 1e3, 1)
             out["decode_tflops"] = round((ALG_TFLOP[args.workload] - et) / dec_ms * 1e3, 1)
             out["encode_frac_of_mfma_peak"] = round(et / enc_ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
-    if rank == 0 and not args.no_roofline:
+    if rank == 0 and not args.no_roofline and args.dtype != "f32":
         vae.enable_hip_graphs(False)  # per-launch timing needs the eager launches
         agg = roofline_pass(step)
-        name, (fl, sec, n) = max(agg.items(), key=lambda kv: kv[1][1])
+        name, (fl, sec, n, fx) = max(agg.items(), key=lambda kv: kv[1][1])
         ach = fl / sec / 1e12
         # HBM traffic per launch of that kernel: from the committed PMC passes of this same command (profiles/)
         traffic = None
-        tj = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.isfile(tj):
-            with open(tj) as f:
-                k = json.load(f).get("kernels", {}).get(name.split("_", 3)[3] if name.count("_") >= 3 else name)
+        short = name.split("_", 3)[3] if name.count("_") >= 3 else name
+        tj = profile_json("pmc_traffic.json")
+        if tj:
+            k = tj.get("kernels", {}).get(short)
             if k:
                 traffic = k["fetch_bytes"] + k["write_bytes"]
+            if "step_total_bytes" in tj:
+                out["hbm"]["pmc_bytes_per_step"] = tj["step_total_bytes"]
+                out["hbm"]["pmc_gbps"] = round(tj["step_total_bytes"] / (elapsed / args.steps) / 1e9, 1)
         out["roofline"] = {
             "bound": "mfma", "kernel": name, "launches_per_step": n,
             "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+            "executed": round(fx / sec / 1e12, 1),
             "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": traffic,
             "traffic_unit": "bytes/launch (PMC, profiles/pmc_traffic.json)",
         }
-        out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "ms": round(v[1] * 1e3, 3), "launches": v[2]}
+        sq = profile_json("pmc_sq.json")
+        if sq and short in sq.get("kernels", {}):
+            out["mfma_busy"] = dict(sq["kernels"][short], source="profiles/pmc_sq.json (SQ counters, separate --pmc passes)")
+        tot_fx, tot_sec = sum(v[3] for v in agg.values()), sum(v[1] for v in agg.values())
+        out["executed_tflops_conv_kernels"] = round(tot_fx / tot_sec / 1e12, 1)
+        out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "executed_tflops": round(v[3] / v[1] / 1e12, 1),
+                              "ms": round(v[1] * 1e3, 3), "launches": v[2]}
                           for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    if rank == 0 and not args.no_parity and args.workload in GOLDEN_OF and \
+            os.path.isfile(os.path.join(P.GOLDEN_DIR, GOLDEN_OF[args.workload] + ".npz")):
+        vae.enable_hip_graphs(False)
+        r = P.measure(vae, GOLDEN_OF[args.workload])
+        out["parity"] = {
+            "against": f"tests/golden/{GOLDEN_OF[args.workload]}.npz = the reference's own modules, CPU fp32, same seeded weights/input",
+            "latent_max_abs": float(f"{r['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{r['latent_mean_abs']:.3e}"),
+            "recon_psnr_db": round(r["recon_psnr_db"], 2), "recon_max_abs": float(f"{r['recon_max_abs']:.3e}"),
+            "reference_own_noise_same_dtype": P.REFERENCE_SELF_NOISE.get(args.dtype),
+            "north_star_tolerance": "|delta| <= 1e-3 on latents",
+        }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(family, H, W)
+        out["cpu_baseline"] = cpu_baseline(family, T, H, W, full=args.cpu_baseline_full)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """ctypes binding of libcvvae_hip.so (include/cvvae.h).  There is NO fallback: if the HIP library is missing
 the import of any compute entry fails loudly -- build it with `python -c "import __graft_entry__ as g; g.build()"`
-or `make -C cv-vae_amd/csrc -j8`."""
+or `make -C cvvae_amd/csrc -j8`."""
 import ctypes
 import os
 
@@ -87,7 +87,7 @@ def load():
     if not os.path.isfile(LIB_PATH):
         raise CvvaeError(
             f"{LIB_PATH} not found: the MI355X HIP extension is not built and there is no CPU/eager fallback. "
-            "Run `make -C cv-vae_amd/csrc -j8` (or __graft_entry__.build()).")
+            "Run `make -C cvvae_amd/csrc -j8` (or __graft_entry__.build()).")
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

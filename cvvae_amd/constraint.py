@@ -12,7 +12,7 @@ import torch
 import torch.nn as nn
 
 from . import engine
-from .modeling import ConvP, NormP, _holder, _Net
+from .modeling import ConvP, NormP, _channel_constraints, _holder, _Net
 
 
 def _resnet2d(cin: int, cout: int) -> nn.Module:
@@ -36,6 +36,8 @@ class Decoder(_Net):
                 or act_fn != "silu" or norm_type != "group" or any(c % 32 for c in boc)):
             raise NotImplementedError("the MI355X path covers the shipped constraint decoder: UpDecoderBlock2D blocks, "
                                       "GroupNorm(32) + SiLU, channel counts that are multiples of 32")
+        bad = _channel_constraints(boc)  # buildable / loadable, but a forward pass raises this message (class default (64,))
+        self._unsupported = bad[0] if bad else None
         self.layers_per_block = layers_per_block
         rev = list(reversed(boc))
         top = rev[0]

@@ -686,7 +686,13 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   // tile and 3 % of a per-frame conv.)
   // fused GroupNorm statistics of what is stored (the ROUNDED values, as the reference's GroupNorm sees them): per lane
   // 4 slots (pr, q) of 4 consecutive channels each: sum, sum of squares; valid-pixel count per pr
+  // SHIFTED sums (numerics: sum x^2 - (sum x)^2 / n cancels as (mean/sigma)^2 * eps): every slot accumulates x - K and (x - K)^2
+  // with K = the slot's first stored value of lane 0 of the half-wave (one v_readlane per slot and tile, one v_sub per value),
+  // so the cancellation is governed by (mean - K) / sigma = O(1) instead of mean / sigma.
   float gs[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gq[2][2] = {{0.f, 0.f}, {0.f, 0.f}}, gc[2] = {0.f, 0.f};
+  float gk[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+  bool gk_set = false;  // fast tail (wave-uniform)
+  unsigned gkm = 0;     // general tail (per lane): bit pr = the shifts of channel pair pr are set
   // per channel pair pr (tile independent): my 8-channel run, its bias, where it lands
   int c8v[2], ccv[2], nshv[2];
   float bia[2][8];
@@ -807,13 +813,19 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
             uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
             asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
             unpack8<T>(pq, rv);
+            if (!gk_set) {  // first stored fragment of the tile (wave-uniform): the shifts of both channel pairs
+              gk[pr][0] = __shfl(rv[0], lane_e & 32);
+              gk[pr][1] = __shfl(rv[4], lane_e & 32);
+              gk_set = pr == 1;
+            }
             gc[pr] += 1.f;
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
               for (int j = 0; j < 4; ++j) {
-                gs[pr][q] += rv[q * 4 + j];
-                gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
+                const float dv = rv[q * 4 + j] - gk[pr][q];
+                gs[pr][q] += dv;
+                gq[pr][q] += dv * dv;
               }
           }
         }
@@ -895,13 +907,22 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
                 uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
                 asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
                 unpack8<T>(pq, rv);
+                if (!((gkm >> pr) & 1)) {  // shifts: the values of the first storing lane of my half-wave (per-lane code here)
+                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);
+                  const unsigned hm = (lane_e & 32) ? (unsigned)(mk >> 32) : (unsigned)mk;
+                  const int src = (lane_e & 32) + __builtin_ctz(hm);
+                  gk[pr][0] = __shfl(rv[0], src);
+                  gk[pr][1] = __shfl(rv[4], src);
+                  gkm |= 1u << pr;
+                }
                 gc[pr] += 1.f;
   #pragma unroll
                 for (int q = 0; q < 2; ++q)
   #pragma unroll
                   for (int j = 0; j < 4; ++j) {
-                    gs[pr][q] += rv[q * 4 + j];
-                    gq[pr][q] += rv[q * 4 + j] * rv[q * 4 + j];
+                    const float dv = rv[q * 4 + j] - gk[pr][q];
+                    gs[pr][q] += dv;
+                    gq[pr][q] += dv * dv;
                   }
               }
             } else {
@@ -946,8 +967,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
           }
           const int g = c >> p.gn_sh, sub = (c >> 2) & (E - 1);
           const float n = gc[pr] * 4.f;
-          const float mean = n > 0.f ? gs[pr][q] / n : 0.f;
-          float m2 = gq[pr][q] - gs[pr][q] * mean;
+          const float dmean = n > 0.f ? gs[pr][q] / n : 0.f;  // mean - K
+          const float mean = n > 0.f ? gk[pr][q] + dmean : 0.f;
+          float m2 = gq[pr][q] - gs[pr][q] * dmean;
           m2 = m2 > 0.f ? m2 : 0.f;
           float* o = p.gnp + (((size_t)b * p.gn_slabs + (size_t)(slab * E + sub)) * p.gn_G + g) * 3;
           o[0] = n;

@@ -492,6 +492,73 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
   }
 }
 
+// General frame count (T' > 8: en_de_n_frames_a_time = None or > 28): one wave per (pixel, query frame), online softmax over
+// the key frames, a lane owns up to 4 x 8 channels (C <= 2048).  Same arithmetic as above: fp32 scores / probabilities /
+// accumulation, one rounding at the store.
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_attn_general_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                    const T* __restrict__ v, long long P, int Tn, long long S,
+                                                                    int C, float scale, T* __restrict__ out) {
+  const long long wid = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*S*Tn
+  if (wid >= P * Tn) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C >> 3;
+  const long long pix = wid / Tn;
+  const int i = (int)(wid - pix * Tn);
+  const long long b = pix / S, s = pix - b * S;
+  const long long base = (b * Tn * S + s) * C;
+  const long long tstride = S * C;
+  float qf[4][8], o[4][8];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int vv = lane + u * 64;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { qf[u][e] = 0.f; o[u][e] = 0.f; }
+    if (vv < nv) unpack8<T>(*reinterpret_cast<const uint4*>(q + base + i * tstride + vv * 8), qf[u]);
+  }
+  float mx = -3.0e38f, sum = 0.f;
+  for (int j = 0; j < Tn; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int vv = lane + u * 64;
+      if (vv < nv) {
+        float kf[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(k + base + j * tstride + vv * 8), kf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) d += qf[u][e] * kf[e];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) d += __shfl_xor(d, off);
+    d *= scale;
+    const float nmx = fmaxf(mx, d);
+    const float corr = __expf(mx - nmx), pj = __expf(d - nmx);
+    sum = sum * corr + pj;
+    mx = nmx;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int vv = lane + u * 64;
+      if (vv < nv) {
+        float vf[8];
+        unpack8<T>(*reinterpret_cast<const uint4*>(v + base + j * tstride + vv * 8), vf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * corr + pj * vf[e];
+      }
+    }
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int vv = lane + u * 64;
+    if (vv < nv) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[u][e] *= inv;
+      *reinterpret_cast<uint4*>(out + base + i * tstride + vv * 8) = pack8<T>(o[u]);
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // layout at the boundary
 // ---------------------------------------------------------------------------------------------------------
@@ -789,11 +856,23 @@ int cvvae_transpose(int32_t dtype, const void* in, int32_t batch, int32_t R, int
 int cvvae_temporal_attention(int32_t dtype, const void* q, const void* k, const void* v, int32_t B, int32_t T, int64_t S,
                              int32_t C, void* out, void* stream) {
   if (!q || !k || !v || !out || B <= 0 || S <= 0 || T <= 0 || C <= 0 || C % 8) return CVVAE_EINVAL;
-  if (T > 8) return CVVAE_EUNSUPPORTED;
   const float scale = 1.0f / sqrtf((float)C);
   const long long P = (long long)B * S;
-  const int grid = (int)((P + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
+  if (T > 8) {  // general frame count: one wave per (pixel, query frame)
+    if (C > 2048 || P * T >= (1LL << 33)) return CVVAE_EUNSUPPORTED;
+    const int gridg = (int)((P * T + 3) / 4);
+    if (dtype == CVVAE_BF16)
+      hipLaunchKernelGGL(temporal_attn_general_kernel<__bf16>, dim3(gridg), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k,
+                         (const __bf16*)v, P, T, (long long)S, C, scale, (__bf16*)out);
+    else if (dtype == CVVAE_F16)
+      hipLaunchKernelGGL(temporal_attn_general_kernel<_Float16>, dim3(gridg), dim3(256), 0, s, (const _Float16*)q,
+                         (const _Float16*)k, (const _Float16*)v, P, T, (long long)S, C, scale, (_Float16*)out);
+    else
+      return CVVAE_EINVAL;
+    CHECK_LAUNCH();
+  }
+  const int grid = (int)((P + 3) / 4);
   if (dtype == CVVAE_BF16)
     hipLaunchKernelGGL(temporal_attn_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)q, (const __bf16*)k,
                        (const __bf16*)v, P, T, (long long)S, C, scale, (__bf16*)out);

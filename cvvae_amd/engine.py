@@ -252,6 +252,19 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
     return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 
+def _encoder_input(x: torch.Tensor, cfg: dict, dtype: torch.dtype):
+    """the encoder's NDHWC input, channel-padded for conv_in's K chunk: converted from the caller's NCDHW clip, or -- cfg
+    "ndhwc_in" (the device-side pixel pre-processing, modeling.encode_frames_u8) -- the padded NDHWC clip as it arrives."""
+    if cfg.get("ndhwc_in"):
+        T, cs = x.shape[1], x.shape[-1]
+        cpad = 32 if (T == 1 and fold_t1()) else 16
+        if x.dtype != dtype or cs < cpad or not x.is_contiguous():
+            raise ValueError(f"ndhwc_in: expected a contiguous [B,T,H,W,>={cpad}] {dtype} clip with zero pad channels")
+        return x, cpad
+    cpad = 32 if (x.shape[2] == 1 and fold_t1()) else 16  # the folded single-frame path runs 32-channel K-chunks
+    return ops.ncdhw_to_ndhwc(x, cpad, dtype), cpad
+
+
 # --------------------------------------------------------------------------------------------------------
 # vae3d_sd3 family
 # --------------------------------------------------------------------------------------------------------
@@ -281,8 +294,7 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
-    cpad = 32 if (x.shape[2] == 1 and fold_t1()) else 16  # the folded single-frame path runs 32-channel K-chunks
-    h = ops.ncdhw_to_ndhwc(x, cpad, dtype)
+    h, cpad = _encoder_input(x, cfg, dtype)
     h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                      gn_out=G32)
     for i in range(len(boc)):
@@ -389,8 +401,7 @@ def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
-    cpad = 32 if (x.shape[2] == 1 and fold_t1()) else 16  # the folded single-frame path runs 32-channel K-chunks
-    h = ops.ncdhw_to_ndhwc(x, cpad, dtype)
+    h, cpad = _encoder_input(x, cfg, dtype)
     h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, gn_out=G32)
     for lvl in range(nlev):
         for j in range(cfg["num_res_blocks"]):

@@ -10,6 +10,7 @@ diffusers is not a dependency: config / weight loading and the two small output 
 import json
 import math
 import os
+import warnings
 from types import SimpleNamespace
 from typing import Optional, Tuple, Union
 
@@ -64,6 +65,7 @@ class _Net(nn.Module):
         super().__init__()
         self._wc = None
         self._cfg = {}
+        self._unsupported = None  # set by the wrapper when the configuration cannot run on the kernels (message)
         self._graphs = None  # enable_hip_graphs(): {(shape, dtype, device, switches): _GraphEntry}
         self._graph_cap = 0
 
@@ -76,13 +78,19 @@ class _Net(nn.Module):
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         if x.dim() != 5:
             raise ValueError(f"expected a [B,C,T,H,W] tensor, got shape {tuple(x.shape)}")
+        if self._unsupported:
+            raise NotImplementedError(self._unsupported)
         if not x.is_cuda:
-            raise RuntimeError("cv-vae_amd runs on an MI355X (ROCm) device only; move the model and the input to 'cuda'. "
+            raise RuntimeError("cvvae_amd runs on an MI355X (ROCm) device only; move the model and the input to 'cuda'. "
                                "There is no CPU fallback.")
-        if self._graphs is not None and not torch.cuda.is_current_stream_capturing():
-            return self._forward_graphed(x)
-        out = type(self)._program(self._cache(), x, self._cfg)
-        return out
+        pdev = self.conv_in.weight.device
+        if pdev != x.device:
+            raise RuntimeError(f"input on {x.device} but the network's parameters are on {pdev}")
+        # every launch of the pass goes to x's device and its current stream, whatever the caller's current device is
+        with torch.cuda.device(x.device):
+            if self._graphs is not None and not torch.cuda.is_current_stream_capturing():
+                return self._forward_graphed(x, **kwargs)
+            return type(self)._program(self._cache(), x, dict(self._cfg, **kwargs))
 
     # ---- hipGraph replay of a whole encoder / decoder pass ------------------------------------------------------------
     # One pass is 40-110 kernel launches.  On clips the GPU time hides the host's launch work; on images and small tiles
@@ -97,9 +105,9 @@ class _Net(nn.Module):
         object.__setattr__(self, "_graph_cap", max(1, int(max_shapes)))
         return self
 
-    def _forward_graphed(self, x: torch.Tensor) -> torch.Tensor:
+    def _forward_graphed(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        key = (tuple(x.shape), x.dtype, x.device.index, engine.fold_upsample(), engine.fold_t1(), engine.fuse_shortcut(), engine.fold_time())
+        key = (tuple(x.shape), x.dtype, x.device.index, tuple(sorted(kwargs.items())), engine.fold_upsample(), engine.fold_t1(), engine.fuse_shortcut(), engine.fold_time())
         ent = self._graphs.get(key)
         if ent is not None and ent[0] != sig:  # weights were replaced / moved / modified: the captured pointers are stale
             del self._graphs[key]
@@ -107,7 +115,7 @@ class _Net(nn.Module):
         if ent is None:
             while len(self._graphs) >= self._graph_cap:
                 self._graphs.pop(next(iter(self._graphs)))
-            prog, wc, cfg = type(self)._program, self._cache(), self._cfg
+            prog, wc, cfg = type(self)._program, self._cache(), dict(self._cfg, **kwargs)
             static_in = x.detach().clone()
             cur = torch.cuda.current_stream()
             side = torch.cuda.Stream()
@@ -269,22 +277,29 @@ class Decoder(_Net):
 # ------------------------------------------------------------------------------------------------------
 # output types (diffusers' AutoencoderKLOutput / DecoderOutput / DiagonalGaussianDistribution contracts)
 # ------------------------------------------------------------------------------------------------------
-class AutoencoderKLOutput(dict):
+class _Output(dict):
+    """diffusers' BaseOutput contract: attribute access, string keys, and integer / slice indexing over `to_tuple()`
+    (`vae.decode(z)[0]`)."""
+
+    def to_tuple(self):
+        return tuple(self.values())
+
+    def __getitem__(self, k):
+        if isinstance(k, (int, slice)):
+            return self.to_tuple()[k]
+        return dict.__getitem__(self, k)
+
+
+class AutoencoderKLOutput(_Output):
     def __init__(self, latent_dist):
         super().__init__(latent_dist=latent_dist)
         self.latent_dist = latent_dist
 
-    def to_tuple(self):
-        return (self.latent_dist,)
 
-
-class DecoderOutput(dict):
+class DecoderOutput(_Output):
     def __init__(self, sample):
         super().__init__(sample=sample)
         self.sample = sample
-
-    def to_tuple(self):
-        return (self.sample,)
 
 
 class DiagonalGaussianDistribution:
@@ -311,6 +326,12 @@ class DiagonalGaussianDistribution:
 
     def mode(self) -> torch.Tensor:
         return self.mean
+
+    def nll(self, sample: torch.Tensor, dims=(1, 2, 3)) -> torch.Tensor:
+        if self.deterministic:
+            return torch.Tensor([0.0])
+        logtwopi = math.log(2.0 * math.pi)
+        return 0.5 * torch.sum(logtwopi + self.logvar + torch.pow(sample - self.mean, 2) / self.var, dim=list(dims))
 
     def kl(self, other=None):
         dims = list(range(1, self.mean.dim()))
@@ -353,6 +374,13 @@ def _convert_deprecated_attention_keys(sd: dict) -> dict:
     return out
 
 
+def _channel_constraints(widths) -> list:
+    """Block widths the kernels can run: the fused GroupNorm statistics need a power-of-two number >= 4 of channels per group
+    (32 groups) and the 1x1 convs (shortcuts, attention) consume 128-channel K chunks -> widths of 128 * 2^k."""
+    bad = [int(w) for w in widths if w < 128 or w % 128 or ((w // 32) & (w // 32 - 1))]
+    return [f"block widths must be 128 * 2^k (GroupNorm slots of the fused statistics, 128-channel K chunks of the 1x1 convs); got {bad}"] if bad else []
+
+
 class _CVVAEBase(nn.Module):
     config_name = "config.json"
     _defaults: dict = {}
@@ -389,6 +417,14 @@ class _CVVAEBase(nn.Module):
         self.reshape_z_dim_to_4 = cfg["reshape_z_dim_to_4"]  # stored, never applied in encode (Appendix A.1)
         self.reshape_x_dim_to_4 = cfg["reshape_x_dim_to_4"]
 
+    def _flag_widths(self, widths):
+        """widths the kernels cannot run: the model can still be built, loaded, converted and saved (parameter holder), but a
+        forward pass raises NotImplementedError with this message instead of failing inside a launch."""
+        bad = _channel_constraints(widths)
+        if bad:
+            warnings.warn(f"{type(self).__name__}: {bad[0]} -- this configuration can be loaded / saved but not run on the MI355X path")
+            self.encoder._unsupported = self.decoder._unsupported = bad[0]
+
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, subfolder: Optional[str] = None,
                         torch_dtype: Optional[torch.dtype] = None, **kwargs):
@@ -403,10 +439,18 @@ class _CVVAEBase(nn.Module):
         with open(cfg_path) as f:
             cfg = json.load(f)
         cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+        extra = sorted(k for k in cfg if k not in cls._defaults)
+        if extra:  # diffusers' ConfigMixin ignores keys the class does not take
+            warnings.warn(f"{cfg_path}: config keys {extra} are not used by {cls.__name__} and were ignored")
+            cfg = {k: v for k, v in cfg.items() if k in cls._defaults}
         model = cls(**cfg)
         variant = kwargs.get("variant")  # diffusers: diffusion_pytorch_model.<variant>.safetensors (e.g. "fp16")
         stem = "diffusion_pytorch_model" + (f".{variant}" if variant else "")
         st = os.path.join(root, stem + ".safetensors")
+        for idx in (st + ".index.json", os.path.join(root, stem + ".bin.index.json")):
+            if os.path.isfile(idx):
+                raise NotImplementedError(f"{idx}: sharded checkpoints are not supported; merge the shards into one "
+                                          f"{stem}.safetensors (the CV-VAE checkpoints are single files of < 1 GB)")
         if os.path.isfile(st):
             from safetensors.torch import load_file
             sd = load_file(st)
@@ -415,7 +459,17 @@ class _CVVAEBase(nn.Module):
             if not os.path.isfile(binp):
                 raise OSError(f"no {stem}.safetensors/.bin under {root}")
             sd = torch.load(binp, map_location="cpu", weights_only=True)
-        model.load_state_dict(_convert_deprecated_attention_keys(sd), strict=True)
+        sd = _convert_deprecated_attention_keys(sd)
+        own = model.state_dict()
+        missing = sorted(k for k in own if k not in sd)
+        bad_shape = sorted(k for k in own if k in sd and tuple(sd[k].shape) != tuple(own[k].shape))
+        if missing or bad_shape:  # a half-initialised codec is never what the caller wants: fail with the full list
+            raise RuntimeError(f"{root}: checkpoint does not fit {cls.__name__}: missing {missing[:8]}{'...' if len(missing) > 8 else ''}"
+                               f", shape mismatch {bad_shape[:8]}")
+        unexpected = sorted(k for k in sd if k not in own)
+        if unexpected:  # diffusers warns about and drops keys the model does not own
+            warnings.warn(f"{root}: {len(unexpected)} checkpoint tensors are not used by {cls.__name__}: {unexpected[:6]}...")
+        model.load_state_dict({k: v for k, v in sd.items() if k in own}, strict=True)
         if torch_dtype is not None:
             model = model.to(torch_dtype)
         model.eval()
@@ -465,25 +519,29 @@ class _CVVAEBase(nn.Module):
     @staticmethod
     def _blend(a, b, o, axis):
         if not b.is_cuda:
-            raise RuntimeError("cv-vae_amd blends on the MI355X only (no CPU path)")
-        if a.is_contiguous() and b.is_contiguous():
-            return ops.blend_(a, b, o, axis)
-        ac, bc = a.contiguous(), b.contiguous()
-        ops.blend_(ac, bc, o, axis)
-        b.copy_(bc)
-        return b
+            raise RuntimeError("cvvae_amd blends on the MI355X only (no CPU path)")
+        with torch.cuda.device(b.device):
+            if a.is_contiguous() and b.is_contiguous():
+                return ops.blend_(a, b, o, axis)
+            ac, bc = a.contiguous(), b.contiguous()
+            ops.blend_(ac, bc, o, axis)
+            b.copy_(bc)
+            return b
 
     # ---- spatial tiles (modeling_vae.py:144-191, 230-277) ---------------------------------------------
-    def _spatial_tiled(self, x, net, tile, stride, overlap_out, stride_out, **kwargs):
+    def _spatial_tiled(self, x, net, tile, stride, overlap_out, stride_out, hdim=3, wdim=4, **kwargs):
+        """hdim / wdim: the H and W axes of the INPUT (3, 4 for NCDHW; 2, 3 for the NDHWC clips of encode_frames_u8); the
+        network outputs are always NCDHW."""
         rows = []
-        for i in range(0, x.shape[3], stride):
+        H, W = x.shape[hdim], x.shape[wdim]
+        for i in range(0, H, stride):
             cols = []
-            for j in range(0, x.shape[4], stride):
-                cols.append(net(x[:, :, :, i:i + tile, j:j + tile]))
-                if j + tile >= x.shape[4]:
+            for j in range(0, W, stride):
+                cols.append(net(x.narrow(hdim, i, min(tile, H - i)).narrow(wdim, j, min(tile, W - j))))
+                if j + tile >= W:
                     break
             rows.append(cols)
-            if i + tile >= x.shape[3]:
+            if i + tile >= H:
                 break
         res = []
         for i, cols in enumerate(rows):
@@ -506,13 +564,15 @@ class _CVVAEBase(nn.Module):
             out_rows.append(torch.cat(cols, dim=4))
         return torch.cat(out_rows, dim=3)
 
-    def spatial_tiled_encode(self, x):
+    def spatial_tiled_encode(self, x, _ndhwc=False):
+        # _ndhwc (private): x is a channel-padded NDHWC clip [B,T,H,W,Cpad] straight from the device-side pre-processing
+        net = (lambda t: self.encoder(t.contiguous(), ndhwc_in=True)) if _ndhwc else self.encoder
         if self.pixel_tile_size is None:
-            return self.encoder(x)
+            return net(x)
         pixel_stride = round(self.pixel_tile_size * (1 - self.tile_overlap_ratio))
         latent_overlap = round(self.latent_tile_size * self.tile_overlap_ratio)
-        return self._spatial_tiled(x, self.encoder, self.pixel_tile_size, pixel_stride, latent_overlap,
-                                   self.latent_tile_size - latent_overlap)
+        return self._spatial_tiled(x, net, self.pixel_tile_size, pixel_stride, latent_overlap,
+                                   self.latent_tile_size - latent_overlap, *((2, 3) if _ndhwc else (3, 4)))
 
     def spatial_tiled_decode(self, z, **kwargs):
         if self.latent_tile_size is None:
@@ -529,13 +589,14 @@ class _CVVAEBase(nn.Module):
         n_rounds = 1 if n_rounds == 0 else n_rounds
         return [(n * stride, (n + 1) * stride + 1) for n in range(n_rounds)]
 
-    def tiled_encode(self, x):
+    def tiled_encode(self, x, _ndhwc=False):
         if self.encode_n_frames_a_time is None:
-            return self.spatial_tiled_encode(x)
+            return self.spatial_tiled_encode(x, _ndhwc)
         assert x.dim() == 5
         outs = []
-        for n, (a, b) in enumerate(self._windows(x.shape[2], self.encode_n_frames_a_time)):
-            z_i = self.spatial_tiled_encode(x[:, :, a:b])
+        tdim = 1 if _ndhwc else 2
+        for n, (a, b) in enumerate(self._windows(x.shape[tdim], self.encode_n_frames_a_time)):
+            z_i = self.spatial_tiled_encode(x.narrow(tdim, a, min(b, x.shape[tdim]) - a), _ndhwc)
             outs.append(z_i if n == 0 else z_i[:, :, 1:])
         return torch.cat(outs, dim=2)
 
@@ -589,8 +650,39 @@ class _CVVAEBase(nn.Module):
             raise ValueError(f"expected uint8 frames [T,H,W,3], got {frames.dtype} {tuple(frames.shape)}")
         T = frames.shape[0]
         frame_end = 1 + (T - 1) // 4 * 4
-        x = ops.frames_u8_to_ndhwc(frames[:frame_end].contiguous(), 8, self.dtype)
-        return self.encode(x[..., :3].permute(0, 4, 1, 2, 3), return_dict=return_dict)
+        # the NDHWC clip, channel-padded for conv_in's K chunk (32 on the single-frame fold path), goes to the encoder as it is:
+        # the reference's NCDHW clip is never built (windows / tiles are cut as views of it)
+        with torch.cuda.device(frames.device):
+            x = ops.frames_u8_to_ndhwc(frames[:frame_end].contiguous(), 32 if frame_end == 1 else 16, self.dtype)
+            posterior = DiagonalGaussianDistribution(self.tiled_encode(x, _ndhwc=True))
+        if not return_dict:
+            return (posterior,)
+        return AutoencoderKLOutput(latent_dist=posterior)
+
+    @torch.no_grad()
+    def encode_latents(self, x: torch.Tensor, sample: bool = True, generator: Optional[torch.Generator] = None,
+                       scale_factor: Optional[float] = None, n_samples_a_time: Optional[int] = None) -> torch.Tensor:
+        """Frozen-encoder latent pre-compute for the diffusion training engines: the arithmetic of
+        `DiffusionEngine.encode_first_stage` (/root/reference/lvdm/models/diffusion.py:159-171: rounds of
+        `en_and_decode_n_samples_a_time` samples, `first_stage_model.encode`, cat, `scale_factor * z`) with the 4-D <-> 5-D
+        adapters of `DiffusionEngineFor3DVAE.encode_first_stage` (:380-385: images [B,C,H,W] run as one-frame clips and the
+        latents come back as [(B T),C,h,w]).  `sample=False` takes the posterior mode (deterministic latents for a cache).
+        x: [B,3,T,H,W] clips or [B,3,H,W] images -> latents [B,z,T',h,w] (clips) / [(B T'),z,h,w] (images)."""
+        images = x.dim() == 4
+        if images:
+            x = x.unsqueeze(2)
+        n = x.shape[0] if n_samples_a_time is None else int(n_samples_a_time)
+        outs = []
+        for a in range(0, x.shape[0], n):
+            post = DiagonalGaussianDistribution(self.tiled_encode(x[a:a + n]))
+            outs.append(post.sample(generator=generator) if sample else post.mode())
+        z = torch.cat(outs, dim=0)
+        sf = scale_factor if scale_factor is not None else getattr(self.config, "scaling_factor", None)
+        if sf is not None and sf != 1.0:
+            z = sf * z
+        if images:
+            z = z.permute(0, 2, 1, 3, 4).reshape(-1, z.shape[1], *z.shape[3:])
+        return z
 
     @torch.no_grad()
     def decode_to_frames_u8(self, z: torch.Tensor, num_frames: Optional[int] = None) -> torch.Tensor:
@@ -642,6 +734,7 @@ class CVVAEModel(_CVVAEBase):
                                z_channels=c.z_channels, double_z=c.double_z, causal=c.causal_encoder)
         self.decoder = Decoder(ch=c.ch, out_ch=c.out_ch, ch_mult=c.ch_mult, num_res_blocks=c.num_res_blocks,
                                z_channels=c.z_channels, causal=c.causal_decoder)
+        self._flag_widths([c.ch * m for m in c.ch_mult])
 
 
 class CVVAESD3Model(_CVVAEBase):
@@ -672,6 +765,7 @@ class CVVAESD3Model(_CVVAEBase):
         self.decoder = Decoder3D(in_channels=c.out_channels, out_channels=c.in_channels, block_out_channels=c.block_out_channels,
                                  layers_per_block=c.layers_per_block, mid_block_add_attention=c.mid_block_add_attention,
                                  causal=c.causal_decoder)
+        self._flag_widths(c.block_out_channels)
 
 
 # `north_star` calls the class AutoencoderKLCVVAE; the reference has no such name -- provide the alias.

@@ -19,13 +19,20 @@ def _dt(t: torch.dtype) -> int:
     return _DT[t]
 
 
-def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def _stream(t: torch.Tensor) -> int:
+    """the HIP stream the launch goes to: the current stream of the TENSOR's device.  A kernel can only be queued on a stream of
+    the runtime's current device, so a tensor on another device is refused here (the model-level entry points -- _Net.forward,
+    blend_h / blend_v -- switch to the input's device themselves; direct callers wrap the call in torch.cuda.device(t.device))."""
+    dev = t.device
+    if dev.index is not None and dev.index != torch.cuda.current_device():
+        raise RuntimeError(f"cvvae_amd.ops: tensor on {dev} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "wrap the call in `with torch.cuda.device(t.device):`")
+    return torch.cuda.current_stream(dev).cuda_stream
 
 
 def _need_gpu(t: torch.Tensor):
     if not t.is_cuda:
-        raise RuntimeError("cv-vae_amd ops run on an MI355X (ROCm) device only; there is no CPU path. "
+        raise RuntimeError("cvvae_amd ops run on an MI355X (ROCm) device only; there is no CPU path. "
                            f"Got a tensor on {t.device}.")
 
 
@@ -75,7 +82,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     # fold = (n, stride): every packed element is the sum of n source elements `stride` apart (coinciding taps);
     # offset: element offset of the first source element (e.g. the centre time tap)
     L.check(lib.cvvae_pack_weights_fold(dt, w.data_ptr() + offset * w.element_size(), cout_, cin_, taps, strides[0],
-                                        strides[1], strides[2], fold[0], fold[1], cin_pad, ck, out.data_ptr(), _stream()),
+                                        strides[1], strides[2], fold[0], fold[1], cin_pad, ck, out.data_ptr(), _stream(w)),
             "cvvae_pack_weights_fold")
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
@@ -106,7 +113,7 @@ def pack_weight_batched(w: torch.Tensor, k: Tuple[int, int, int], cin_pad: int, 
     per = round_up(lib.cvvae_packed_weight_bytes(cout, cin_pad, taps), 16)
     out = torch.zeros((batch, per), dtype=torch.uint8, device=w.device)
     L.check(lib.cvvae_pack_weights_batched(dt, w.data_ptr(), batch, w[0].numel(), cout, cin, taps, strides[0], strides[1],
-                                           strides[2], cin_pad, kchunk(k), out.data_ptr(), per, _stream()),
+                                           strides[2], cin_pad, kchunk(k), out.data_ptr(), per, _stream(w)),
             "cvvae_pack_weights_batched")
     b = torch.zeros(round_up(cout, 32), dtype=torch.float32, device=w.device)
     return PackedConv(out, b, cout, cin_pad, tuple(k), cin, batch_stride=per)
@@ -127,7 +134,7 @@ def pack_weight_tfolds(w: torch.Tensor, bias: Optional[torch.Tensor], cin_pad: O
     cin_pad = round_up(ci, ck) if cin_pad is None else cin_pad
     out = torch.zeros(lib.cvvae_packed_weight_bytes(co, cin_pad, 6 * nsp), dtype=torch.uint8, device=w.device)
     L.check(lib.cvvae_pack_weights_tfolds(dt, w.data_ptr(), co, ci, nsp, ci * 3 * nsp, 3 * nsp, 1, cin_pad, ck, out.data_ptr(),
-                                          _stream()), "cvvae_pack_weights_tfolds")
+                                          _stream(w)), "cvvae_pack_weights_tfolds")
     b = torch.zeros(round_up(co, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:co] = bias.detach().to(torch.float32)
@@ -161,10 +168,10 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int
     per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 24 if time_folds else (4 if tfold else 12))
     out = torch.zeros(4 * per, dtype=torch.uint8, device=w.device)
     if time_folds:  # 12 taps per phase + the time-fold slots (replicate time padding)
-        L.check(lib.cvvae_pack_weights_upfold_tfolds(dt, w.data_ptr(), cout_, cin_, cin_pad, out.data_ptr(), _stream()),
+        L.check(lib.cvvae_pack_weights_upfold_tfolds(dt, w.data_ptr(), cout_, cin_, cin_pad, out.data_ptr(), _stream(w)),
                 "cvvae_pack_weights_upfold_tfolds")
     else:
-        L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, tfold, out.data_ptr(), _stream()),
+        L.check(lib.cvvae_pack_weights_upfold(dt, w.data_ptr(), cout_, cin_, cin_pad, tfold, out.data_ptr(), _stream(w)),
                 "cvvae_pack_weights_upfold")
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
@@ -260,13 +267,13 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
                                              gsc.data_ptr() if gsc is not None else None,
                                              gsh.data_ptr() if gsh is not None else None, shortcut[0].data_ptr(),
                                              shortcut[1].w.data_ptr(), out.data_ptr(), gn_out,
-                                             part.buf.data_ptr() if part is not None else None, _stream()),
+                                             part.buf.data_ptr() if part is not None else None, _stream(x)),
                     "cvvae_conv_fwd_gn_sc")
             return
         L.check(lib.cvvae_conv_fwd_gn(d, x.data_ptr(), pw.w.data_ptr(), bias_t.data_ptr(),
                                       residual.data_ptr() if residual is not None else None,
                                       gsc.data_ptr() if gsc is not None else None, gsh.data_ptr() if gsh is not None else None,
-                                      out.data_ptr(), gn_out, part.buf.data_ptr() if part is not None else None, _stream()),
+                                      out.data_ptr(), gn_out, part.buf.data_ptr() if part is not None else None, _stream(x)),
                 "cvvae_conv_fwd_gn")
 
     if PROFILE is None:
@@ -283,7 +290,7 @@ def gn_finalize(part: GNPartials, gamma: torch.Tensor, beta: torch.Tensor, eps: 
     scale = torch.empty((part.rows, part.C), dtype=torch.float32, device=part.buf.device)
     shift = torch.empty((part.rows, part.C), dtype=torch.float32, device=part.buf.device)
     L.check(lib.cvvae_gn_finalize(part.buf.data_ptr(), part.rows, part.slabs, part.C, part.groups, eps, gamma.data_ptr(),
-                                  beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream()), "cvvae_gn_finalize")
+                                  beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream(part.buf)), "cvvae_gn_finalize")
     return scale, shift
 
 
@@ -311,7 +318,7 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: floa
     shift = torch.empty((rows, C), dtype=torch.float32, device=x.device)
     ws = torch.empty(lib.cvvae_gn_workspace_bytes(rows, groups, S), dtype=torch.uint8, device=x.device)
     L.check(lib.cvvae_gn_stats(_dt(x.dtype), x.data_ptr(), rows, S, C, C, groups, eps, gamma.data_ptr(), beta.data_ptr(),
-                               scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream()), "cvvae_gn_stats")
+                               scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream(x)), "cvvae_gn_stats")
     return scale, shift
 
 
@@ -322,7 +329,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: flo
     C = x.shape[-1]
     out = torch.empty_like(x)
     L.check(lib.cvvae_layernorm(_dt(x.dtype), x.data_ptr(), x.numel() // C, C, eps, gamma.data_ptr(), beta.data_ptr(),
-                                out.data_ptr(), _stream()), "cvvae_layernorm")
+                                out.data_ptr(), _stream(x)), "cvvae_layernorm")
     return out
 
 
@@ -334,7 +341,7 @@ def softmax_rows(s: torch.Tensor, n_valid: int, dtype: torch.dtype, ld_p: Option
     rows, ld_s = s.shape
     ld_p = ld_s if ld_p is None else ld_p
     p = torch.empty((rows, ld_p), dtype=dtype, device=s.device)
-    L.check(lib.cvvae_softmax_rows(_dt(dtype), s.data_ptr(), rows, n_valid, ld_s, p.data_ptr(), ld_p, _stream()),
+    L.check(lib.cvvae_softmax_rows(_dt(dtype), s.data_ptr(), rows, n_valid, ld_s, p.data_ptr(), ld_p, _stream(s)),
             "cvvae_softmax_rows")
     return p
 
@@ -346,7 +353,7 @@ def transpose(x: torch.Tensor) -> torch.Tensor:
     assert x.dim() == 3 and x.is_contiguous()
     b, R, C = x.shape
     out = torch.empty((b, C, R), dtype=x.dtype, device=x.device)
-    L.check(lib.cvvae_transpose(_dt(x.dtype), x.data_ptr(), b, R, C, C, R * C, out.data_ptr(), R, R * C, _stream()),
+    L.check(lib.cvvae_transpose(_dt(x.dtype), x.data_ptr(), b, R, C, C, R * C, out.data_ptr(), R, R * C, _stream(x)),
             "cvvae_transpose")
     return out
 
@@ -359,7 +366,7 @@ def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> tor
     B, T, H, W, C = q.shape
     out = torch.empty_like(q)
     L.check(lib.cvvae_temporal_attention(_dt(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), B, T, H * W, C,
-                                         out.data_ptr(), _stream()), "cvvae_temporal_attention")
+                                         out.data_ptr(), _stream(q)), "cvvae_temporal_attention")
     return out
 
 
@@ -372,7 +379,7 @@ def ncdhw_to_ndhwc(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tens
     if x.dtype not in _DT:
         raise TypeError(f"unsupported input dtype {x.dtype}")
     out = torch.empty((B, T, H, W, cpad), dtype=dtype, device=x.device)
-    L.check(lib.cvvae_ncdhw_to_ndhwc(_DT[x.dtype], _dt(dtype), x.data_ptr(), B, C, T, H, W, cpad, out.data_ptr(), _stream()),
+    L.check(lib.cvvae_ncdhw_to_ndhwc(_DT[x.dtype], _dt(dtype), x.data_ptr(), B, C, T, H, W, cpad, out.data_ptr(), _stream(x)),
             "cvvae_ncdhw_to_ndhwc")
     return out
 
@@ -383,7 +390,7 @@ def ndhwc_to_ncdhw(x: torch.Tensor, c: int) -> torch.Tensor:
     assert x.dim() == 5 and x.is_contiguous()
     B, T, H, W, Cs = x.shape
     out = torch.empty((B, c, T, H, W), dtype=x.dtype, device=x.device)
-    L.check(lib.cvvae_ndhwc_to_ncdhw(_dt(x.dtype), x.data_ptr(), B, c, T, H, W, Cs, out.data_ptr(), _stream()),
+    L.check(lib.cvvae_ndhwc_to_ncdhw(_dt(x.dtype), x.data_ptr(), B, c, T, H, W, Cs, out.data_ptr(), _stream(x)),
             "cvvae_ndhwc_to_ncdhw")
     return out
 
@@ -396,7 +403,7 @@ def blend_(a: torch.Tensor, b: torch.Tensor, overlap: int, axis: int) -> torch.T
     rows = b.shape[0] * b.shape[1] * b.shape[2]
     assert a.shape[:3] == b.shape[:3]
     L.check(lib.cvvae_blend(_dt(b.dtype), a.data_ptr(), a.shape[3], a.shape[4], b.data_ptr(), b.shape[3], b.shape[4], rows,
-                            overlap, axis, _stream()), "cvvae_blend")
+                            overlap, axis, _stream(b)), "cvvae_blend")
     return b
 
 
@@ -407,7 +414,7 @@ def frames_u8_to_ndhwc(frames: torch.Tensor, cpad: int, dtype: torch.dtype) -> t
     assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[-1] == 3 and frames.is_contiguous()
     T, H, W, _ = frames.shape
     out = torch.empty((1, T, H, W, cpad), dtype=dtype, device=frames.device)
-    L.check(lib.cvvae_frames_u8_to_ndhwc(_dt(dtype), frames.data_ptr(), T * H * W, cpad, out.data_ptr(), _stream()),
+    L.check(lib.cvvae_frames_u8_to_ndhwc(_dt(dtype), frames.data_ptr(), T * H * W, cpad, out.data_ptr(), _stream(frames)),
             "cvvae_frames_u8_to_ndhwc")
     return out
 
@@ -419,6 +426,6 @@ def ncdhw_to_frames_u8(x: torch.Tensor) -> torch.Tensor:
     assert x.dim() == 5 and x.shape[0] == 1 and x.shape[1] == 3 and x.is_contiguous()
     _, _, T, H, W = x.shape
     out = torch.empty((T, H, W, 3), dtype=torch.uint8, device=x.device)
-    L.check(lib.cvvae_ncdhw_to_frames_u8(_dt(x.dtype), x.data_ptr(), T * H * W, out.data_ptr(), _stream()),
+    L.check(lib.cvvae_ncdhw_to_frames_u8(_dt(x.dtype), x.data_ptr(), T * H * W, out.data_ptr(), _stream(x)),
             "cvvae_ncdhw_to_frames_u8")
     return out

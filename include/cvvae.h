@@ -3,7 +3,7 @@
  *
  * The reference (AILab-CVC/CV-VAE) is pure PyTorch: it has no FFI / operator registry.  Its hot path
  * dispatches to ATen ops from Python.  Each entry point below replaces one ATen op family
- * at the call sites cited next to it; the Python host (cv-vae_amd/) binds them with ctypes and mirrors the
+ * at the call sites cited next to it; the Python host (cvvae_amd/) binds them with ctypes and mirrors the
  * reference's module API (models/modeling_vae.py) above them.  INTEGRATION.md shows the binding.
  *
  * Conventions

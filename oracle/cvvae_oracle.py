@@ -1,7 +1,7 @@
 """CPU oracle for the CV-VAE encode/decode path.  TEST INFRASTRUCTURE -- NOT PRODUCT CODE.
 
 Only `tests/`, `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may import this
-file, and there only as the checker.  The product (`cv-vae_amd/`) never imports it and fails
+file, and there only as the checker.  The product (`cvvae_amd/`) never imports it and fails
 loudly when the HIP extension is missing.
 
 What it is: a plain fp32 (optionally fp64) functional restatement, on PyTorch-CPU tensor ops, of the

@@ -21,3 +21,25 @@ CONSTRAINT_CASES = {
     "constraint2d_4d_12x8": (CONSTRAINT_CFG, (2, 16, 12, 8), 0, 11),    # 4-D latents, two images, non-square
 }
 
+
+# BASELINE.json configs at FULL size (SURVEY 8c "and on GPU the BASELINE shapes"): fixtures hold the full `moments` and a
+# bounded part of `recon` -- recon_sub[t] = recon[:, :, t, (t % s)::s, (3t % s)::s] (stride s over H and W with a per-frame phase,
+# so every kernel tile and every pixel phase of the frame is sampled) -- plus fp64 global moments of the whole recon.
+# name -> (family, config overrides, input shape, weight seed, input seed, recon stride s)
+BIG_CASES = {
+    "cfg1_vae3d_t1_256": ("vae3d", {}, (1, 3, 1, 256, 256), 0, 21, 1),      # BASELINE cfg 1: one 256x256 image
+    "cfg2_vae3d_t17_256": ("vae3d", {}, (1, 3, 17, 256, 256), 0, 22, 4),    # BASELINE cfg 2
+    "cfg3_sd3_t17_512": ("sd3", {}, (1, 3, 17, 512, 512), 0, 23, 4),        # BASELINE cfg 3: the configuration the metric is quoted on
+    # one 17-frame window of BASELINE cfg 4 (720x1280: 2x3 spatial tiles of 576/272 x 576/576/384 pixels, blended)
+    "cfg4win_sd3_t17_720x1280": ("sd3", {}, (1, 3, 17, 720, 1280), 0, 24, 8),
+}
+
+
+def recon_subsample(recon, s: int):
+    """recon [B,C,T,H,W] (numpy or torch) -> [B,C,T,H/s,W/s]: frame t sampled at rows (t % s)::s, columns (3t % s)::s"""
+    import numpy as np
+    frames = [recon[:, :, t, (t % s)::s, ((3 * t) % s)::s] for t in range(recon.shape[2])]
+    if hasattr(recon, "numpy"):
+        import torch
+        return torch.stack(frames, dim=2)
+    return np.stack(frames, axis=2)

@@ -65,9 +65,54 @@ def main_constraint():
         print(f"{name}: latents {tuple(zshape)} recon {tuple(recon.shape)} wsum {wsum:.6f}")
 
 
+def main_big(only=None):
+    """BASELINE-size fixtures (cfg 1 / 2 / 3 and one window of cfg 4) from the reference's own modules; minutes of CPU each.
+    The reference's fp16 / bf16 CPU runs of the same case are recorded too (its own low-precision noise at THIS shape: the
+    yardstick the GPU tolerances are read against)."""
+    import time
+
+    from oracle.golden_cases import BIG_CASES, recon_subsample
+
+    ref = load_reference()
+    torch.set_grad_enabled(False)
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, (family, over, shape, wseed, xseed, s) in BIG_CASES.items():
+        if only and name not in only:
+            continue
+        cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
+        model = cls(**over).eval()
+        sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+        model.load_state_dict(sd, strict=True)
+        x = seeded_input(shape, xseed)
+        t0 = time.time()
+        post = model.encode(x).latent_dist
+        t1 = time.time()
+        moments = post.parameters
+        recon = model.decode(post.mode()).sample
+        t2 = time.time()
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        r64 = recon.double()
+        np.savez_compressed(
+            os.path.join(out_dir, name + ".npz"),
+            moments=moments.numpy().astype(np.float32),
+            recon_sub=recon_subsample(recon, s).numpy().astype(np.float32),
+            recon_shape=np.asarray(recon.shape, dtype=np.int64),
+            recon_stride=np.int64(s),
+            recon_mean=np.float64(r64.mean()), recon_sqmean=np.float64((r64 * r64).mean()),
+            recon_frame_mean=r64.mean(dim=(0, 1, 3, 4)).numpy(),
+            weight_abs_sum=np.float64(wsum),
+            n_tensors=np.int64(len(sd)),
+            ref_cpu_seconds=np.asarray([t1 - t0, t2 - t1]), ref_cpu_threads=np.int64(torch.get_num_threads()),
+        )
+        print(f"{name}: moments {tuple(moments.shape)} recon {tuple(recon.shape)} wsum {wsum:.6f} "
+              f"reference CPU fp32 encode {t1 - t0:.1f}s decode {t2 - t1:.1f}s ({torch.get_num_threads()} threads)", flush=True)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "constraint":
         main_constraint()
+    elif len(sys.argv) > 1 and sys.argv[1] == "big":
+        main_big(sys.argv[2:])
     else:
         main()
         main_constraint()

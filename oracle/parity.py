@@ -1,0 +1,75 @@
+"""Parity measurement of a device model against the reference-generated fixtures (tests/golden).  TEST INFRASTRUCTURE:
+imported by tests/, __graft_entry__.smoke() and bench.py's parity leg only -- as the checker, never on the product path.
+
+Metrics follow SURVEY 8(d): latent max / mean |delta| on `moments`, recon PSNR = 10 log10(4 / MSE) on [-1, 1] data.
+"""
+import os
+
+import numpy as np
+import torch
+
+from .golden_cases import BIG_CASES, CASES, recon_subsample
+from .seeded import seeded_input, seeded_state_dict
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+# the reference's OWN low-precision noise (its fp16 / bf16 CPU run vs its fp32 run; T=9, 96x96)
+REFERENCE_SELF_NOISE = {
+    "f16": {"latent_max": 3.2e-3, "latent_mean": 6.5e-4, "recon_psnr_db": 65.8},
+    "bf16": {"latent_max": 2.8e-2, "latent_mean": 5.3e-3, "recon_psnr_db": 47.5},
+}
+
+
+def load_seeded(model, wseed: int):
+    sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+    model.load_state_dict(sd, strict=True)
+    return sd
+
+
+def case_of(name: str):
+    """-> (family, overrides, shape, wseed, xseed, recon stride or 0 for a fully stored recon)"""
+    if name in BIG_CASES:
+        return BIG_CASES[name]
+    return CASES[name] + (0,)
+
+
+@torch.no_grad()
+def measure(model, name: str, golden_dir: str = GOLDEN_DIR) -> dict:
+    """`model`: a device model that already carries seeded_state_dict(shapes, wseed of the case), in its run dtype.
+    encode(x) is compared on `moments`; decode() is run on the REFERENCE's latent so the decoder is judged on identical
+    input.  Returns plain floats."""
+    family, over, shape, wseed, xseed, s = case_of(name)
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    dtype, dev = model.dtype, model.device
+    x = seeded_input(shape, xseed).to(dtype).to(dev)
+    mom = model.encode(x).latent_dist.parameters.float().cpu().numpy()
+    gm = gold["moments"]
+    assert mom.shape == gm.shape, (mom.shape, gm.shape)
+    zc = gm.shape[1] // 2
+    z = torch.from_numpy(gm[:, :zc]).to(dtype).to(dev)
+    rec = model.decode(z).sample.float().cpu()
+    if s:
+        assert tuple(rec.shape) == tuple(int(v) for v in gold["recon_shape"])
+        r, g = recon_subsample(rec, s).numpy(), gold["recon_sub"]
+        extra = {"recon_mean_delta": float(abs(rec.double().mean().item() - float(gold["recon_mean"]))),
+                 "recon_sampled_fraction": round(1.0 / (s * s), 4)}
+    else:
+        r, g = rec.numpy(), gold["recon"]
+        extra = {}
+    assert r.shape == g.shape, (r.shape, g.shape)
+    d = np.abs(mom - gm)
+    dm = np.abs(mom[:, :zc] - gm[:, :zc])  # the latent proper (posterior mean); `moments` also holds logvar
+    mse = float(((r - g).astype(np.float64) ** 2).mean())
+    out = {
+        "case": name, "shape": list(shape),
+        "latent_max_abs": float(dm.max()), "latent_mean_abs": float(dm.mean()),
+        "moments_max_abs": float(d.max()), "moments_mean_abs": float(d.mean()),
+        "recon_max_abs": float(np.abs(r - g).max()), "recon_psnr_db": float(10 * np.log10(4.0 / max(mse, 1e-30))),
+    }
+    out.update(extra)
+    return out
+
+
+def fmt(tag: str, m: dict) -> str:
+    return (f"{m['case']:28s} {tag:5s} latent max|d| {m['latent_max_abs']:.3e} mean|d| {m['latent_mean_abs']:.3e}  "
+            f"moments max|d| {m['moments_max_abs']:.3e}  recon max|d| {m['recon_max_abs']:.3e} PSNR {m['recon_psnr_db']:.2f} dB")

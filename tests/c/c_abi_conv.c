@@ -1,6 +1,6 @@
 /* c_abi_conv.c -- the C ABI of libcvvae_hip.so used from plain C (no Python, no torch): pack a 1x1x1 weight, run
  * cvvae_conv_fwd on device buffers, check against a host-side dot product.  Built and run by tests/test_gpu_c_abi.py:
- *   gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c/c_abi_conv.c -Lcv-vae_amd -lcvvae_hip
+ *   gcc -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude tests/c/c_abi_conv.c -Lcvvae_amd -lcvvae_hip
  *       -L/opt/rocm/lib -lamdhip64 -lm -o /tmp/c_abi_conv
  * (the HIP runtime is only here for hipMalloc / hipMemcpy; every library entry point is plain C.) */
 #include <hip/hip_runtime_api.h>

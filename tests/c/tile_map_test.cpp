@@ -1,4 +1,4 @@
-// Host-side checks of cv-vae_amd/csrc/tile_map.h: (1) conv_fwd_kernel's blockIdx -> logical tile map must be a bijection of
+// Host-side checks of cvvae_amd/csrc/tile_map.h: (1) conv_fwd_kernel's blockIdx -> logical tile map must be a bijection of
 // [0, nwg) for every grid shape the host can launch, and with short tiles every XCD must run all its long tiles before its
 // short ones; (2) the per-frame time-fold plan must reproduce the 3-tap sum under both padding modes.  Built with g++ by
 // tests/test_tile_map.py (no GPU, no HIP).

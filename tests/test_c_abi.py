@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 14
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/cvvae.h but not exported"
-        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in cv-vae_amd/_lib.py"
+        assert n in _lib.PROTOTYPES, f"{n} has no ctypes prototype in cvvae_amd/_lib.py"
     assert lib.cvvae_abi_version() == _lib.ABI_VERSION
 
 

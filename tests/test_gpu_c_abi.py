@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def test_library_from_plain_c(tmp_path):
     gcc = shutil.which("gcc") or "gcc"
     exe = os.path.join(tmp_path, "c_abi_conv")
-    lib_dir = os.path.join(ROOT, "cv-vae_amd")
+    lib_dir = os.path.join(ROOT, "cvvae_amd")
     rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
     # plain gcc: the HIP runtime is only used for hipMalloc / hipMemcpy (its C header wants the platform macro)
     subprocess.run([gcc, "-D__HIP_PLATFORM_AMD__", "-I" + os.path.join(rocm, "include"), "-I" + os.path.join(ROOT, "include"),

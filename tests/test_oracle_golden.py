@@ -52,3 +52,36 @@ def test_oracle_constraint_decoder_matches_reference_golden(name, golden_dir):
         rec = O.constraint_decoder(seeded_input(zshape, zseed), sd, cfg)
     assert tuple(rec.shape) == gold["recon"].shape
     assert np.abs(rec.numpy() - gold["recon"]).max() <= TOL_RECON
+
+
+from oracle.golden_cases import BIG_CASES, recon_subsample  # noqa: E402
+
+
+@pytest.mark.parametrize("name", sorted(BIG_CASES))
+def test_baseline_size_fixtures(name, golden_dir):
+    """BASELINE-size fixtures (oracle/make_golden.py big): integrity of every fixture against oracle/seeded.py and the shape
+    laws; the oracle restatement itself is re-run against the cfg 1 fixture (seconds of CPU; the larger ones cost minutes and
+    are the GPU tests' yardstick)."""
+    path = os.path.join(golden_dir, name + ".npz")
+    if not os.path.isfile(path):
+        pytest.skip(f"{name}.npz not generated")
+    family, over, shape, wseed, xseed, s = BIG_CASES[name]
+    gold = np.load(path)
+    sd = seeded_state_dict(state_dict_shapes(family, dict(over)), wseed)
+    assert len(sd) == int(gold["n_tensors"])
+    wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+    assert abs(wsum - float(gold["weight_abs_sum"])) < 1e-6 * wsum
+    B, _, T, H, W = shape
+    zc = 32 if family == "sd3" else 8
+    assert gold["moments"].shape == (B, zc, 1 + (T - 1) // 4, H // 8, W // 8)
+    assert tuple(gold["recon_shape"]) == shape and int(gold["recon_stride"]) == s
+    assert gold["recon_sub"].shape == (B, 3, T, H // s, W // s)
+    assert np.isfinite(gold["moments"]).all() and np.isfinite(gold["recon_sub"]).all()
+    if name.startswith("cfg1"):
+        x = seeded_input(shape, xseed)
+        with torch.no_grad():
+            mom = O.encode_moments(x, sd, dict(over), family)
+            rec = O.decode_sample(O.posterior_mode(mom), sd, dict(over), family)
+        assert np.abs(mom.numpy() - gold["moments"]).max() <= TOL_MOMENTS
+        assert np.abs(recon_subsample(rec, s).numpy() - gold["recon_sub"]).max() <= TOL_RECON
+        assert abs(float(rec.double().mean()) - float(gold["recon_mean"])) <= 1e-5

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Timing of the frozen 2-D constraint decoder (cv-vae_amd/constraint.py) at the training config's shapes
+"""Timing of the frozen 2-D constraint decoder (cvvae_amd/constraint.py) at the training config's shapes
 (configs/cvvae_sd3_constraint_training.yaml: 17-frame 256x256 clips -> latents [1,16,5,32,32]; 320x320 images, batch 8 ->
 [8,16,40,40]) and at a 512x512 clip's latents.  usage: python tools/constraint_bench.py [--iters N] [--hip-graphs]"""
 import argparse

@@ -2,7 +2,7 @@
 """Registers / scratch / LDS / occupancy of every kernel in the given .hip files (default: all conv instances), from
 hipcc's -Rpass-analysis=kernel-resource-usage remarks.  usage: python tools/kernel_resources.py [file.hip ...]"""
 import glob, os, re, subprocess, sys
-csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cv-vae_amd", "csrc")
+csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "cvvae_amd", "csrc")
 files = sys.argv[1:] or sorted(glob.glob(os.path.join(csrc, "conv_inst_*.hip")))
 for f in files:
     out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-c", f,

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Print registers / scratch / LDS / occupancy of every kernel in the given .hip files (default: all conv instances),
 # from hipcc's -Rpass-analysis=kernel-resource-usage remarks.
-cd "$(dirname "$0")/../cv-vae_amd/csrc" || exit 1
+cd "$(dirname "$0")/../cvvae_amd/csrc" || exit 1
 files=${@:-conv_inst_*.hip}
 for f in $files; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 --cuda-device-only -c $f -o /dev/null \

@@ -21,7 +21,7 @@ vae = (cvvae_amd.CVVAESD3Model if a.family == "sd3" else cvvae_amd.CVVAEModel)()
 x = (torch.rand(tuple(int(v) for v in a.shape.split(","))) * 2 - 1).to(dtype).cuda()
 
 # every X(...) row of the instance table -> a force string
-rows = re.findall(r"X\(([^)]*)\)", open(os.path.join(ROOT, "cv-vae_amd", "csrc", "conv_table.h")).read())
+rows = re.findall(r"X\(([^)]*)\)", open(os.path.join(ROOT, "cvvae_amd", "csrc", "conv_table.h")).read())
 forces = sorted({"%sx%sx%s:%sx%sx%s:%s" % tuple(r.replace(" ", "").split(",")[i] for i in (6, 7, 8, 9, 10, 11, 12)) for r in rows if r[0].isdigit()})
 
 calls = {}
