@@ -142,10 +142,12 @@ struct Geo {
   static constexpr int PIXB = CK * 2 + 16;
   static constexpr int BUFB = NPIX * PIXB;
   static constexpr int LDSB = 2 * BUFB;
+  static constexpr int NWV = WM * WN * KG;  // waves per workgroup: 8 (one workgroup per CU) or 4 (TWO workgroups per CU)
   static constexpr int IPP = 2 * KSUB;   // 16-byte items per pixel
   static constexpr int PPP = 256 / IPP;  // pixels per staging pass of one 256-thread group
-  static constexpr int NPH = ((NPIX + 1) / 2 + PPP - 1) / PPP * PPP;  // pixels staged by group X
-  static constexpr int NPASS = (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
+  // pixels staged by group X (NWV == 8: the two wave groups split the halo; NWV == 4: the single group stages all of it)
+  static constexpr int NPH = NWV == 4 ? (NPIX + PPP - 1) / PPP * PPP : ((NPIX + 1) / 2 + PPP - 1) / PPP * PPP;
+  static constexpr int NPASS = NWV == 4 ? NPH / PPP : (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
   static constexpr int SBATCH = NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4);
   static constexpr int STEPS = NTAPS * KSUB;   // k16 steps per chunk, ordered ks-major: st = ks * NTAPS + tap
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
@@ -154,13 +156,14 @@ struct Geo {
   // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
   static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
   static constexpr int SMEMB = cmax(LDSB, REDB);
-  static_assert(WM * WN * KG == 8, "8 waves per workgroup");
+  static_assert(NWV == 8 || (NWV == 4 && KG == 1), "8 waves per workgroup, or 4 (two workgroups per CU; no K-group split)");
+  static_assert(NWV == 8 || LDSB <= 80 * 1024, "two resident workgroups share the CU's 160 KiB of LDS");
   static_assert(KG == 1 || (KG == 2 && KSUB % 2 == 0 && MREP % 2 == 0 && WM * WN == 4), "K-group split");
   static_assert(BM % (32 * WM) == 0, "tile rows must split into 32-row MFMA fragments per wave");
   static_assert(STEPS_W % PF == 0, "weight prefetch ring must divide the steps of a chunk");
   static_assert(SMEMB <= 160 * 1024, "LDS budget");
   static_assert(PF * 1024 <= WEIGHT_TAIL_BYTES, "weight prefetch ring reads past the packed buffer's tail");
-  static_assert(NPH <= NPIX || NPIX <= PPP, "split");
+  static_assert(NWV == 4 || NPH <= NPIX || NPIX <= PPP, "split");
 };
 
 template <typename T>
@@ -191,8 +194,12 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
 
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
           int PRO, int UPS>
-__global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
+__global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) void conv_fwd_kernel(const ConvArgs p) {
   using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB>;
+  // NWV == 4 (WM x WN = 4 waves, 256 threads, <= 256 VGPRs, <= 80 KiB of LDS): TWO workgroups are resident per CU, one wave of
+  // each per SIMD.  Nothing couples them, so one workgroup's serial parts (first halo chunk, store tail, barrier waits, the
+  // GroupNorm + SiLU VALU work of the staging, which runs ~4x slower beside a saturated MFMA stream) run under the other's MFMAs.
+  constexpr int NWV = G::NWV;
   using v8 = typename Tr<T>::v8;
   constexpr int MREP = G::MREP, PIXB = G::PIXB, NPASS = G::NPASS, STEPS = G::STEPS, STEPS_W = G::STEPS_W, PF = G::PF,
                 CK = G::CK, NTAPS = G::NTAPS;
@@ -202,7 +209,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int grp = wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
+  const int grp = NWV == 4 ? 0 : wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
   const int wave_n = wave % WN;
   const int wave_m = (wave / WN) % WM;
   const int kgrp = KG == 2 ? grp : 0;  // K-group: which half of the chunk's k16 sub-chunks this wave multiplies
@@ -253,7 +260,9 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   //      either.  cfg 3: 6-20 % fewer MFMAs on the causal encoder convs, 4-13 % on the decoder's.
   constexpr bool TFOLD = (KT == 3 && KG == 1);
   constexpr int NSP = KH * KW, GS = NSP * KSUB;  // steps of one time group
-  static_assert(!TFOLD || (GS % PF == 0 && (TT == 1 || (TH * TW) % (MREP * 32) == 0)), "time-group plan");
+  // a wave's fragments lie in ONE output frame -- or (WM == 1 with a multi-frame tile: the 4-wave instances) span all of the
+  // tile's frames, in which case the tile takes a fold only when every frame has the same plan (else: plain three groups)
+  static_assert(!TFOLD || (GS % PF == 0 && (TT == 1 || WM == 1 || (TH * TW) % (MREP * 32) == 0)), "time-group plan");
   const long long w_ks = (long long)(TFOLD ? p.w_taps : NTAPS) * 512;  // elements between consecutive k16 record groups
   const long long w_cs = w_ks * KSUB;                                   // ... between consecutive K chunks
   int tf_ng = 3;
@@ -283,7 +292,17 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
       }
     };
     int slot0, slot1, dt0, dt1;
-    tf_variant(t0 + (TT > 1 ? (wave_m * MREP * 32) / (TH * TW) : 0), tf_ng, slot0, slot1, dt0, dt1);
+    tf_variant(t0 + (TT > 1 && WM > 1 ? (wave_m * MREP * 32) / (TH * TW) : 0), tf_ng, slot0, slot1, dt0, dt1);
+    bool plain = false;  // WM == 1, TT > 1: the wave covers every frame of the tile -> one plan for all of them, or none
+    if (TT > 1 && WM == 1) {
+#pragma unroll
+      for (int tt = 1; tt < TT; ++tt) {
+        int ng, s0_, s1_, d0_, d1_;
+        tf_variant(t0 + tt, ng, s0_, s1_, d0_, d1_);
+        plain = plain || ng != tf_ng || s0_ != slot0 || s1_ != slot1 || d0_ != dt0 || d1_ != dt1;
+      }
+      if (plain) { tf_ng = 3; slot0 = 0; slot1 = 1; dt0 = 0; dt1 = 1; }
+    }
     tf_w0 = (long long)slot0 * (NSP * 512);
     tf_w1 = (long long)slot1 * (NSP * 512);
     tf_l0 = (unsigned)dt0 * (G::FH * G::FW * PIXB);
@@ -294,6 +313,7 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
     for (int tt = 0; tt < TT; ++tt) {  // union over the output frames of the tile
       int ng, s0_, s1_, d0_, d1_;
       tf_variant(t0 + tt, ng, s0_, s1_, d0_, d1_);
+      if (plain) { ng = 3; d0_ = 0; d1_ = 1; }
       const int lo = tt * ST + d0_, hi = tt * ST + (ng == 3 ? 2 : (ng == 2 ? d1_ : d0_));
       hf_a = lo < hf_a ? lo : hf_a;
       hf_b = hi > hf_b ? hi : hf_b;
@@ -305,7 +325,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
   const int sq = tl % G::IPP;  // my 16-byte slice (8 channels) inside the chunk -- fixed for the whole kernel
   const int spl = tl / G::IPP;
   const int hbase = hf_a * (G::FH * G::FW), hcnt = (hf_b - hf_a + 1) * (G::FH * G::FW);
-  const int nph_x = TFOLD ? (((hcnt + 1) / 2 + G::PPP - 1) / G::PPP * G::PPP) : G::NPH;  // pixels staged by group X
+  const int nph_x = NWV == 4 ? (hcnt + G::PPP - 1) / G::PPP * G::PPP   // the single group stages all of it
+                             : (TFOLD ? (((hcnt + 1) / 2 + G::PPP - 1) / G::PPP * G::PPP) : G::NPH);  // pixels staged by group X
   const int pstart = hbase + (grp ? nph_x : 0);
   const int pend = hbase + (grp ? hcnt : (nph_x < hcnt ? nph_x : hcnt));
   int srcpix[NPASS];
@@ -985,8 +1006,8 @@ __global__ __launch_bounds__(512) void conv_fwd_kernel(const ConvArgs p) {
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
           int PRO, int UPS>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS>), dim3(grid), dim3(512),
-                     0, s, a);
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS>), dim3(grid),
+                     dim3(WM * WN * KG * 64), 0, s, a);
   return (int)hipGetLastError();
 }
 

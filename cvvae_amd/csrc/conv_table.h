@@ -66,6 +66,14 @@
   X(1,1,1, 1,1,1, 1,1,256, 2,4,1, 8, 0,0) \
   X(1,1,1, 1,1,1, 1,1,256, 2,4,1, 8, 2,0)
 
+// FOUR-wave instances (WM x WN x KG = 4: 256 threads, <= 80 KiB of LDS, two workgroups resident per CU) for the 128-channel
+// layers at 17x512^2, whose staging VALU work (GroupNorm + SiLU of every halo element for only 128 output channels) and store
+// tail are too large a share of a tile to hide inside one workgroup: see conv_kernel.h (NWV) and DESIGN.md section 3.1
+#define CVVAE_CONV_G11(X) \
+  X(1,3,3, 1,1,1, 1,8,32, 1,4,1, 2, 1,0) \
+  X(3,3,3, 1,1,1, 2,8,16, 1,4,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,16, 1,4,1, 1, 1,0)
+
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \
-  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X)
+  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X)

@@ -23,7 +23,7 @@ def short(n):
     return n[-60:]
 
 
-def main(d, flt=None, json_out=None):
+def main(d, flt=None, json_out=None, sq_out=None, steps=0):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0, 0.0]))
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -57,6 +57,41 @@ def main(d, flt=None, json_out=None):
         json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of bench.py; fetch = 2 x FETCH_SIZE KiB "
                              "(gfx950 correction of MI355X_MICROARCH.md), write = WRITE_SIZE KiB; mean per dispatch",
                    "kernels": js}, open(json_out, "w"), indent=1)
+        # whole-step HBM traffic (every kernel of the run, conv or not) when the number of profiled steps is known
+        tot = sum((fe * 2 * 1024 + wr * 1024) * n for _, k, n, dur, fe, wr, *_ in rows if fe is not None and wr is not None)
+        doc = json.load(open(json_out))
+        if steps:
+            doc["steps_profiled"] = steps
+            doc["step_total_bytes"] = round(tot / steps)
+        json.dump(doc, open(json_out, "w"), indent=1)
+    if sq_out:
+        # MFMA-busy per kernel: SQ_VALU_MFMA_BUSY_CYCLES (cycles a SIMD's matrix pipe is busy, summed over the chip) over the SIMD
+        # cycles of the dispatch = GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 * 256 CUs * 4 SIMDs -- the gfx94x MfmaUtil formula
+        # (ROCm 7.2 ships no gfx950 derived metrics).  The SQ wait buckets are quad-cycle counts: reported as shares of WAVE_CYCLES.
+        import json
+        js = {}
+        for k, cs in acc.items():
+            def mean(c):
+                return cs[c][1] / cs[c][0] if c in cs and cs[c][0] else None
+            mb, ga = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("GRBM_GUI_ACTIVE")
+            if mb is None or not ga:
+                continue
+            e = {"mfma_busy": round(mb / (ga / 8.0 * 1024.0), 4), "dispatches": max(v[0] for v in cs.values())}
+            wc = mean("SQ_WAVE_CYCLES")
+            for c, nm in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any"),
+                          ("SQ_WAIT_INST_LDS", "wait_inst_lds")):
+                if mean(c) is not None and wc:
+                    e[nm + "_share_of_wave_cycles"] = round(mean(c) / wc, 4)
+            sb = mean("SQ_BUSY_CYCLES")
+            if sb:
+                e["sq_busy_cycles"] = round(sb)
+            for c in cs:
+                if c.startswith("SQ_INSTS_VALU_MFMA"):
+                    e[c.lower()] = round(mean(c))
+            js[k[len("conv_*_"):] if k.startswith("conv_*_") else k] = e
+        json.dump({"source": "rocprofv3 --pmc SQ_* passes of bench.py (separate from the traffic passes); mfma_busy = "
+                             "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), mean per dispatch",
+                   "kernels": js}, open(sq_out, "w"), indent=1)
     fmt = lambda v, s: ("%" + s) % v if v is not None else " " * (int(s.split(".")[0]) - 1) + "-"
     for _, k, n, dur, fe, wr, hit, miss, ga, durg in sorted(rows, reverse=True):
         print(f"{k:58s} {n:5d} {dur:9.1f} {fmt(fe * 2 * 1024 / 1e9 if fe is not None else None, '9.3f')} "
@@ -66,6 +101,8 @@ def main(d, flt=None, json_out=None):
 
 
 if __name__ == "__main__":
-    a = [x for x in sys.argv[1:] if not x.startswith("--json=")]
+    a = [x for x in sys.argv[1:] if not x.startswith("--")]
     j = [x[7:] for x in sys.argv[1:] if x.startswith("--json=")]
-    main(a[0], a[1] if len(a) > 1 else None, j[0] if j else None)
+    q = [x[5:] for x in sys.argv[1:] if x.startswith("--sq=")]
+    st = [int(x[8:]) for x in sys.argv[1:] if x.startswith("--steps=")]
+    main(a[0], a[1] if len(a) > 1 else None, j[0] if j else None, q[0] if q else None, st[0] if st else 0)
