@@ -130,7 +130,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // to PF KiB past the last real fragment: cvvae_packed_weight_bytes() appends this many readable bytes.
 constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
 
-template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB>
+template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, bool XP = false>
 struct Geo {
   static constexpr int NTAPS = KT * KH * KW;
   static constexpr int BM = TT * TH * TW;
@@ -139,7 +139,9 @@ struct Geo {
   static constexpr int FT = (TT - 1) * ST + KT, FH = (TH - 1) * SH + KH, FW = (TW - 1) * SW + KW;
   static constexpr int NPIX = FT * FH * FW;
   static constexpr int CK = 16 * KSUB;
-  static constexpr int PIXB = CK * 2 + 16;
+  // XP (fp32 activations, split-fp16 MFMA): a pixel holds, per 16 channels, hi[0..7] hi[8..15] lo[0..7] lo[8..15] (64 bytes)
+  static constexpr int PIXB = (XP ? CK * 4 : CK * 2) + 16;
+  static constexpr int XPM = XP ? 3 : 1;  // MFMAs (and weight records) per k16 sub-chunk and tap
   static constexpr int BUFB = NPIX * PIXB;
   static constexpr int LDSB = 2 * BUFB;
   static constexpr int NWV = WM * WN * KG;  // waves per workgroup: 8 (one workgroup per CU) or 4 (TWO workgroups per CU)
@@ -149,13 +151,14 @@ struct Geo {
   static constexpr int NPH = NWV == 4 ? (NPIX + PPP - 1) / PPP * PPP : ((NPIX + 1) / 2 + PPP - 1) / PPP * PPP;
   static constexpr int NPASS = NWV == 4 ? NPH / PPP : (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
   static constexpr int SBATCH = NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4);
-  static constexpr int STEPS = NTAPS * KSUB;   // k16 steps per chunk, ordered ks-major: st = ks * NTAPS + tap
+  static constexpr int STEPS = NTAPS * KSUB * XPM;   // k16 steps per chunk, ordered ks-major: st = (ks * NTAPS + tap) * XPM + part
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
   // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
-  static constexpr int PF = (STEPS_W % 9 == 0) ? (MREP >= 8 ? 3 : 9) : (STEPS_W % 8 == 0 ? (MREP >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
+  static constexpr int PF = XP ? 3 : (STEPS_W % 9 == 0) ? (MREP >= 8 ? 3 : 9) : (STEPS_W % 8 == 0 ? (MREP >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
   // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
   static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
   static constexpr int SMEMB = cmax(LDSB, REDB);
+  static_assert(!XP || KG == 1, "split-precision instances: no K-group split");
   static_assert(NWV == 8 || (NWV == 4 && KG == 1), "8 waves per workgroup, or 4 (two workgroups per CU; no K-group split)");
   static_assert(NWV == 8 || LDSB <= 80 * 1024, "two resident workgroups share the CU's 160 KiB of LDS");
   static_assert(KG == 1 || (KG == 2 && KSUB % 2 == 0 && MREP % 2 == 0 && WM * WN == 4), "K-group split");
@@ -180,6 +183,51 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return __builtin_bit_cast(uint4, x);
 }
 
+// 8 consecutive elements <-> fp32 registers, for the 16-bit storage types (one 16-byte access) and for float (two)
+template <typename T>
+struct Raw8 {
+  uint4 a;
+};
+template <>
+struct Raw8<float> {
+  uint4 a, b;
+};
+template <typename T>
+__device__ __forceinline__ Raw8<T> ldraw8(const T* p) {
+  Raw8<T> r;
+  r.a = *reinterpret_cast<const uint4*>(p);
+  return r;
+}
+template <>
+__device__ __forceinline__ Raw8<float> ldraw8<float>(const float* p) {
+  Raw8<float> r;
+  r.a = reinterpret_cast<const uint4*>(p)[0];
+  r.b = reinterpret_cast<const uint4*>(p)[1];
+  return r;
+}
+template <typename T>
+__device__ __forceinline__ void unraw8(const Raw8<T>& r, float (&f)[8]) {
+  unpack8<T>(r.a, f);
+}
+template <>
+__device__ __forceinline__ void unraw8<float>(const Raw8<float>& r, float (&f)[8]) {
+  f[0] = __uint_as_float(r.a.x); f[1] = __uint_as_float(r.a.y); f[2] = __uint_as_float(r.a.z); f[3] = __uint_as_float(r.a.w);
+  f[4] = __uint_as_float(r.b.x); f[5] = __uint_as_float(r.b.y); f[6] = __uint_as_float(r.b.z); f[7] = __uint_as_float(r.b.w);
+}
+template <typename T>
+__device__ __forceinline__ void ld8(const T* p, float (&f)[8]) {
+  unraw8<T>(ldraw8<T>(p), f);
+}
+template <typename T>
+__device__ __forceinline__ void st8(T* p, const float (&f)[8]) {
+  *reinterpret_cast<uint4*>(p) = pack8<T>(f);
+}
+template <>
+__device__ __forceinline__ void st8<float>(float* p, const float (&f)[8]) {
+  reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
+  reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 // out-of-range tap handling: replicate = clamp, zero = flag
@@ -192,10 +240,20 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
   return c;
 }
 
+// XP ("extended precision", T = _Float16): the model is fp32 -- activations, residuals and outputs are float tensors, the
+// packed weights are split-fp16 records (cvvae_pack_weights* with dtype CVVAE_F32).  Every fp32 operand x is staged as
+// hi = fp16(x), lo = fp16(x - hi) and every product runs as THREE fp16 MFMAs into the same fp32 accumulator:
+//   Whi.hi + Whi.lo + Wlo.hi   (Wlo.lo ~ 2^-22 relative is dropped)
+// arranged so that the K = 16 of one MFMA holds [Whi(c0..7) | Whi(c0..7)] x [hi(c0..7) | lo(c0..7)]  (parts 1, 2: channels
+// 0..7 / 8..15 of the sub-chunk) and [Wlo(c0..15)] x [hi(c0..15)] (part 0).  ~fp32 results (relative error ~1e-6) at 3x the
+// MFMA work: the reference's fp32 model path (from_pretrained without torch_dtype) and north_star's |delta| <= 1e-3 bound.
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS>
+          int PRO, int UPS, bool XP = false>
 __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) void conv_fwd_kernel(const ConvArgs p) {
-  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB>;
+  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, XP>;
+  using TIO = std::conditional_t<XP, float, T>;  // element type of the activation tensors in HBM
+  static_assert(!XP || std::is_same<T, _Float16>::value, "split precision runs on fp16 MFMA");
+  constexpr int XPM = G::XPM;
   // NWV == 4 (WM x WN = 4 waves, 256 threads, <= 256 VGPRs, <= 80 KiB of LDS): TWO workgroups are resident per CU, one wave of
   // each per SIMD.  Nothing couples them, so one workgroup's serial parts (first halo chunk, store tail, barrier waits, the
   // GroupNorm + SiLU VALU work of the staging, which runs ~4x slower beside a saturated MFMA stream) run under the other's MFMAs.
@@ -259,14 +317,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   //      p.w_taps == 2*NTAPS); zero frames are simply skipped.  Halo frames no wave of the workgroup reads are not staged
   //      either.  cfg 3: 6-20 % fewer MFMAs on the causal encoder convs, 4-13 % on the decoder's.
   constexpr bool TFOLD = (KT == 3 && KG == 1);
-  constexpr int NSP = KH * KW, GS = NSP * KSUB;  // steps of one time group
+  constexpr int NSP = KH * KW, GS = NSP * KSUB * XPM;  // steps of one time group
   // a wave's fragments lie in ONE output frame -- or (WM == 1 with a multi-frame tile: the 4-wave instances) span all of the
   // tile's frames, in which case the tile takes a fold only when every frame has the same plan (else: plain three groups)
   static_assert(!TFOLD || (GS % PF == 0 && (TT == 1 || WM == 1 || (TH * TW) % (MREP * 32) == 0)), "time-group plan");
   const long long w_ks = (long long)(TFOLD ? p.w_taps : NTAPS) * 512;  // elements between consecutive k16 record groups
   const long long w_cs = w_ks * KSUB;                                   // ... between consecutive K chunks
   int tf_ng = 3;
-  long long tf_w0 = 0, tf_w1 = NSP * 512, tf_w2 = 2 * NSP * 512;  // weight slot of each time group (element offsets)
+  long long tf_w0 = 0, tf_w1 = NSP * XPM * 512, tf_w2 = 2 * NSP * XPM * 512;  // weight slot of each time group (element offsets)
   unsigned tf_l0 = 0, tf_l1 = G::FH * G::FW * PIXB, tf_l2 = 2 * G::FH * G::FW * PIXB;  // LDS frame of each time group
   int hf_a = 0, hf_b = G::FT - 1;  // halo frames [hf_a, hf_b] some wave of this workgroup reads
   if constexpr (TFOLD) {
@@ -278,7 +336,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       auto clampT = [&](int v) { return v < 0 ? 0 : (v >= p.Tl ? p.Tl - 1 : v); };
       ng = 3; slot0 = 0; slot1 = 1; dt0 = 0; dt1 = 1;
       if (p.mode_t != 0) {  // replicate
-        if (p.w_taps == 2 * NTAPS) {
+        if (p.w_taps == 2 * NTAPS * XPM) {
           const bool eq01 = clampT(f0) == clampT(f0 + 1), eq12 = clampT(f0 + 1) == clampT(f0 + 2);
           if (eq01 && eq12) { ng = 1; slot0 = 5; dt0 = 1; }
           else if (eq01) { ng = 2; slot0 = 3; dt0 = 1; slot1 = 2; dt1 = 2; }
@@ -303,8 +361,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       }
       if (plain) { tf_ng = 3; slot0 = 0; slot1 = 1; dt0 = 0; dt1 = 1; }
     }
-    tf_w0 = (long long)slot0 * (NSP * 512);
-    tf_w1 = (long long)slot1 * (NSP * 512);
+    tf_w0 = (long long)slot0 * (NSP * XPM * 512);
+    tf_w1 = (long long)slot1 * (NSP * XPM * 512);
     tf_l0 = (unsigned)dt0 * (G::FH * G::FW * PIXB);
     tf_l1 = (unsigned)dt1 * (G::FH * G::FW * PIXB);
     hf_a = G::FT;
@@ -354,14 +412,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     srcpix[k] = sp;
     if (__builtin_amdgcn_ballot_w64(sp != -2) != 0) passmask |= 1u << k;
   }
-  const int lds_w0 = (pstart + spl) * PIXB + sq * 16;
-  const T* __restrict__ inp = reinterpret_cast<const T*>(p.in);
+  const int lds_w0 = (pstart + spl) * PIXB + (XP ? (sq >> 1) * 64 + (sq & 1) * 16 : sq * 16);  // XP: my hi slice; lo = +32
+  const TIO* __restrict__ inp = reinterpret_cast<const TIO*>(p.in);
   const size_t gn_row = (size_t)(b * p.gn_rpb + (p.gn_rpb > 1 ? t0 : 0)) * (size_t)p.Cin;
 
 #ifdef CVVAE_CONV_PROBE
   int probe_n = 0;
 #endif
-  auto stage_from = [&](auto pro_tag, const T* __restrict__ src, size_t src_ps, int chunk, int bufsel) {
+  auto stage_from = [&](auto pro_tag, const TIO* __restrict__ src, size_t src_ps, int chunk, int bufsel) {
     constexpr int PRO_ = decltype(pro_tag)::value;  // prologue applied to THIS source (the shortcut input has none)
     const int c0 = chunk * CK + sq * 8;
     float sc[8], sh[8];
@@ -376,14 +434,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     constexpr int SB = G::SBATCH;  // passes in flight together (bounds the staging registers)
 #pragma unroll
     for (int k0 = 0; k0 < NPASS; k0 += SB) {
-      uint4 raw[SB];
+      Raw8<TIO> raw[SB];
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
         if (k < NPASS && ((passmask >> k) & 1)) {
           // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
           const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
-          raw[kk] = *reinterpret_cast<const uint4*>(src + (size_t)sp * src_ps + c0);
+          raw[kk] = ldraw8<TIO>(src + (size_t)sp * src_ps + c0);
         }
       }
 #ifdef CVVAE_CONV_PROBE
@@ -398,10 +456,31 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         const int k = k0 + kk;
         if (k < NPASS && ((passmask >> k) & 1)) {
           if (srcpix[k] == -2) continue;
-          uint4 o = raw[kk];
+          if constexpr (XP) {  // fp32 source -> (GroupNorm affine, SiLU in fp32) -> hi = fp16(x), lo = fp16(x - hi)
+            float f[8], fl[8];
+            unraw8<float>(raw[kk], f);
+            if (PRO_ != 0) {
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                float v = f[j] * sc[j] + sh[j];
+                f[j] = (PRO_ == 1) ? silu_f(v) : v;
+              }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              const float h = (float)(T)f[j];
+              fl[j] = f[j] - h;
+              f[j] = h;
+            }
+            uint4 oh = pack8<T>(f), ol = pack8<T>(fl);
+            if (srcpix[k] < 0) oh = ol = make_uint4(0, 0, 0, 0);  // zero padding is applied AFTER GroupNorm+SiLU
+            *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = oh;
+            *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB) + 32) = ol;
+          } else {
+          uint4 o = raw[kk].a;
           if (PRO_ != 0) {
             float f[8];
-            unpack8<T>(raw[kk], f);
+            unpack8<T>(raw[kk].a, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               float v = f[j] * sc[j] + sh[j];
@@ -411,6 +490,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           }
           if (srcpix[k] < 0) o = make_uint4(0, 0, 0, 0);  // zero padding is applied AFTER GroupNorm+SiLU
           *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = o;
+          }
         }
       }
     }
@@ -431,7 +511,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                          kgrp * (KSUB / KG) * 32);
   }
   // step i of a time group: k16 sub-chunk i / NSP, spatial tap i % NSP
-  auto tf_rec = [&](int i) -> long long { return (long long)(i / NSP) * w_ks + (i % NSP) * 512; };
+  auto tf_rec = [&](int i) -> long long {
+    const int j = i / XPM, part = i % XPM;
+    return (long long)(j / NSP) * w_ks + ((j % NSP) * XPM + part) * 512;
+  };
+  // XP: LDS byte offset of step (k16 sub-chunk ks, part) inside a pixel, and the lane term of parts 1, 2: lanes 32-63 read the
+  // lo half 32 bytes above the hi half (aoff[] carries (lane >> 5) * 16, the standard k split of part 0)
+  const unsigned lhi16 = XP ? (unsigned)((lane >> 5) * 16) : 0u;
   const T* wq = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
                 (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
                 (TFOLD ? (size_t)(active ? nb : 0) * (size_t)p.nchunks * (size_t)w_cs
@@ -469,7 +555,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   //      residual of fragments 2c, 2c+1 before its MFMAs (16 VGPRs) and adds it to those accumulators afterwards: the loads
   //      fly under ~150 MFMAs (a 16-byte run = quads 2pr, 2pr+1 of the lane).  Measured: +1.3 % (128 ch) ... +2.7 %
   //      (512 ch) on the conv2 layers.
-  constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0);
+  constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0 && !XP);
   const bool res_pre = RES_PRE && p.res != nullptr && p.res_pre != 0 && p.nchunks >= MREP / 2;
   uint4 rpre[2][2];
 
@@ -501,12 +587,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
           for (int i = 0; i < GS; ++i) {
             const v8 wv = wf[i % PF];
-            const int nsp = (i + 1) % NSP, nks = (i + 1) / NSP;
-            const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * 32;
+            const int nj = (i + 1) / XPM, npart = (i + 1) % XPM;
+            const int nsp = nj % NSP, nks = nj / NSP;
+            const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
               acc[r] = Tr<T>::mfma(wv, ab[i & 1][r], acc[r]);
-              if (i + 1 < GS) ab[(i + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + (unsigned)noff]);
+              if (i + 1 < GS)
+                ab[(i + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
             }
             if (i + 1 == GS && !lastg) {  // first fragments of the next time group (set 0: its step 0)
 #pragma unroll
@@ -546,13 +634,15 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
       for (int st = 0; st < STEPS_W; ++st) {
         const v8 wv = wf[st % PF];
-        const int nks = (st + 1) / NTAPS, nt = (st + 1) % NTAPS;  // next step's k-sub-chunk (within my K-group) / tap
+        const int nq = (st + 1) / XPM, npart = (st + 1) % XPM;
+        const int nks = nq / NTAPS, nt = nq % NTAPS;  // next step's k-sub-chunk (within my K-group) / tap
         const int ndt = nt / (KH * KW), ndy = (nt / KW) % KH, ndx = nt % KW;
-        const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * 32;
+        const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
 #pragma unroll
         for (int r = 0; r < MREP; ++r) {
           acc[r] = Tr<T>::mfma(wv, ab[st & 1][r], acc[r]);
-          if (st + 1 < STEPS_W) ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (unsigned)noff]);
+          if (st + 1 < STEPS_W)
+            ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
         }
         // ring refill: my record st+PF of this chunk, or (wrapping) record st+PF-STEPS_W of the next chunk
         wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512);
@@ -592,12 +682,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   //      above has released both halo buffers)
   if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0) {
     if (p.in2 != nullptr) {
-      const T* __restrict__ inp2 = reinterpret_cast<const T*>(p.in2);
+      const TIO* __restrict__ inp2 = reinterpret_cast<const TIO*>(p.in2);
       auto stage2 = [&](int chunk, int bufsel) {
         stage_from(std::integral_constant<int, 0>{}, inp2, (size_t)p.in2_ps, chunk, bufsel);
       };
       constexpr unsigned ctr = (unsigned)((1 * G::FW + 1) * PIXB);  // centre tap (dy = dx = 1)
-      const T* w2q = reinterpret_cast<const T*>(p.w2) + (size_t)(active ? nb : 0) * (size_t)p.nchunks2 * (KSUB * 512) + lane * 8;
+      const T* w2q = reinterpret_cast<const T*>(p.w2) + (size_t)(active ? nb : 0) * (size_t)p.nchunks2 * (KSUB * XPM * 512) + lane * 8;
       stage2(0, 0);
       __syncthreads();
       for (int c = 0; c < p.nchunks2; ++c) {
@@ -606,14 +696,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         if (grp == 0 && more) stage2(c + 1, cur ^ 1);
         if (active) {
           const unsigned lb = (unsigned)(cur * G::BUFB);
-          v8 wv[KSUB];
+          v8 wv[KSUB * XPM];
 #pragma unroll
-          for (int ks = 0; ks < KSUB; ++ks) wv[ks] = *reinterpret_cast<const v8*>(w2q + ((size_t)c * KSUB + ks) * 512);
+          for (int ks = 0; ks < KSUB * XPM; ++ks) wv[ks] = *reinterpret_cast<const v8*>(w2q + ((size_t)c * KSUB * XPM + ks) * 512);
 #pragma unroll
           for (int ks = 0; ks < KSUB; ++ks)
 #pragma unroll
-            for (int r = 0; r < MREP; ++r)
-              acc[r] = Tr<T>::mfma(wv[ks], *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + ctr + ks * 32]), acc[r]);
+            for (int part = 0; part < XPM; ++part)
+#pragma unroll
+              for (int r = 0; r < MREP; ++r)
+                acc[r] = Tr<T>::mfma(wv[ks * XPM + part],
+                                     *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (part ? lhi16 : 0u) + ctr +
+                                                                        ks * (XP ? 64 : 32) + (part == 2 ? 16 : 0)]),
+                                     acc[r]);
         }
         if (grp == 1 && more) stage2(c + 1, cur ^ 1);
         __syncthreads();
@@ -689,12 +784,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         if (cb >= p.Cout) continue;
         const float4 bv = *reinterpret_cast<const float4*>(p.bias + cb);
         const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
-        T* o = reinterpret_cast<T*>(p.out);
+        TIO* o = reinterpret_cast<TIO*>(p.out);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
           if (cb + j < p.Cout)
             o[((((size_t)b * p.Cout + (cb + j)) * p.To + to) * p.Ho + yo) * (size_t)p.Wo + xo] =
-                (T)(bias_pre ? acc[r][g * 4 + j] : acc[r][g * 4 + j] * p.alpha + bb[j]);
+                (TIO)(bias_pre ? acc[r][g * 4 + j] : acc[r][g * 4 + j] * p.alpha + bb[j]);
       }
     }
     CVVAE_PROBE_MARK();
@@ -762,7 +857,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   constexpr int TWm = TW < 32 ? TW : 32;
   static_assert(TW % 32 == 0 || (32 % TW == 0 && TH % (32 / TW) == 0), "fragment rows must tile the workgroup tile");
   const bool tile_full = (t0 + TT <= p.To) && (y0 + TH <= p.Ho) && (x0 + TW <= p.Wo) && ((nb + 1) * 32 <= p.Cout) &&
-                         !p.out_f32 && (p.out_mode != 2 || (C2 & 31) == 0);
+                         !p.out_f32 && !XP && (p.out_mode != 2 || (C2 & 31) == 0);
   if (tile_full) {
     const int l31 = lane_e & 31;
     const int Wst = (UPS == 2 ? 2 : 1) * p.Wo, Hst = (UPS == 2 ? 2 : 1) * p.Ho;  // stored frame size
@@ -855,7 +950,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   } else {
   #pragma unroll
     for (int r0 = 0; r0 < MREP; r0 += RB) {
-      uint4 rres[RB][2];
+      Raw8<TIO> rres[RB][2];
       int pixr[RB];
       bool ff[RB];
   #pragma unroll
@@ -869,8 +964,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           for (int pr = 0; pr < 2; ++pr) {
             const int pix = pix_of(pixr[ri], ff[ri], pr);
             // unconditional 16-byte load (pixel 0 for lanes with nothing to store) keeps the loads branch-free
-            rres[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) +
-                                                           (long long)(pix < 0 ? 0 : pix) * (long long)p.out_ps + ccv[pr]);
+            rres[ri][pr] = ldraw8<TIO>(reinterpret_cast<const TIO*>(p.res) + (long long)(pix < 0 ? 0 : pix) * (long long)p.out_ps +
+                                       ccv[pr]);
           }
         }
       }
@@ -899,17 +994,36 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           }
           if (p.res && !res_pre) {
             float rf[8];
-            unpack8<T>(rres[ri][pr], rf);
+            unraw8<TIO>(rres[ri][pr], rf);
   #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rf[j];
           }
           const int c8 = c8v[pr];
           const bool full = (c8 + 7 < p.Cout);
-          if (p.out_f32) {
+          if (XP || p.out_f32) {
             float* o = reinterpret_cast<float*>(p.out) + off;
             if (full) {
               *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
               *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+              if (XP && p.gnp) {  // fused GroupNorm statistics of the fp32 values stored (shifted sums, as below)
+                if (!((gkm >> pr) & 1)) {
+                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);
+                  const unsigned hm = (lane_e & 32) ? (unsigned)(mk >> 32) : (unsigned)mk;
+                  const int src = (lane_e & 32) + __builtin_ctz(hm);
+                  gk[pr][0] = __shfl(v[0], src);
+                  gk[pr][1] = __shfl(v[4], src);
+                  gkm |= 1u << pr;
+                }
+                gc[pr] += 1.f;
+  #pragma unroll
+                for (int q = 0; q < 2; ++q)
+  #pragma unroll
+                  for (int j = 0; j < 4; ++j) {
+                    const float dv = v[q * 4 + j] - gk[pr][q];
+                    gs[pr][q] += dv;
+                    gq[pr][q] += dv * dv;
+                  }
+              }
             } else {
   #pragma unroll
               for (int j = 0; j < 8; ++j)
@@ -1004,9 +1118,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS>
+          int PRO, int UPS, bool XP = false>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
-  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS>), dim3(grid),
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XP>), dim3(grid),
                      dim3(WM * WN * KG * 64), 0, s, a);
   return (int)hipGetLastError();
 }

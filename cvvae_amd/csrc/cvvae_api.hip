@@ -16,21 +16,27 @@ namespace cvvae {
   extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t); \
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_ALL(CVVAE_EXTERN)
+#define CVVAE_EXTERN_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,true>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_XP(CVVAE_EXTERN_XP)
 
 typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 
 struct Instance {
   int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, kg, ksub, pro, ups;
-  launch_fn fn[2];  // [CVVAE_F16], [CVVAE_BF16]
+  launch_fn fn[3];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one)
   char name[96];
 };
 
 #define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
-    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>}, ""},
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr}, ""},
+#define CVVAE_ROW_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
+   {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,true>}, ""},
 
-static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW)};
+static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_XP(CVVAE_ROW_XP)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -58,6 +64,7 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
   for (int pass = 0; pass < 2 && !best; ++pass)
   for (int i = 0; i < g_ntable; ++i) {
     const Instance& e = g_table[i];
+    if (!e.fn[d->dtype]) continue;  // fp32 models run the split-precision instances, fp16 / bf16 models the others
     if (pass == 0 && ft &&
         (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) continue;
     // the folded upsample (upsample2x == 2) runs 3x2x2 phase kernels; everything else matches the descriptor's taps
@@ -114,6 +121,7 @@ static const Instance* odd_frame_sibling(const cvvae_conv_desc* d, const Instanc
   if (e->tt != 2 || !(d->To & 1) || d->To < 3 || d->upsample2x == 2 || d->sT != 1) return nullptr;
   for (int i = 0; i < g_ntable; ++i) {
     const Instance& s = g_table[i];
+    if (!s.fn[d->dtype]) continue;
     if (s.tt == 1 && s.th == e->th && s.tw == e->tw && s.wm == e->wm && s.wn == e->wn && s.kg == e->kg && s.ksub == e->ksub &&
         s.pro == e->pro && s.ups == e->ups && s.kt == e->kt && s.kh == e->kh && s.kw == e->kw && s.st == e->st && s.sh == e->sh &&
         s.sw == e->sw)
@@ -124,15 +132,15 @@ static const Instance* odd_frame_sibling(const cvvae_conv_desc* d, const Instanc
 
 static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
-    snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d", e->kt, e->kh, e->kw, e->st,
-             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups);
+    snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d%s", e->kt, e->kh, e->kw, e->st,
+             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups, e->fn[2] ? "_xp" : "");
   (void)dtype;
   return e->name;
 }
 
 static int check_desc(const cvvae_conv_desc* d) {
   if (!d) return CVVAE_EINVAL;
-  if (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16) return CVVAE_EINVAL;
+  if (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16 && d->dtype != CVVAE_F32) return CVVAE_EINVAL;
   if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0)
     return CVVAE_EINVAL;
   const int ck = cvvae_conv_kchunk(d->kT, d->kH, d->kW);
@@ -284,7 +292,8 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
     a.in2_ps = d->sc_in_pix_stride;
     a.nchunks2 = d->sc_Cin / (16 * e->ksub);
   }
-  a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT * (d->w_time_folds ? 2 : 1)) / 2) : 0;
+  const int xpm = d->dtype == CVVAE_F32 ? 3 : 1;  // packed records per (k16, tap): the split-precision layout carries three
+  a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT * (d->w_time_folds ? 2 : 1) * xpm) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;
   a.mode_t = d->pad_mode_t; a.mode_hw = d->pad_mode_hw;
@@ -301,7 +310,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.order = 1;
   if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
   a.alpha = d->alpha;
-  a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1);
+  a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1) * xpm;
   static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid
   a.res_pre = (residual && d->alpha == 1.0f && !d->out_f32 && !res_pre_off) ? 1 : 0;
   // tuning aid (tools/tune_instances.py re-launches recorded calls under CVVAE_CONV_FORCE: the record table was sized for

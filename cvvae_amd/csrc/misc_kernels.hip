@@ -59,6 +59,58 @@ __global__ void pack_weights_kernel(const T* __restrict__ src, int Cout_src, int
   *reinterpret_cast<typename Tr<T>::v8*>(dst + (rec * ksub + ks) * 512 + lane * 8) = v;
 }
 
+// Split-precision records (dtype CVVAE_F32: fp32 source, conv_fwd_kernel<..., XP>): THREE fp16 records per (k16, tap),
+//   part 0: Wlo(c)  at k = c            (c = 0..15 of the sub-chunk)      x  B = hi(c)            -> Wlo.hi
+//   part 1: Whi(c)  at k = c and c + 8  (c = 0..7)                        x  B = [hi(c) | lo(c)]  -> Whi.hi + Whi.lo
+//   part 2: Whi(c)  at k = c-8 and c    (c = 8..15)                       x  B = [hi(c) | lo(c)]
+// with Whi = fp16(w), Wlo = fp16(w - Whi); w = the (folded, fp32) source element.  The host pre-scales the weights by a power
+// of two (ops.py) so that Wlo stays in fp16's normal range; the conv's alpha undoes it.
+__device__ __forceinline__ void xp_store(_Float16* dst, long long rec3, int lane, const float (&w)[16]) {
+  // w[0..15]: the 16 channels of the sub-chunk for my output row.  lane >> 5 selects k half of the MFMA A operand.
+  const int kh = lane >> 5;
+  f16x8 p0, p1, p2;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float a0 = w[kh * 8 + j];
+    p0[j] = (_Float16)(a0 - (float)(_Float16)a0);  // Wlo of channel kh*8 + j
+    p1[j] = (_Float16)w[j];                        // Whi of channel j      (both k halves)
+    p2[j] = (_Float16)w[8 + j];                    // Whi of channel 8 + j  (both k halves)
+  }
+  *reinterpret_cast<f16x8*>(dst + (rec3 + 0) * 512 + lane * 8) = p0;
+  *reinterpret_cast<f16x8*>(dst + (rec3 + 1) * 512 + lane * 8) = p1;
+  *reinterpret_cast<f16x8*>(dst + (rec3 + 2) * 512 + lane * 8) = p2;
+}
+
+__global__ void pack_weights_xp_kernel(const float* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
+                                       long long s_ci, long long s_tap, int nchunks, _Float16* __restrict__ dst,
+                                       long long nfrag_lanes, int fold_n, long long s_fold, long long s_batch,
+                                       long long d_batch, int dst_taps, int dst_tap0) {
+  const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= nfrag_lanes) return;
+  src += (long long)blockIdx.y * s_batch;
+  dst += (long long)blockIdx.y * d_batch;
+  const int lane = (int)(gid & 63);
+  long long f = gid >> 6;
+  const int tap = (int)(f % taps);
+  f /= taps;
+  const int chunk = (int)(f % nchunks);  // k16 index
+  const int nb = (int)(f / nchunks);
+  const int co = nb * 32 + sigma_row(lane & 31);
+  float w[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int ci = chunk * 16 + j;
+    float a = 0.f;
+    if (co < Cout_src && ci < Cin_src) {
+      const float* e = src + (long long)co * s_co + (long long)ci * s_ci + (long long)tap * s_tap;
+      for (int q = 0; q < (fold_n <= 1 ? 1 : fold_n); ++q) a += e[(long long)q * s_fold];
+    }
+    w[j] = a;
+  }
+  const long long rec = ((long long)nb * nchunks + chunk) * dst_taps + dst_tap0 + tap;
+  xp_store(dst, rec * 3, lane, w);
+}
+
 // Nearest-2x upsample folded into the conv weights (Upsample3D: F.interpolate(scale (1,2,2)) then a 3x3x3 conv,
 // models/vae_blocks3d_sd3.py:342-356, models/vae_models.py:218-229).  Output row 2y+py reads upsampled rows 2y+py-1..2y+py+1
 // = stored rows {y-1, y, y} (py = 0) or {y, y, y+1} (py = 1): two stored rows per phase, with the weights of the taps that
@@ -108,6 +160,43 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
   *reinterpret_cast<typename Tr<T>::v8*>(dst + (long long)phase * phase_stride_elems + rec * 512 + lane * 8) = v;
 }
 
+__global__ void pack_upfold_xp_kernel(const float* __restrict__ src, int Cout, int Cin, int nchunks, _Float16* __restrict__ dst,
+                                      long long per_phase_lanes, long long phase_stride_elems, int tfold, int dst_taps,
+                                      int dst_tap0) {
+  const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid0 >= 4 * per_phase_lanes) return;
+  const int phase = (int)(gid0 / per_phase_lanes);
+  const long long gid = gid0 - (long long)phase * per_phase_lanes;
+  const int py = phase >> 1, px = phase & 1;
+  const int lane = (int)(gid & 63);
+  long long f = gid >> 6;
+  const int ntap = tfold ? 4 : 12;
+  const int tap = (int)(f % ntap);
+  f /= ntap;
+  const int chunk = (int)(f % nchunks);
+  const int nb = (int)(f / nchunks);
+  const int kt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
+  const int kt_lo = tfold == 0 ? kt : (tfold == 1 || tfold == 3 ? 0 : 1), kt_hi = tfold == 0 ? kt : (tfold == 2 || tfold == 3 ? 1 : 2);
+  const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
+  const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
+  const int co = nb * 32 + sigma_row(lane & 31);
+  float w16[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int ci = chunk * 16 + j;
+    float acc = 0.f;
+    if (co < Cout && ci < Cin) {
+      const float* w = src + ((long long)co * Cin + ci) * 27;
+      for (int k = kt_lo; k <= kt_hi; ++k)
+        for (int ky = y_lo; ky <= y_hi; ++ky)
+          for (int kx = x_lo; kx <= x_hi; ++kx) acc += w[k * 9 + ky * 3 + kx];
+    }
+    w16[j] = acc;
+  }
+  const long long rec = ((long long)nb * nchunks + chunk) * dst_taps + dst_tap0 + tap;
+  xp_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // GroupNorm statistics.  Stage 1: grid (nsplit, rows); each block reduces a slab of pixels for all channels
 // with Welford/Chan updates on 4-channel quads; stage 2 merges the slabs and emits the affine table.
@@ -145,12 +234,12 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
     // deviations) over the 32 values of each channel quad held in registers, and ONE Chan merge per batch
     constexpr int U = 8;
     for (; px + (long long)(U - 1) * ppp < p1; px += (long long)U * ppp) {
-      uint4 u[U];
+      Raw8<T> u[U];
 #pragma unroll
-      for (int i = 0; i < U; ++i) u[i] = *reinterpret_cast<const uint4*>(base + (px + (long long)i * ppp) * ps);
+      for (int i = 0; i < U; ++i) u[i] = ldraw8<T>(base + (px + (long long)i * ppp) * ps);
       float f[U][8];
 #pragma unroll
-      for (int i = 0; i < U; ++i) unpack8<T>(u[i], f[i]);
+      for (int i = 0; i < U; ++i) unraw8<T>(u[i], f[i]);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         float sum = 0.f;
@@ -170,9 +259,8 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const T* __restrict__ x
       }
     }
     for (; px < p1; px += ppp) {
-      const uint4 u = *reinterpret_cast<const uint4*>(base + px * ps);
       float f[8];
-      unpack8<T>(u, f);
+      ld8<T>(base + px * ps, f);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const float a = f[h * 4 + 0], b = f[h * 4 + 1], c = f[h * 4 + 2], d = f[h * 4 + 3];
@@ -312,7 +400,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   float sum = 0.f;
   for (int v = lane; v < nv; v += 64) {
     float f[8];
-    unpack8<T>(*reinterpret_cast<const uint4*>(x + pix * C + v * 8), f);
+    ld8<T>(x + pix * C + v * 8, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) sum += f[j];
   }
@@ -322,7 +410,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   float var = 0.f;
   for (int v = lane; v < nv; v += 64) {
     float f[8];
-    unpack8<T>(*reinterpret_cast<const uint4*>(x + pix * C + v * 8), f);
+    ld8<T>(x + pix * C + v * 8, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) var += (f[j] - mean) * (f[j] - mean);
   }
@@ -331,10 +419,10 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const T* __restrict__ x,
   const float rstd = rsqrtf(var / (float)C + eps);
   for (int v = lane; v < nv; v += 64) {
     float f[8];
-    unpack8<T>(*reinterpret_cast<const uint4*>(x + pix * C + v * 8), f);
+    ld8<T>(x + pix * C + v * 8, f);
 #pragma unroll
     for (int j = 0; j < 8; ++j) f[j] = (f[j] - mean) * rstd * gamma[v * 8 + j] + beta[v * 8 + j];
-    *reinterpret_cast<uint4*>(out + pix * C + v * 8) = pack8<T>(f);
+    st8<T>(out + pix * C + v * 8, f);
   }
 }
 
@@ -422,12 +510,12 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
     float qf[8][8];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i < Tn) unpack8<T>(*reinterpret_cast<const uint4*>(qb + i * tstride + vv * 8), qf[i]);
+      if (i < Tn) ld8<T>(qb + i * tstride + vv * 8, qf[i]);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       if (j < Tn) {
         float kf[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(kb + j * tstride + vv * 8), kf);
+        ld8<T>(kb + j * tstride + vv * 8, kf);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           if (i < Tn) {
@@ -477,7 +565,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
     for (int j = 0; j < 8; ++j) {
       if (j < Tn) {
         float vf[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(vb + j * tstride + vv * 8), vf);
+        ld8<T>(vb + j * tstride + vv * 8, vf);
 #pragma unroll
         for (int i = 0; i < 8; ++i)
           if (i < Tn) {
@@ -488,7 +576,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const T* __restrict_
     }
 #pragma unroll
     for (int i = 0; i < 8; ++i)
-      if (i < Tn) *reinterpret_cast<uint4*>(out + base + i * tstride + vv * 8) = pack8<T>(o[i]);
+      if (i < Tn) st8<T>(out + base + i * tstride + vv * 8, o[i]);
   }
 }
 
@@ -514,7 +602,7 @@ __global__ __launch_bounds__(256) void temporal_attn_general_kernel(const T* __r
     const int vv = lane + u * 64;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { qf[u][e] = 0.f; o[u][e] = 0.f; }
-    if (vv < nv) unpack8<T>(*reinterpret_cast<const uint4*>(q + base + i * tstride + vv * 8), qf[u]);
+    if (vv < nv) ld8<T>(q + base + i * tstride + vv * 8, qf[u]);
   }
   float mx = -3.0e38f, sum = 0.f;
   for (int j = 0; j < Tn; ++j) {
@@ -524,7 +612,7 @@ __global__ __launch_bounds__(256) void temporal_attn_general_kernel(const T* __r
       const int vv = lane + u * 64;
       if (vv < nv) {
         float kf[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(k + base + j * tstride + vv * 8), kf);
+        ld8<T>(k + base + j * tstride + vv * 8, kf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) d += qf[u][e] * kf[e];
       }
@@ -541,7 +629,7 @@ __global__ __launch_bounds__(256) void temporal_attn_general_kernel(const T* __r
       const int vv = lane + u * 64;
       if (vv < nv) {
         float vf[8];
-        unpack8<T>(*reinterpret_cast<const uint4*>(v + base + j * tstride + vv * 8), vf);
+        ld8<T>(v + base + j * tstride + vv * 8, vf);
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[u][e] = o[u][e] * corr + pj * vf[e];
       }
@@ -554,7 +642,7 @@ __global__ __launch_bounds__(256) void temporal_attn_general_kernel(const T* __r
     if (vv < nv) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) o[u][e] *= inv;
-      *reinterpret_cast<uint4*>(out + base + i * tstride + vv * 8) = pack8<T>(o[u]);
+      st8<T>(out + base + i * tstride + vv * 8, o[u]);
     }
   }
 }
@@ -606,9 +694,9 @@ __global__ __launch_bounds__(256) void frames_u8_to_ndhwc_kernel(const uint8_t* 
   }
 #pragma unroll
   for (int c = 3; c < 8; ++c) v[c] = 0.f;
-  *reinterpret_cast<uint4*>(out + pix * Cpad) = pack8<T>(v);
+  st8<T>(out + pix * Cpad, v);
   const float z[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 8; c0 < Cpad; c0 += 8) *reinterpret_cast<uint4*>(out + pix * Cpad + c0) = pack8<T>(z);
+  for (int c0 = 8; c0 < Cpad; c0 += 8) st8<T>(out + pix * Cpad + c0, z);
 }
 
 template <typename T>
@@ -684,7 +772,7 @@ int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, in
 int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src,
                                int32_t Cin_src, int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad,
                                int32_t kchunk, void* dst, int64_t dst_batch_stride, void* stream) {
-  if (batch <= 0 || dst_batch_stride % 16 || (size_t)dst_batch_stride < cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps))
+  if (batch <= 0 || dst_batch_stride % 16 || (size_t)dst_batch_stride < cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps * (dtype == CVVAE_F32 ? 3 : 1)))
     return CVVAE_EINVAL;
   return pack_impl(dtype, src, batch, s_batch, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst,
                    dst_batch_stride, stream);
@@ -711,6 +799,10 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
     hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid, batch), dim3(256), 0, s, (const _Float16*)src, Cout_src,
                        Cin_src, taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n,
                        fold_n, (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
+  else if (dtype == CVVAE_F32)  // fp32 source -> split-precision records (3 per (k16, tap); one thread per record TRIPLE)
+    hipLaunchKernelGGL(pack_weights_xp_kernel, dim3(grid, batch), dim3(256), 0, s, (const float*)src, Cout_src, Cin_src, taps,
+                       (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, (_Float16*)dst, n, fold_n, (long long)s_fold,
+                       (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -724,7 +816,7 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
 int cvvae_pack_weights_tfolds(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t nsp, int64_t s_co,
                               int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream) {
   if (nsp <= 0) return CVVAE_EINVAL;
-  const int es = 2;  // bytes per element (fp16 / bf16)
+  const int es = dtype == CVVAE_F32 ? 4 : 2;  // bytes per source element
   const char* sp = (const char*)src;
   int rc = pack_impl(dtype, src, 1, 0, Cout_src, Cin_src, 3 * nsp, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst, 0, stream, 6 * nsp, 0);
   if (rc) return rc;
@@ -741,7 +833,7 @@ static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t C
                          int32_t dst_taps, int32_t dst_tap0, void* stream) {
   const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16, ntap = tfold ? 4 : 12;
   const long long per_phase = (long long)nb * nchunks * ntap * 64;
-  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, dst_taps) / 2);
+  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, dst_taps * (dtype == CVVAE_F32 ? 3 : 1)) / 2);
   const int grid = (int)((4 * per_phase + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
@@ -750,6 +842,9 @@ static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t C
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_upfold_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout, Cin, nchunks,
                        (_Float16*)dst, per_phase, stride, tfold, dst_taps, dst_tap0);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(pack_upfold_xp_kernel, dim3(grid), dim3(256), 0, s, (const float*)src, Cout, Cin, nchunks, (_Float16*)dst,
+                       per_phase, stride, tfold, dst_taps, dst_tap0);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

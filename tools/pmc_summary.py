@@ -41,7 +41,7 @@ def main(d, flt=None, json_out=None, sq_out=None, steps=0):
     for k, cs in acc.items():
         def mean(c):
             return cs[c][1] / cs[c][0] if c in cs and cs[c][0] else None
-        n = max(v[0] for v in cs.values())
+        n = min(v[0] for v in cs.values() if v[0])  # a counter collected in two passes sees every dispatch twice
         dur = max((v[2] / v[0] for v in cs.values() if v[0]), default=0.0)
         fe, wr = mean("FETCH_SIZE"), mean("WRITE_SIZE")
         hit, miss, ga = mean("TCC_HIT_sum"), mean("TCC_MISS_sum"), mean("GRBM_GUI_ACTIVE")
@@ -76,7 +76,7 @@ def main(d, flt=None, json_out=None, sq_out=None, steps=0):
             mb, ga = mean("SQ_VALU_MFMA_BUSY_CYCLES"), mean("GRBM_GUI_ACTIVE")
             if mb is None or not ga:
                 continue
-            e = {"mfma_busy": round(mb / (ga / 8.0 * 1024.0), 4), "dispatches": max(v[0] for v in cs.values())}
+            e = {"mfma_busy": round(mb / (ga / 8.0 * 1024.0), 4), "dispatches": min(v[0] for v in cs.values() if v[0])}
             wc = mean("SQ_WAVE_CYCLES")
             for c, nm in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any"),
                           ("SQ_WAIT_INST_LDS", "wait_inst_lds")):
