@@ -61,6 +61,7 @@ PROTOTYPES = {
     "cvvae_gn_finalize": (_i32, [_vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_gn_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cvvae_gn_stats": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cvvae_gn_silu_apply": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp]),
     "cvvae_layernorm": (_i32, [_i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "cvvae_softmax_rows": (_i32, [_i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "cvvae_transpose": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp]),

@@ -111,6 +111,8 @@ struct ConvArgs {
   int w_taps;    // taps per k16 record group of the packed weights: NTAPS, or 2*NTAPS with the time-fold slots (KT == 3)
   int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
   int probe_nostore;  // probe builds (-DCVVAE_CONV_PROBE) only: run the store tail without its stores
+  int phase_sync;     // 1: every wave multiplies chunk c, THEN stages chunk c+1 (no wave stages beside another's MFMA stream);
+                      // 0: the two wave groups run opposite phase orders (X: stage -> MFMA, Y: MFMA -> stage)
 };
 
 #ifdef CVVAE_CONV_PROBE
@@ -229,6 +231,9 @@ __device__ __forceinline__ void st8<float>(float* p, const float (&f)[8]) {
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+// GroupNorm affine as ONE fused multiply-add wherever it is evaluated (conv prologue, cvvae_gn_silu_apply): the two forms
+// must round identically
+__device__ __forceinline__ float gn_affine(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
 
 // out-of-range tap handling: replicate = clamp, zero = flag
 __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
@@ -462,7 +467,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             if (PRO_ != 0) {
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
-                float v = f[j] * sc[j] + sh[j];
+                float v = gn_affine(f[j], sc[j], sh[j]);
                 f[j] = (PRO_ == 1) ? silu_f(v) : v;
               }
             }
@@ -483,7 +488,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             unpack8<T>(raw[kk].a, f);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-              float v = f[j] * sc[j] + sh[j];
+              float v = gn_affine(f[j], sc[j], sh[j]);
               f[j] = (PRO_ == 1) ? silu_f(v) : v;
             }
             o = pack8<T>(f);
@@ -568,7 +573,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     const int cur = c & 1;
     const bool more = (c + 1) < p.nchunks;
     CVVAE_PROBE_MARK();
-    if (grp == 0 && more) stage(c + 1, cur ^ 1);
+    const bool stage_first = grp == 0 && !p.phase_sync;
+    if (stage_first && more) stage(c + 1, cur ^ 1);
     CVVAE_PROBE_MARK();
     if constexpr (TFOLD) {
       if (active) {
@@ -674,7 +680,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       }
     }
     CVVAE_PROBE_MARK();
-    if (grp == 1 && more) stage(c + 1, cur ^ 1);
+    if (!stage_first && more) stage(c + 1, cur ^ 1);
     CVVAE_PROBE_MARK();
     __syncthreads();
   }
@@ -693,7 +699,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       for (int c = 0; c < p.nchunks2; ++c) {
         const int cur = c & 1;
         const bool more = (c + 1) < p.nchunks2;
-        if (grp == 0 && more) stage2(c + 1, cur ^ 1);
+        const bool stage_first = grp == 0 && !p.phase_sync;
+        if (stage_first && more) stage2(c + 1, cur ^ 1);
         if (active) {
           const unsigned lb = (unsigned)(cur * G::BUFB);
           v8 wv[KSUB * XPM];
@@ -710,7 +717,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                                                                         ks * (XP ? 64 : 32) + (part == 2 ? 16 : 0)]),
                                      acc[r]);
         }
-        if (grp == 1 && more) stage2(c + 1, cur ^ 1);
+        if (!stage_first && more) stage2(c + 1, cur ^ 1);
         __syncthreads();
       }
     }

@@ -81,27 +81,27 @@
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0) \
   X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0) \
-  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 0,0) \
-  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0) \
-  X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 4, 0,0) \
-  X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 4, 2,0) \
-  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0) \
+  X(1,1,1, 1,1,1, 1,1,128, 1,8,1, 4, 0,0) \
+  X(1,1,1, 1,1,1, 1,1,128, 1,8,1, 4, 2,0) \
+  X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 1, 0,2) \
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
-  X(1,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
+  X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
 // (split in two translation units for the parallel build)
 #define CVVAE_CONV_XP_A(X) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0) \
   X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0) \
-  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2)
+  X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 1, 0,2)
 #define CVVAE_CONV_XP_B(X) \
-  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 0,0) \
-  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0) \
-  X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 4, 0,0) \
-  X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 4, 2,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0) \
+  X(1,1,1, 1,1,1, 1,1,128, 1,8,1, 4, 0,0) \
+  X(1,1,1, 1,1,1, 1,1,128, 1,8,1, 4, 2,0) \
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
-  X(1,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
+  X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
 
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \

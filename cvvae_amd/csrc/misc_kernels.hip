@@ -387,6 +387,32 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// GroupNorm-apply (+ SiLU) pass: the conv prologue's arithmetic (gn_affine + silu_f of conv_kernel.h), once per element
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void gn_silu_apply_kernel(const T* __restrict__ x, long long S, int C, long long ps,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int silu, T* __restrict__ out, long long nvec) {
+  const int cv = C >> 3;
+  for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < nvec; g += (long long)gridDim.x * 256) {
+    const long long pix = g / cv;
+    const int c0 = (int)(g - pix * cv) * 8;
+    const long long row = pix / S;
+    float f[8];
+    ld8<T>(x + pix * ps + c0, f);
+    const float4 a0 = *reinterpret_cast<const float4*>(scale + row * C + c0), a1 = *reinterpret_cast<const float4*>(scale + row * C + c0 + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(shift + row * C + c0), b1 = *reinterpret_cast<const float4*>(shift + row * C + c0 + 4);
+    const float sc[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = gn_affine(f[j], sc[j], sh[j]);
+      f[j] = silu ? silu_f(v) : v;
+    }
+    st8<T>(out + pix * C + c0, f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // LayerNorm over C per pixel: one wave per pixel, C multiple of 8, C <= 64*8*4
 // ---------------------------------------------------------------------------------------------------------
 template <typename T>
@@ -462,18 +488,19 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------------
 // transpose of 2-byte elements, 32x32 LDS tiles
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void transpose16_kernel(const uint16_t* __restrict__ in, int R, int C, long long ld_in,
-                                                          long long bs_in, uint16_t* __restrict__ out, long long ld_out,
+template <typename E>  // E = uint16_t (fp16 / bf16 elements) or uint32_t (float)
+__global__ __launch_bounds__(256) void transpose16_kernel(const E* __restrict__ in, int R, int C, long long ld_in,
+                                                          long long bs_in, E* __restrict__ out, long long ld_out,
                                                           long long bs_out) {
-  __shared__ uint16_t t[32][33];
-  const uint16_t* ib = in + (long long)blockIdx.z * bs_in;
-  uint16_t* ob = out + (long long)blockIdx.z * bs_out;
+  __shared__ E t[32][33];
+  const E* ib = in + (long long)blockIdx.z * bs_in;
+  E* ob = out + (long long)blockIdx.z * bs_out;
   const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int r = r0 + ty + k * 8, c = c0 + tx;
-    t[ty + k * 8][tx] = (r < R && c < C) ? ib[(long long)r * ld_in + c] : (uint16_t)0;
+    t[ty + k * 8][tx] = (r < R && c < C) ? ib[(long long)r * ld_in + c] : (E)0;
   }
   __syncthreads();
 #pragma unroll
@@ -663,7 +690,7 @@ __global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const TS* __restric
       const int c = c0 + j;
       f[j] = (c < C) ? (float)in[(b * C + c) * THW + s] : 0.f;
     }
-    *reinterpret_cast<uint4*>(out + pix * Cpad + c0) = pack8<TD>(f);
+    st8<TD>(out + pix * Cpad + c0, f);
   }
 }
 
@@ -891,10 +918,34 @@ int cvvae_gn_stats(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(gn_partial_kernel<_Float16>, dim3(nsplit, rows), dim3(256), 0, s, (const _Float16*)x, (long long)S, C,
                        (long long)pix_stride, groups, nsplit, (float*)workspace);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(gn_partial_kernel<float>, dim3(nsplit, rows), dim3(256), 0, s, (const float*)x, (long long)S, C,
+                       (long long)pix_stride, groups, nsplit, (float*)workspace);
   else
     return CVVAE_EINVAL;
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(rows), dim3(256), 0, s, (const float*)workspace, nsplit, groups, C, eps, gamma,
                      beta, scale, shift);
+  CHECK_LAUNCH();
+}
+
+int cvvae_gn_silu_apply(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_t C, int64_t pix_stride,
+                        const float* scale, const float* shift, int32_t silu, void* out, void* stream) {
+  if (!x || !scale || !shift || !out || rows <= 0 || S <= 0 || C <= 0 || C % 8 || pix_stride < C || pix_stride % 8) return CVVAE_EINVAL;
+  const long long nvec = (long long)rows * S * (C / 8);
+  long long blocks = (nvec + 255) / 256;
+  if (blocks > 256LL * 64) blocks = 256LL * 64;  // grid-stride beyond 64 blocks per CU
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(gn_silu_apply_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)x, (long long)S, C,
+                       (long long)pix_stride, scale, shift, silu, (__bf16*)out, nvec);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(gn_silu_apply_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16*)x, (long long)S, C,
+                       (long long)pix_stride, scale, shift, silu, (_Float16*)out, nvec);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(gn_silu_apply_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)x, (long long)S, C,
+                       (long long)pix_stride, scale, shift, silu, (float*)out, nvec);
+  else
+    return CVVAE_EINVAL;
   CHECK_LAUNCH();
 }
 
@@ -918,6 +969,9 @@ int cvvae_layernorm(int32_t dtype, const void* x, int64_t P, int32_t C, float ep
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(layernorm_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)x, (long long)P, C, eps,
                        gamma, beta, (_Float16*)out);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)x, (long long)P, C, eps,
+                       gamma, beta, (float*)out);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -933,6 +987,9 @@ int cvvae_softmax_rows(int32_t dtype, const float* sc, int64_t rows, int32_t n_v
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(softmax_rows_kernel<_Float16>, dim3((unsigned)rows), dim3(256), 0, s, sc, n_valid, (long long)ld_s,
                        (_Float16*)p, (long long)ld_p);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(softmax_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, sc, n_valid, (long long)ld_s,
+                       (float*)p, (long long)ld_p);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -941,10 +998,16 @@ int cvvae_softmax_rows(int32_t dtype, const float* sc, int64_t rows, int32_t n_v
 int cvvae_transpose(int32_t dtype, const void* in, int32_t batch, int32_t R, int32_t C, int64_t ld_in, int64_t bs_in,
                     void* out, int64_t ld_out, int64_t bs_out, void* stream) {
   if (!in || !out || batch <= 0 || R <= 0 || C <= 0) return CVVAE_EINVAL;
-  if (dtype != CVVAE_BF16 && dtype != CVVAE_F16) return CVVAE_EINVAL;
-  hipLaunchKernelGGL(transpose16_kernel, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
-                     (const uint16_t*)in, R, C, (long long)ld_in, (long long)bs_in, (uint16_t*)out, (long long)ld_out,
-                     (long long)bs_out);
+  if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(transpose16_kernel<uint32_t>, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const uint32_t*)in, R, C, (long long)ld_in, (long long)bs_in, (uint32_t*)out, (long long)ld_out,
+                       (long long)bs_out);
+  else if (dtype == CVVAE_BF16 || dtype == CVVAE_F16)
+    hipLaunchKernelGGL(transpose16_kernel<uint16_t>, dim3((C + 31) / 32, (R + 31) / 32, batch), dim3(256), 0, (hipStream_t)stream,
+                       (const uint16_t*)in, R, C, (long long)ld_in, (long long)bs_in, (uint16_t*)out, (long long)ld_out,
+                       (long long)bs_out);
+  else
+    return CVVAE_EINVAL;
   CHECK_LAUNCH();
 }
 
@@ -963,6 +1026,9 @@ int cvvae_temporal_attention(int32_t dtype, const void* q, const void* k, const 
     else if (dtype == CVVAE_F16)
       hipLaunchKernelGGL(temporal_attn_general_kernel<_Float16>, dim3(gridg), dim3(256), 0, s, (const _Float16*)q,
                          (const _Float16*)k, (const _Float16*)v, P, T, (long long)S, C, scale, (_Float16*)out);
+    else if (dtype == CVVAE_F32)
+      hipLaunchKernelGGL(temporal_attn_general_kernel<float>, dim3(gridg), dim3(256), 0, s, (const float*)q,
+                         (const float*)k, (const float*)v, P, T, (long long)S, C, scale, (float*)out);
     else
       return CVVAE_EINVAL;
     CHECK_LAUNCH();
@@ -974,6 +1040,9 @@ int cvvae_temporal_attention(int32_t dtype, const void* q, const void* k, const 
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(temporal_attn_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)q, (const _Float16*)k,
                        (const _Float16*)v, P, T, (long long)S, C, scale, (_Float16*)out);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(temporal_attn_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)q, (const float*)k,
+                       (const float*)v, P, T, (long long)S, C, scale, (float*)out);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -997,6 +1066,11 @@ int cvvae_ncdhw_to_ndhwc(int32_t src_dtype, int32_t dst_dtype, const void* in, i
     else if (src_dtype == CVVAE_F16) L(_Float16, _Float16);
     else if (src_dtype == 2) L(float, _Float16);
     else return CVVAE_EINVAL;
+  } else if (dst_dtype == CVVAE_F32) {
+    if (src_dtype == CVVAE_BF16) L(__bf16, float);
+    else if (src_dtype == CVVAE_F16) L(_Float16, float);
+    else if (src_dtype == 2) L(float, float);
+    else return CVVAE_EINVAL;
   } else
     return CVVAE_EINVAL;
 #undef L
@@ -1015,6 +1089,9 @@ int cvvae_ndhwc_to_ncdhw(int32_t dtype, const void* in, int32_t B, int32_t C, in
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, C, THW,
                        (long long)pix_stride, npix, (_Float16*)out);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(ndhwc_to_ncdhw_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, C, THW,
+                       (long long)pix_stride, npix, (float*)out);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -1029,6 +1106,9 @@ int cvvae_frames_u8_to_ndhwc(int32_t dtype, const uint8_t* frames, int64_t npix,
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(frames_u8_to_ndhwc_kernel<_Float16>, dim3(grid), dim3(256), 0, s, frames, (long long)npix, Cpad,
                        (_Float16*)out);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(frames_u8_to_ndhwc_kernel<float>, dim3(grid), dim3(256), 0, s, frames, (long long)npix, Cpad,
+                       (float*)out);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -1042,6 +1122,9 @@ int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t
     hipLaunchKernelGGL(ncdhw_to_frames_u8_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)in, (long long)thw, frames);
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(ncdhw_to_frames_u8_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, (long long)thw,
+                       frames);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(ncdhw_to_frames_u8_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)in, (long long)thw,
                        frames);
   else
     return CVVAE_EINVAL;
@@ -1061,6 +1144,9 @@ int cvvae_blend(int32_t dtype, const void* a, int32_t Ha, int32_t Wa, void* b, i
                        (long long)rows, overlap, axis);
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(blend_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)a, Ha, Wa, (_Float16*)b, Hb, Wb,
+                       (long long)rows, overlap, axis);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(blend_kernel<float>, dim3(grid), dim3(256), 0, s, (const float*)a, Ha, Wa, (float*)b, Hb, Wb,
                        (long long)rows, overlap, axis);
   else
     return CVVAE_EINVAL;

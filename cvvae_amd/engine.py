@@ -30,12 +30,14 @@ class WeightCache:
     def _key(self, *ps):
         return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps if p is not None)
 
-    def conv(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None, time_folds: bool = False) -> ops.PackedConv:
-        """time_folds (k = (3, kH, kW)): packed with the summed time slots for boundary frames (ops.pack_weight_tfolds)"""
+    def conv(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None, time_folds: bool = False,
+             wscale: Optional[float] = None) -> ops.PackedConv:
+        """time_folds (k = (3, kH, kW)): packed with the summed time slots for boundary frames (ops.pack_weight_tfolds);
+        wscale (fp32 models): pack with this power-of-two scale (a fused shortcut shares its conv's accumulators)"""
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        tag = pre + "#tf" if time_folds else pre
+        tag = pre + "#tf" if time_folds else (pre if wscale is None else f"{pre}#ws{wscale}")
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -45,7 +47,7 @@ class WeightCache:
         if time_folds:
             pw = ops.pack_weight_tfolds(w.detach().reshape(co, ci, *k), b.detach(), cin_pad=cin_pad)
         else:
-            pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad)
+            pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad, wscale=wscale)
         self._c[tag] = (key, pw)
         return pw
 
@@ -139,14 +141,44 @@ def fuse_shortcut() -> bool:
     return os.environ.get("CVVAE_FUSE_SHORTCUT", "1") != "0"
 
 
+def prepass(x: torch.Tensor, k: Tuple[int, int, int], cout: int) -> bool:
+    """GroupNorm+SiLU in front of a conv: fused into the conv's staging (prologue), or applied ONCE by cvvae_gn_silu_apply and
+    the conv run without prologue (bit-identical results).  The fused form evaluates the activation for every halo copy and every
+    N-tile of a pixel, and on gfx950 that VALU work adds to the MFMA time instead of hiding under it; the pass costs one read +
+    write of the activation.  CVVAE_PREPASS: "0" never, "1" always, "k333" every 3x3x3 conv, default = the measured policy."""
+    mode = os.environ.get("CVVAE_PREPASS", "auto")
+    if mode == "0":
+        return False
+    if mode == "1":
+        return True
+    if mode == "k333":
+        return k[0] == 3
+    return PREPASS_AUTO(x, k, cout)
+
+
+def PREPASS_AUTO(x, k, cout) -> bool:  # measured policy (DESIGN.md section 3.1); round-2 default: fused everywhere
+    return False
+
+
+def _activated(x: torch.Tensor, kw: dict, k: Tuple[int, int, int], cout: int) -> Tuple[torch.Tensor, dict]:
+    """(input, conv kwargs) with the GN+SiLU prologue either kept fused or applied by the pass (see prepass)"""
+    if kw.get("prologue") == L.PRO_GN_SILU and not kw.get("gn_per_frame") and prepass(x, k, cout):
+        return ops.gn_silu_apply(x, kw["gn"]), dict(kw, prologue=L.PRO_NONE, gn=None)
+    return x, kw
+
+
 def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
     """conv2 (per-frame 3x3 over GN+SiLU(h), zero pad) + shortcut(x) + add -- vae_blocks3d_sd3.py:559-567, vae_models.py:404-410."""
     pw2 = wc.conv(pre + ".conv2", (1, 3, 3))
     kw = dict(pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2, gn_out=G32 if want_stats else 0)
+    if prepass(h, (1, 3, 3), pw2.cout):
+        h = ops.gn_silu_apply(h, g2)
+        kw.update(prologue=L.PRO_NONE, gn=None)
     if not wc.has(sc_name + ".weight"):
         y = ops.conv(h, pw2, residual=x, **kw)
-    elif fuse_shortcut():
-        y = ops.conv(h, pw2, shortcut=(x, wc.conv(sc_name, (1, 1, 1))), bias=wc.bias_sum(pre + ".conv2", sc_name), **kw)
+    elif fuse_shortcut():  # (fp32 models: the shortcut weights are packed with conv2's power-of-two scale -- one accumulator set)
+        pws = wc.conv(sc_name, (1, 1, 1), wscale=pw2.wscale if x.dtype == torch.float32 else None)
+        y = ops.conv(h, pw2, shortcut=(x, pws), bias=wc.bias_sum(pre + ".conv2", sc_name), **kw)
     else:
         y = ops.conv(h, pw2, residual=conv1x1(wc, x, sc_name), **kw)
     return y if want_stats else (y, None)
@@ -173,10 +205,12 @@ def conv3(wc: WeightCache, x: torch.Tensor, pre: str, *, pad, pad_mode_t, pad_mo
     time padding makes the three taps coincide it runs as the temporally folded 1x3x3 conv (fold_t1)."""
     if x.shape[1] == 1 and fold_t1() and pad[0][0] + pad[0][1] == 2:
         pw = wc.conv_t1(pre, "sum" if pad_mode_t == REP else "center", cin_pad=cin_pad)
+        x, kw = _activated(x, kw, (1, 3, 3), pw.cout)
         return ops.conv(x, pw, stride=(1, stride[1], stride[2]), pad=((0, 0), pad[1], pad[2]), pad_mode_hw=pad_mode_hw, **kw)
     tf = pad_mode_t == REP and fold_time()
-    return ops.conv(x, wc.conv(pre, (3, 3, 3), cin_pad=cin_pad, time_folds=tf), stride=stride, pad=pad, pad_mode_t=pad_mode_t,
-                    pad_mode_hw=pad_mode_hw, **kw)
+    pw = wc.conv(pre, (3, 3, 3), cin_pad=cin_pad, time_folds=tf)
+    x, kw = _activated(x, kw, (3, 3, 3), pw.cout)
+    return ops.conv(x, pw, stride=stride, pad=pad, pad_mode_t=pad_mode_t, pad_mode_hw=pad_mode_hw, **kw)
 
 
 def upsample_conv(wc: WeightCache, h: torch.Tensor, pre: str, pad, mode_t, mode_hw, up_time: bool):

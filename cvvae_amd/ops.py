@@ -12,11 +12,32 @@ from . import _lib as L
 _DT = {torch.float16: L.F16, torch.bfloat16: L.BF16, torch.float32: L.F32}
 
 
+# fp32 models (the reference's default when from_pretrained gets no torch_dtype) run in SPLIT PRECISION: float tensors in HBM,
+# every product as three fp16 MFMAs (include/cvvae.h CVVAE_F32; csrc/conv_kernel.h XP): ~1e-6 relative error, 3x the MFMA work.
+SUPPORTS_FP32 = True
+
+
 def _dt(t: torch.dtype) -> int:
-    if t not in (torch.float16, torch.bfloat16):
-        raise TypeError(f"the MI355X path computes on fp16/bf16 MFMA; got {t}. Load the model with torch_dtype="
-                        "torch.float16 or torch.bfloat16 (as cvvae_inference_video.py does).")
+    if t not in _DT:
+        raise TypeError(f"the MI355X path runs fp16 / bf16 models on MFMA and fp32 models in split precision; got {t}")
     return _DT[t]
+
+
+def _xpm(t: torch.dtype) -> int:
+    """packed records per (k16, tap): 3 in the split-precision layout of fp32 weights"""
+    return 3 if t == torch.float32 else 1
+
+
+def _wscale(w: torch.Tensor) -> float:
+    """fp32 weights are packed as fp16 hi + lo of w * 2^k (k chosen so that max|w| * 2^k is in [512, 1024): the lo parts stay in
+    fp16's normal range and sums of up to 27 folded taps cannot overflow); the conv's alpha divides the accumulators by 2^k."""
+    if w.dtype != torch.float32:
+        return 1.0
+    m = float(w.detach().abs().max())
+    if not (m > 0.0) or m != m or m == float("inf"):
+        return 1.0
+    import math
+    return float(2.0 ** (9 - math.floor(math.log2(m)) ))
 
 
 def _stream(t: torch.Tensor) -> int:
@@ -56,11 +77,13 @@ class PackedConv:
     batch_stride: int = 0    # bytes between the packed weights of consecutive batch items (pack_weight_batched)
     alg_taps: int = 0        # taps of the REFERENCE op when the packed weights are a folded form (0: kT*kH*kW)
     time_folds: bool = False  # packed with the time-fold slots (pack_weight_tfolds / pack_weight_upfold(time_folds=True))
+    wscale: float = 1.0       # fp32 (split-precision) weights were packed as w * wscale (a power of two); conv() undoes it
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
                 strides: Optional[Tuple[int, int, int]] = None, cout: Optional[int] = None, cin: Optional[int] = None,
-                out: Optional[torch.Tensor] = None, fold: Tuple[int, int] = (1, 0), offset: int = 0) -> PackedConv:
+                out: Optional[torch.Tensor] = None, fold: Tuple[int, int] = (1, 0), offset: int = 0,
+                wscale: Optional[float] = None) -> PackedConv:
     """Pack a conv / linear weight ([Cout, Cin, *k] contiguous, or any strided view described by `strides` =
     (s_co, s_ci, s_tap) in elements) into MFMA fragment order for cvvae_conv_fwd."""
     lib = L.load()
@@ -75,10 +98,14 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
         cout_, cin_ = cout, cin
     ck = kchunk(k)
     cin_pad = round_up(cin_, ck) if cin_pad is None else cin_pad
-    nbytes = lib.cvvae_packed_weight_bytes(cout_, cin_pad, taps)
+    nbytes = lib.cvvae_packed_weight_bytes(cout_, cin_pad, taps * _xpm(w.dtype))
     if out is None:
         out = torch.zeros(nbytes, dtype=torch.uint8, device=w.device)
     assert out.numel() * out.element_size() >= nbytes
+    # wscale (fp32 weights only): force the power-of-two pack scale, e.g. the scale of the conv a fused shortcut accumulates with
+    ws = _wscale(w) if (wscale is None or w.dtype != torch.float32) else float(wscale)
+    if ws != 1.0:
+        w = w * ws
     # fold = (n, stride): every packed element is the sum of n source elements `stride` apart (coinciding taps);
     # offset: element offset of the first source element (e.g. the centre time tap)
     L.check(lib.cvvae_pack_weights_fold(dt, w.data_ptr() + offset * w.element_size(), cout_, cin_, taps, strides[0],
@@ -87,7 +114,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_)
+    return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_, wscale=ws)
 
 
 @dataclass
@@ -110,7 +137,7 @@ def pack_weight_batched(w: torch.Tensor, k: Tuple[int, int, int], cin_pad: int, 
     assert w.is_contiguous()
     batch = w.shape[0]
     taps = k[0] * k[1] * k[2]
-    per = round_up(lib.cvvae_packed_weight_bytes(cout, cin_pad, taps), 16)
+    per = round_up(lib.cvvae_packed_weight_bytes(cout, cin_pad, taps * _xpm(w.dtype)), 16)
     out = torch.zeros((batch, per), dtype=torch.uint8, device=w.device)
     L.check(lib.cvvae_pack_weights_batched(dt, w.data_ptr(), batch, w[0].numel(), cout, cin, taps, strides[0], strides[1],
                                            strides[2], cin_pad, kchunk(k), out.data_ptr(), per, _stream(w)),
@@ -132,13 +159,16 @@ def pack_weight_tfolds(w: torch.Tensor, bias: Optional[torch.Tensor], cin_pad: O
     k = (3, kh, kw)
     ck = kchunk(k)
     cin_pad = round_up(ci, ck) if cin_pad is None else cin_pad
-    out = torch.zeros(lib.cvvae_packed_weight_bytes(co, cin_pad, 6 * nsp), dtype=torch.uint8, device=w.device)
+    out = torch.zeros(lib.cvvae_packed_weight_bytes(co, cin_pad, 6 * nsp * _xpm(w.dtype)), dtype=torch.uint8, device=w.device)
+    ws = _wscale(w)
+    if ws != 1.0:
+        w = w * ws
     L.check(lib.cvvae_pack_weights_tfolds(dt, w.data_ptr(), co, ci, nsp, ci * 3 * nsp, 3 * nsp, 1, cin_pad, ck, out.data_ptr(),
                                           _stream(w)), "cvvae_pack_weights_tfolds")
     b = torch.zeros(round_up(co, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:co] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, co, cin_pad, k, ci, time_folds=True)
+    return PackedConv(out, b, co, cin_pad, k, ci, time_folds=True, wscale=ws)
 
 
 def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin_pad: Optional[int] = None) -> PackedConv:
@@ -165,8 +195,11 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int
     assert w.numel() == cout_ * cin_ * 27
     cin_pad = round_up(cin_, 32)
     assert not (tfold and time_folds)
-    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, 24 if time_folds else (4 if tfold else 12))
+    per = lib.cvvae_packed_weight_bytes(cout_, cin_pad, (24 if time_folds else (4 if tfold else 12)) * _xpm(w.dtype))
     out = torch.zeros(4 * per, dtype=torch.uint8, device=w.device)
+    ws = _wscale(w)
+    if ws != 1.0:
+        w = w * ws
     if time_folds:  # 12 taps per phase + the time-fold slots (replicate time padding)
         L.check(lib.cvvae_pack_weights_upfold_tfolds(dt, w.data_ptr(), cout_, cin_, cin_pad, out.data_ptr(), _stream(w)),
                 "cvvae_pack_weights_upfold_tfolds")
@@ -177,7 +210,7 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
     return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True, alg_taps=27,
-                      time_folds=time_folds)
+                      time_folds=time_folds, wscale=ws)
 
 
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
@@ -218,18 +251,21 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.To, d.Ho, d.Wo, d.Cout = To, Ho, Wo, cout
     d.out_mode = out_mode
     d.out_f32 = 1 if out_f32 else 0
-    d.alpha = alpha
+    d.alpha = alpha / pw.wscale
     d.w_batch_stride = pw.batch_stride
     d.w_time_folds = 1 if pw.time_folds else 0
     if shortcut is not None:
         x2, pw2 = shortcut
         assert residual is None and x2.shape[:4] == x.shape[:4] and x2.is_contiguous() and x2.dtype == x.dtype
         assert pw2.k == (1, 1, 1) and pw2.cout == cout and x2.shape[-1] >= pw2.cin
+        if pw2.wscale != pw.wscale:
+            raise ValueError("fused shortcut on an fp32 model: both weights accumulate in one register set, so they must be packed "
+                             "with the same power-of-two scale (pack_weight(..., wscale=pw.wscale))")
         d.sc_Cin, d.sc_in_pix_stride = pw2.cin, x2.shape[-1]
     bias_t = pw.bias if bias is None else bias
     assert bias_t.dtype == torch.float32 and bias_t.numel() >= round_up(cout, 32)
     assert pw.batch_stride == 0 or pw.w.shape[0] == B, "batched weights: one packed set per batch item of the input"
-    odt = torch.float32 if out_f32 else x.dtype
+    odt = torch.float32 if out_f32 else x.dtype  # fp32 models: every tensor is float
     if out_mode == L.OUT_NCDHW:
         shape = (B, cout, To, Ho, Wo)
         d.out_pix_stride = 0
@@ -320,6 +356,22 @@ def gn_stats(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: floa
     L.check(lib.cvvae_gn_stats(_dt(x.dtype), x.data_ptr(), rows, S, C, C, groups, eps, gamma.data_ptr(), beta.data_ptr(),
                                scale.data_ptr(), shift.data_ptr(), ws.data_ptr(), _stream(x)), "cvvae_gn_stats")
     return scale, shift
+
+
+def gn_silu_apply(x: torch.Tensor, gn: Tuple[torch.Tensor, torch.Tensor], silu: bool = True, per_frame: bool = False) -> torch.Tensor:
+    """act(x * scale + shift) once per element (cvvae_gn_silu_apply): x [B,T,H,W,C], (scale, shift) fp32 tables [rows, C] with
+    rows = B (5-D GroupNorm) or B*T (per frame).  The values equal what conv(..., prologue=PRO_GN_SILU / PRO_GN, gn=gn) stages."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous()
+    B, T, H, W, C = x.shape
+    rows, S = (B * T, H * W) if per_frame else (B, T * H * W)
+    sc, sh = gn
+    assert sc.dtype == torch.float32 and tuple(sc.shape) == (rows, C) and sc.is_contiguous() and sh.is_contiguous()
+    out = torch.empty_like(x)
+    L.check(lib.cvvae_gn_silu_apply(_dt(x.dtype), x.data_ptr(), rows, S, C, C, sc.data_ptr(), sh.data_ptr(), 1 if silu else 0,
+                                    out.data_ptr(), _stream(x)), "cvvae_gn_silu_apply")
+    return out
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> torch.Tensor:

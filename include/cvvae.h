@@ -190,6 +190,18 @@ int cvvae_gn_stats(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_
                    float eps, const float* gamma, const float* beta, float* scale, float* shift, void* workspace,
                    void* stream);
 
+/*
+ * GroupNorm-apply (+ SiLU) as its own pass: out[row][s][c] = act(x[row][s][c] * scale[row][c] + shift[row][c]), act = SiLU
+ * (silu != 0) or identity, fp32 arithmetic, one rounding to the storage dtype -- the very values the conv prologue
+ * (CVVAE_PRO_GN_SILU / CVVAE_PRO_GN) stages, so a conv over `out` without prologue is bit-identical to the fused form.
+ * The fused prologue re-evaluates the activation for every halo copy and every N-tile of a pixel (4-8x on the 256/512-channel
+ * 3x3x3 layers) and VALU work does not overlap the MFMA stream on gfx950; where that costs more than one read + write of the
+ * activation, the host applies GroupNorm+SiLU once with this entry (engine.py prepass policy).
+ * Replaces aten::native_group_norm's normalisation + aten::silu (models/vae_blocks3d_sd3.py:523-524,547-548).
+ */
+int cvvae_gn_silu_apply(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_t C, int64_t pix_stride,
+                        const float* scale, const float* shift, int32_t silu, void* out, void* stream);
+
 /* LayerNorm over C for every pixel (vae3d temporal attention, models/vae_models.py:571,575). in/out [P][C]. */
 int cvvae_layernorm(int32_t dtype, const void* x, int64_t P, int32_t C, float eps, const float* gamma, const float* beta,
                     void* out, void* stream);

@@ -92,10 +92,16 @@ def main_big(only=None):
         t2 = time.time()
         wsum = float(sum(v.double().abs().sum() for v in sd.values()))
         r64 = recon.double()
+        mnp = moments.numpy().astype(np.float32)
+        zc = mnp.shape[1] // 2
+        # fixtures stay small: above 4 MB the posterior mean is kept in full and the log-variance at stride 2 over H and W
+        mom_kw = dict(moments=mnp) if mnp.nbytes <= (4 << 20) else dict(
+            moments_mean=mnp[:, :zc].copy(), moments_logvar_sub=mnp[:, zc:, :, ::2, ::2].copy(),
+            moments_shape=np.asarray(mnp.shape, dtype=np.int64))
         np.savez_compressed(
             os.path.join(out_dir, name + ".npz"),
-            moments=moments.numpy().astype(np.float32),
             recon_sub=recon_subsample(recon, s).numpy().astype(np.float32),
+            **mom_kw,
             recon_shape=np.asarray(recon.shape, dtype=np.int64),
             recon_stride=np.int64(s),
             recon_mean=np.float64(r64.mean()), recon_sqmean=np.float64((r64 * r64).mean()),

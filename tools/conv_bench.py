@@ -51,6 +51,12 @@ CASES = {
 
 def setenv(f):
     """f = "FORCE" or "FORCE@ORDER" (CVVAE_CONV_FORCE / CVVAE_CONV_ORDER tuning knobs of libcvvae_hip.so)"""
+    f, _, envs = f.partition("!")  # "...!NAME=VAL,NAME=VAL": extra library knobs for this variant (reset otherwise)
+    for k in ("CVVAE_CONV_PHASE_SYNC",):
+        os.environ.pop(k, None)
+    for kv in filter(None, envs.split(",")):
+        k, _, v = kv.partition("=")
+        os.environ[k] = v
     force, _, order = f.partition("@")
     os.environ["CVVAE_CONV_FORCE"] = force
     if order:
@@ -101,7 +107,7 @@ def main():
         for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
             for f in forces_c:
                 pw = pws[f]
-                setenv(f.replace("+tf", ""))
+                setenv(f.replace("+tf", ""))  # (labels: FORCE[@ORDER][!ENV=VAL,...][+tf])
                 ops.PROFILE = lambda d, pw_, launch, f=f: (kname.__setitem__(f, ops.conv_kernel_name(d)), launch())
                 y = ops.conv(x, pw, **kw)
                 if isinstance(y, tuple):

@@ -33,6 +33,12 @@ static const int CIN = 512, COUT = 512, TT_ = 9, HH = 128, WW = 128, PT = 0;
 #elif CFG == 7 // c2d256: ResnetBlock conv2 at 9x256^2
 #define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 0;
+#elif CFG == 8 // c2d128, the 16-row tile the library picks at 17x512^2
+#define INST 1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 1,0
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 0;
+#elif CFG == 9 // c2d128, four-wave instance (two workgroups per CU)
+#define INST 1,3,3, 1,1,1, 1,8,32, 1,4,1, 2, 1,0
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 0;
 #elif CFG == 5 // enc256 without prologue (pro0) for comparison
 #define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
