@@ -77,6 +77,11 @@ def main(d, flt=None, json_out=None, sq_out=None, steps=0):
             if mb is None or not ga:
                 continue
             e = {"mfma_busy": round(mb / (ga / 8.0 * 1024.0), 4), "dispatches": min(v[0] for v in cs.values() if v[0])}
+            durg = cs["GRBM_GUI_ACTIVE"][2] / cs["GRBM_GUI_ACTIVE"][0]  # mean duration (us) of the dispatches of that pass
+            if durg:
+                # shader clock during the dispatch; mfma_busy x clock / 2.4 GHz = executed share of the NOMINAL 2.5 PFLOP/s peak
+                e["clk_ghz"] = round(ga / 8.0 / (durg * 1e3), 3)
+                e["mfma_busy_x_clk_over_nominal"] = round(e["mfma_busy"] * e["clk_ghz"] / 2.4, 4)
             wc = mean("SQ_WAVE_CYCLES")
             for c, nm in (("SQ_WAIT_ANY", "wait_any"), ("SQ_WAIT_INST_ANY", "wait_inst_any"), ("SQ_ACTIVE_INST_ANY", "active_inst_any"),
                           ("SQ_WAIT_INST_LDS", "wait_inst_lds")):
