@@ -30,6 +30,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <type_traits>
 
@@ -228,6 +229,20 @@ template <>
 __device__ __forceinline__ void st8<float>(float* p, const float (&f)[8]) {
   reinterpret_cast<float4*>(p)[0] = make_float4(f[0], f[1], f[2], f[3]);
   reinterpret_cast<float4*>(p)[1] = make_float4(f[4], f[5], f[6], f[7]);
+}
+
+// sum over the 32 lanes of each half-wave, delivered in lanes 31 and 63 (other lanes hold partial sums): four DPP row
+// shifts (zero fill) give lane 15 of every 16-lane row its row sum, row_bcast:15 adds it into the next row (rows 1 and 3)
+__device__ __forceinline__ float half_wave_sum(float x) {
+  auto shr = [](float v, auto ctrl) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), decltype(ctrl)::value, 0xf, 0xf, true));
+  };
+  x += shr(x, std::integral_constant<int, 0x111>{});  // row_shr:1
+  x += shr(x, std::integral_constant<int, 0x112>{});  // row_shr:2
+  x += shr(x, std::integral_constant<int, 0x114>{});  // row_shr:4
+  x += shr(x, std::integral_constant<int, 0x118>{});  // row_shr:8
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x142, 0xa, 0xf, false));  // row_bcast:15
+  return x;
 }
 
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
@@ -937,8 +952,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
             unpack8<T>(pq, rv);
             if (!gk_set) {  // first stored fragment of the tile (wave-uniform): the shifts of both channel pairs
-              gk[pr][0] = __shfl(rv[0], lane_e & 32);
-              gk[pr][1] = __shfl(rv[4], lane_e & 32);
+              // (v_readlane, not a ds_bpermute shuffle: the value must be THE SAME in every lane of the half-wave)
+              const float k0l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), 0));
+              const float k0h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), 32));
+              const float k1l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), 0));
+              const float k1h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), 32));
+              gk[pr][0] = (lane_e & 32) ? k0h : k0l;
+              gk[pr][1] = (lane_e & 32) ? k1h : k1l;
               gk_set = pr == 1;
             }
             gc[pr] += 1.f;
@@ -1014,11 +1034,15 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
               if (XP && p.gnp) {  // fused GroupNorm statistics of the fp32 values stored (shifted sums, as below)
                 if (!((gkm >> pr) & 1)) {
-                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);
-                  const unsigned hm = (lane_e & 32) ? (unsigned)(mk >> 32) : (unsigned)mk;
-                  const int src = (lane_e & 32) + __builtin_ctz(hm);
-                  gk[pr][0] = __shfl(v[0], src);
-                  gk[pr][1] = __shfl(v[4], src);
+                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);  // lanes storing this run (wave-uniform mask)
+                  const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+                  const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
+                  const float k0l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), slo));
+                  const float k0h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), shi));
+                  const float k1l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[4]), slo));
+                  const float k1h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[4]), shi));
+                  gk[pr][0] = (lane_e & 32) ? k0h : k0l;
+                  gk[pr][1] = (lane_e & 32) ? k1h : k1l;
                   gkm |= 1u << pr;
                 }
                 gc[pr] += 1.f;
@@ -1050,11 +1074,15 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                 asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
                 unpack8<T>(pq, rv);
                 if (!((gkm >> pr) & 1)) {  // shifts: the values of the first storing lane of my half-wave (per-lane code here)
-                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);
-                  const unsigned hm = (lane_e & 32) ? (unsigned)(mk >> 32) : (unsigned)mk;
-                  const int src = (lane_e & 32) + __builtin_ctz(hm);
-                  gk[pr][0] = __shfl(rv[0], src);
-                  gk[pr][1] = __shfl(rv[4], src);
+                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);  // lanes storing this run (wave-uniform mask)
+                  const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+                  const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
+                  const float k0l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), slo));
+                  const float k0h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), shi));
+                  const float k1l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), slo));
+                  const float k1h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), shi));
+                  gk[pr][0] = (lane_e & 32) ? k0h : k0l;
+                  gk[pr][1] = (lane_e & 32) ? k1h : k1l;
                   gkm |= 1u << pr;
                 }
                 gc[pr] += 1.f;
@@ -1078,21 +1106,19 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     }
   }
   if (p.gnp) {
-    // wave reduction over the 32 pixels of each half-wave (the two halves hold different channels), then lanes 0 and 32
+    // wave reduction over the 32 pixels of each half-wave (the two halves hold different channels), then lanes 31 and 63
     // write one (n, mean, M2) record per 4-channel slot: record index inside its group = the slot's position in the group
+    // (DPP row shifts + row broadcast inside the VALU -- no LDS-pipe shuffles: lanes 31 / 63 end with the sums of their half)
 #pragma unroll
-    for (int off = 16; off; off >>= 1) {
+    for (int pr = 0; pr < 2; ++pr) {
+      gc[pr] = half_wave_sum(gc[pr]);
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        gc[pr] += __shfl_xor(gc[pr], off);
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-          gs[pr][q] += __shfl_xor(gs[pr][q], off);
-          gq[pr][q] += __shfl_xor(gq[pr][q], off);
-        }
+      for (int q = 0; q < 2; ++q) {
+        gs[pr][q] = half_wave_sum(gs[pr][q]);
+        gq[pr][q] = half_wave_sum(gq[pr][q]);
       }
     }
-    if ((lane_e & 31) == 0) {
+    if ((lane_e & 31) == 31) {
       const int E = 1 << (p.gn_sh - 2);  // 4-channel slots per group
       const int part = ((UPS == 2 ? tile_in_b * 4 + phase : tile_in_b) * WM + wave_m) * KG + kgrp;
 #pragma unroll
@@ -1127,8 +1153,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
           int PRO, int UPS, bool XP = false>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
+  // (debug aid: CVVAE_NW4_SOLO=1 pads a 4-wave launch's LDS so that only ONE workgroup fits a CU)
+  static const bool solo = getenv("CVVAE_NW4_SOLO") && atoi(getenv("CVVAE_NW4_SOLO"));
   hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XP>), dim3(grid),
-                     dim3(WM * WN * KG * 64), 0, s, a);
+                     dim3(WM * WN * KG * 64), (WM * WN * KG == 4 && solo) ? 48 * 1024 : 0, s, a);
   return (int)hipGetLastError();
 }
 

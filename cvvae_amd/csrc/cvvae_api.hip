@@ -88,13 +88,14 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
     cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
     if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)
-    // four-wave instances (two workgroups per CU): their halo / weight terms above are those of a half-size tile, but the second
-    // resident workgroup hides the staging and the tails.  Measured (profiles/r2_ab_4wave_*.log): per-frame 3x3 at 128 channels
-    // with residual + statistics 1.71 -> 1.62 ms (+6 %); 3x3x3 at 128 channels 3.38 -> 3.55 ms (-4 %: its 8-wave two-frame tile
-    // already sits at the chip's power frontier).  CVVAE_CONV_NW4 overrides both factors (tuning aid).
+    // four-wave instances (two workgroups per CU): NOT selected by default.  Measured (profiles/r2_ab_4wave_*.log): per-frame 3x3 at
+    // 128 channels with residual + statistics 1.71 -> 1.62 ms (+6 %), 3x3x3 at 128 channels 3.38 -> 3.55 ms (-4 %) -- but with two
+    // workgroups resident on a CU a few of the fused GroupNorm records came out wrong and differed from run to run (3 of 11520;
+    // the stored outputs were bit-identical and correct; gone when the launch is padded to one workgroup per CU; unexplained:
+    // DESIGN.md section 3.1).  CVVAE_CONV_NW4=<factor> makes them eligible (tuning / debugging aid).
     if (e.wm * e.wn * e.kg == 4) {
       static const double nw4 = getenv("CVVAE_CONV_NW4") ? atof(getenv("CVVAE_CONV_NW4")) : 0.0;
-      cost *= nw4 > 0.0 ? nw4 : (e.kt == 1 ? 0.9 : 100.0);
+      cost *= nw4 > 0.0 ? nw4 : 100.0;
     }
     // strided convs do 4-8x fewer MFMAs per staged byte and their halos (430 KiB per workgroup at 128 channels) do not survive in
     // L2 between K-chunk passes: every pass re-fetches whole 128-byte lines for 32 bytes of them.  32-channel chunks halve

@@ -1,0 +1,58 @@
+"""debug aid: determinism of the 4-wave per-frame conv when two workgroups share a CU (grid > #CUs)"""
+import os, sys, itertools
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cvvae_amd import ops
+
+torch.manual_seed(0)
+dt = torch.bfloat16
+x = torch.randn((3, 5, 64, 96, 128), device="cuda").to(dt)
+res = torch.randn((3, 5, 64, 96, 128), device="cuda").to(dt)
+gsc = (1 + 0.1 * torch.randn((3, 128), device="cuda"))
+gsh = 0.1 * torch.randn((3, 128), device="cuda")
+w = (torch.randn((128, 128, 1, 3, 3), device="cuda") / (128 * 9) ** 0.5).to(dt)
+pw = ops.pack_weight(w.reshape(128, 128, 9), torch.randn(128, device="cuda"), (1, 3, 3))
+P2D = ((0, 0), (1, 1), (1, 1))
+
+def run(force, pro, use_res, stats):
+    os.environ["CVVAE_CONV_FORCE"] = force
+    kw = dict(pad=P2D)
+    if pro: kw.update(prologue=1, gn=(gsc, gsh))
+    if use_res: kw.update(residual=res)
+    if stats: kw.update(gn_out=32)
+    r = ops.conv(x, pw, **kw)
+    torch.cuda.synchronize()
+    return r if stats else (r, None)
+
+for force in ("1x8x32:1x4x1:2", "1x8x32:2x4x1:2"):
+    for pro, use_res, stats in itertools.product((0, 1), (0, 1), (0, 1)):
+        outs = [run(force, pro, use_res, stats) for _ in range(4)]
+        same = all(torch.equal(outs[0][0], o[0]) for o in outs[1:])
+        nd = max((outs[0][0].float() - o[0].float()).abs().max().item() for o in outs[1:])
+        ps = True if not stats else all(torch.equal(outs[0][1].buf, o[1].buf) for o in outs[1:])
+        print(f"{force:18s} pro={pro} res={use_res} stats={stats}: y identical={same} (max diff {nd:.3e}) partials identical={ps}", flush=True)
+for rp in ("0", "1"):
+    os.environ["CVVAE_RES_PRELOAD"] = rp
+
+print("---- which records differ (4-wave, pro=1, stats=1)")
+outs = [run("1x8x32:1x4x1:2", 1, 0, 1) for _ in range(3)]
+a, b = outs[0][1].buf, outs[1][1].buf          # [rows, slabs, G, 3]
+d = (a != b)
+print("shape", tuple(a.shape), "differing entries", int(d.sum()), "by field", [int(d[..., i].sum()) for i in range(3)])
+idx = d.any(-1).nonzero()[:12]
+for r, s, g in idx.tolist():
+    print("  row", r, "slab", s, "group", g, a[r, s, g].tolist(), b[r, s, g].tolist())
+ones, zeros = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
+sc_f, sh_f = ops.gn_finalize(outs[0][1], ones, zeros, 1e-6)
+sc_s, sh_s = ops.gn_stats(outs[0][0], ones, zeros, 1e-6)
+print("finalize vs stats pass: scale rel err", ((sc_f - sc_s).abs() / sc_s.abs()).max().item(), "shift abs err", (sh_f - sh_s).abs().max().item())
+# per-record check against a direct computation from y: record (slab = tile, group g) covers a tile of 8x32 pixels x 4 channels
+y = outs[0][0].float()
+B, T, H, W, C = y.shape
+yt = y.view(B, T, H // 8, 8, W // 32, 32, 32, 4).permute(0, 1, 2, 4, 6, 3, 5, 7).reshape(B, T * (H // 8) * (W // 32), 32, -1)
+mean_ref = yt.mean(-1)
+err = (a[..., 1] - mean_ref).abs()
+print("record mean vs direct tile mean: max err", err.max().item(), "n field unique", a[..., 0].unique().tolist()[:5])
+bad = (err > 1e-3).nonzero()[:10]
+print("bad records", bad.tolist())
+print("lds solo env", os.environ.get("CVVAE_NW4_SOLO"))
