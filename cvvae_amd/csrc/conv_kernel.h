@@ -1118,6 +1118,22 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         gq[pr][q] = half_wave_sum(gq[pr][q]);
       }
     }
+    // the writers (lanes 31 / 63) may be lanes that stored nothing (ragged tiles): they take the shifts from the first lane of
+    // their half that set them (all setting lanes of a half hold the same value)
+    if (!tile_full) {
+#pragma unroll
+      for (int pr = 0; pr < 2; ++pr) {
+        const unsigned long long mk = __builtin_amdgcn_ballot_w64(((gkm >> pr) & 1) != 0);
+        const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+        const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+          const float kl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), slo));
+          const float kh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), shi));
+          gk[pr][q] = (lane_e & 32) ? kh : kl;
+        }
+      }
+    }
     if ((lane_e & 31) == 31) {
       const int E = 1 << (p.gn_sh - 2);  // 4-channel slots per group
       const int part = ((UPS == 2 ? tile_in_b * 4 + phase : tile_in_b) * WM + wave_m) * KG + kgrp;
