@@ -20,8 +20,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # max / mean |delta| of the LATENT (posterior mean) and recon PSNR against the reference's fp32 outputs.  The bands are the
 # reference's own low-precision noise with the same head-room as tests/test_gpu_model.py; the fp32
 # model (3xfp16 split MFMA) must meet north_star's |delta| <= 1e-3 as a MAX.
+# (the maximum over N latent values of a noise of fixed sigma grows like sqrt(2 ln N): the fp16 band of the small fixtures, 4e-3 at
+# N ~ 1e4-1e5, becomes 5e-3 at the 1.15e6 latent values of the 720x1280 window; the mean band does not move)
 TOL = {
-    torch.float16: dict(latent_max=4.0e-3, latent_mean=8.0e-4, psnr=62.0),
+    torch.float16: dict(latent_max=5.0e-3, latent_mean=8.0e-4, psnr=62.0),
     torch.bfloat16: dict(latent_max=3.5e-2, latent_mean=6.0e-3, psnr=45.0),
     torch.float32: dict(latent_max=1.0e-3, latent_mean=1.0e-4, psnr=80.0),
 }
