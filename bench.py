@@ -353,7 +353,8 @@ def main():
         # HBM traffic per launch of that kernel: from the committed PMC passes of this same command (profiles/)
         traffic = None
         short = name.split("_", 3)[3] if name.count("_") >= 3 else name
-        tj = profile_json("pmc_traffic.json")
+        profiled = args.workload.startswith("cfg3") and args.dtype == "bf16"  # the committed PMC passes are of THIS command
+        tj = profile_json("pmc_traffic.json") if profiled else None
         if tj:
             k = tj.get("kernels", {}).get(short)
             if k:
@@ -368,7 +369,7 @@ def main():
             "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": traffic,
             "traffic_unit": "bytes/launch (PMC, profiles/pmc_traffic.json)",
         }
-        sq = profile_json("pmc_sq.json")
+        sq = profile_json("pmc_sq.json") if profiled else None
         if sq and short in sq.get("kernels", {}):
             out["mfma_busy"] = dict(sq["kernels"][short], source="profiles/pmc_sq.json (SQ counters, separate --pmc passes)")
         tot_fx, tot_sec = sum(v[3] for v in agg.values()), sum(v[1] for v in agg.values())
