@@ -16,8 +16,12 @@ def short(n):
     m = re.search(r"conv_fwd_kernel<(.*?)>\(", n)
     if m:
         f = [x.strip() for x in m.group(1).split(",")]
+        xp = ""
+        if f[-1] in ("true", "false"):  # trailing template argument XP (split-precision instances) since ABI 6
+            xp = "_xp" if f[-1] == "true" else ""
+            f = f[:-1]
         t = f[-9:]
-        return f"conv_*_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{t[8]}"
+        return f"conv_*_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{t[8]}{xp}"
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"^void ", "", n)
     return n[-60:]
