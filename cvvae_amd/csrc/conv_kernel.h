@@ -112,6 +112,7 @@ struct ConvArgs {
   int w_taps;    // taps per k16 record group of the packed weights: NTAPS, or 2*NTAPS with the time-fold slots (KT == 3)
   int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
   int probe_nostore;  // probe builds (-DCVVAE_CONV_PROBE) only: run the store tail without its stores
+  int stats_noshift;  // debug aid (CVVAE_STATS_NOSHIFT=1): fused statistics as plain sums (shift K = 0)
   int phase_sync;     // 1: every wave multiplies chunk c, THEN stages chunk c+1 (no wave stages beside another's MFMA stream);
                       // 0: the two wave groups run opposite phase orders (X: stage -> MFMA, Y: MFMA -> stage)
 };
@@ -951,14 +952,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
             asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
             unpack8<T>(pq, rv);
-            if (!gk_set) {  // first stored fragment of the tile (wave-uniform): the shifts of both channel pairs
-              // (v_readlane, not a ds_bpermute shuffle: the value must be THE SAME in every lane of the half-wave)
-              const float k0l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), 0));
-              const float k0h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), 32));
-              const float k1l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), 0));
-              const float k1h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), 32));
-              gk[pr][0] = (lane_e & 32) ? k0h : k0l;
-              gk[pr][1] = (lane_e & 32) ? k1h : k1l;
+            if (!gk_set) {  // first stored fragment of the tile: every lane shifts by ITS OWN first value of the slot (made common
+              // to the half-wave just before the reduction -- no cross-lane traffic at the start of the tail)
+              gk[pr][0] = p.stats_noshift == 1 ? 0.f : rv[0];
+              gk[pr][1] = p.stats_noshift == 1 ? 0.f : rv[4];
               gk_set = pr == 1;
             }
             gc[pr] += 1.f;
@@ -1034,15 +1031,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
               if (XP && p.gnp) {  // fused GroupNorm statistics of the fp32 values stored (shifted sums, as below)
                 if (!((gkm >> pr) & 1)) {
-                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);  // lanes storing this run (wave-uniform mask)
-                  const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
-                  const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
-                  const float k0l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), slo));
-                  const float k0h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[0]), shi));
-                  const float k1l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[4]), slo));
-                  const float k1h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v[4]), shi));
-                  gk[pr][0] = (lane_e & 32) ? k0h : k0l;
-                  gk[pr][1] = (lane_e & 32) ? k1h : k1l;
+                  gk[pr][0] = v[0];  // per-lane shift (see the fast tail)
+                  gk[pr][1] = v[4];
                   gkm |= 1u << pr;
                 }
                 gc[pr] += 1.f;
@@ -1074,15 +1064,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                 asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
                 unpack8<T>(pq, rv);
                 if (!((gkm >> pr) & 1)) {  // shifts: the values of the first storing lane of my half-wave (per-lane code here)
-                  const unsigned long long mk = __builtin_amdgcn_ballot_w64(true);  // lanes storing this run (wave-uniform mask)
-                  const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
-                  const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
-                  const float k0l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), slo));
-                  const float k0h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[0]), shi));
-                  const float k1l = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), slo));
-                  const float k1h = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rv[4]), shi));
-                  gk[pr][0] = (lane_e & 32) ? k0h : k0l;
-                  gk[pr][1] = (lane_e & 32) ? k1h : k1l;
+                  gk[pr][0] = rv[0];  // per-lane shift (see the fast tail)
+                  gk[pr][1] = rv[4];
                   gkm |= 1u << pr;
                 }
                 gc[pr] += 1.f;
@@ -1108,6 +1091,25 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   if (p.gnp) {
     // wave reduction over the 32 pixels of each half-wave (the two halves hold different channels), then lanes 31 and 63
     // write one (n, mean, M2) record per 4-channel slot: record index inside its group = the slot's position in the group
+    // every lane accumulated around its own shift K_l; re-express its sums around the COMMON shift K0 of its half-wave (the
+    // K_l of the half's first lane that stored something):  S0 = S + n (K_l - K0),  Q0 = Q + 2 (K_l - K0) S + n (K_l - K0)^2
+    // (exact algebra; K_l - K0 is of the order of sigma, so nothing cancels)
+#pragma unroll
+    for (int pr = 0; pr < 2; ++pr) {
+      const unsigned long long mk = tile_full ? ~0ull : __builtin_amdgcn_ballot_w64(((gkm >> pr) & 1) != 0);
+      const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
+      const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float kl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), slo));
+        const float kh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), shi));
+        const float k0 = (lane_e & 32) ? kh : kl;
+        const float dk = gk[pr][q] - k0, nl = gc[pr] * 4.f;
+        gq[pr][q] += dk * (2.f * gs[pr][q] + nl * dk);
+        gs[pr][q] += nl * dk;
+        gk[pr][q] = k0;
+      }
+    }
     // (DPP row shifts + row broadcast inside the VALU -- no LDS-pipe shuffles: lanes 31 / 63 end with the sums of their half)
 #pragma unroll
     for (int pr = 0; pr < 2; ++pr) {
@@ -1118,21 +1120,17 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         gq[pr][q] = half_wave_sum(gq[pr][q]);
       }
     }
-    // the writers (lanes 31 / 63) may be lanes that stored nothing (ragged tiles): they take the shifts from the first lane of
-    // their half that set them (all setting lanes of a half hold the same value)
-    if (!tile_full) {
+    float gdev[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+    if (p.stats_noshift == 3) {  // debug aid: do all lanes of a half hold the same shift at the END of the tail?
 #pragma unroll
-      for (int pr = 0; pr < 2; ++pr) {
-        const unsigned long long mk = __builtin_amdgcn_ballot_w64(((gkm >> pr) & 1) != 0);
-        const unsigned mlo = (unsigned)mk, mhi = (unsigned)(mk >> 32);
-        const int slo = mlo ? __builtin_ctz(mlo) : 0, shi = 32 + (mhi ? __builtin_ctz(mhi) : 0);
+      for (int pr = 0; pr < 2; ++pr)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-          const float kl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), slo));
-          const float kh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), shi));
-          gk[pr][q] = (lane_e & 32) ? kh : kl;
+          const float kl = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), 31));
+          const float kh = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, gk[pr][q]), 63));
+          const float dv = gk[pr][q] - ((lane_e & 32) ? kh : kl);
+          gdev[pr][q] = half_wave_sum(dv < 0.f ? -dv : dv);
         }
-      }
     }
     if ((lane_e & 31) == 31) {
       const int E = 1 << (p.gn_sh - 2);  // 4-channel slots per group
@@ -1158,7 +1156,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           float* o = p.gnp + (((size_t)b * p.gn_slabs + (size_t)(slab * E + sub)) * p.gn_G + g) * 3;
           o[0] = n;
           o[1] = mean;
-          o[2] = m2;
+          o[2] = p.stats_noshift == 2 ? gk[pr][q] : (p.stats_noshift == 3 ? gdev[pr][q] : m2);  // (debug aid: expose the shift)
         }
     }
   }

@@ -313,6 +313,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.order = 1;
   if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
   a.alpha = d->alpha;
+  if (const char* f = getenv("CVVAE_STATS_NOSHIFT")) a.stats_noshift = atoi(f);  // debug aid
   if (const char* f = getenv("CVVAE_CONV_PHASE_SYNC")) a.phase_sync = atoi(f) ? 1 : 0;  // tuning aid (conv_kernel.h phase_sync)
   a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1) * xpm;
   static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid
