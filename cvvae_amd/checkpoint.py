@@ -19,7 +19,14 @@ def load_any(path: str) -> Dict[str, torch.Tensor]:
     if path.endswith(".safetensors"):
         from safetensors.torch import load_file
         return load_file(path)
-    obj = torch.load(path, map_location="cpu", weights_only=True)
+    try:
+        obj = torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as e:  # pickle.UnpicklingError: Lightning checkpoints may carry non-tensor objects (hyper-parameters, callbacks)
+        raise RuntimeError(
+            f"{path}: torch.load(weights_only=True) refused this checkpoint ({type(e).__name__}: {str(e).splitlines()[0][:160]}). "
+            "It holds pickled objects besides tensors.  If you trust the file, allow-list the reported classes with "
+            "torch.serialization.add_safe_globals([...]) before calling, or re-export it once with "
+            "torch.save({'state_dict': torch.load(path, weights_only=False)['state_dict']}, new_path).") from e
     if isinstance(obj, dict) and "state_dict" in obj and isinstance(obj["state_dict"], dict):
         obj = obj["state_dict"]
     if not isinstance(obj, dict):

@@ -45,3 +45,19 @@ def test_missing_or_mismatched_tensors_raise(tmp_path):
     torch.save({"state_dict": sd}, src)
     with pytest.raises(KeyError, match="1 missing"):
         checkpoint.convert_training_checkpoint(src, os.path.join(tmp_path, "o"), "sd3", **SMALL["sd3"])
+
+
+class Opaque:  # a non-tensor object as Lightning checkpoints carry them: not allow-listed for weights_only unpickling
+    pass
+
+
+def test_checkpoint_with_pickled_objects_gets_a_clear_error(tmp_path):
+    """Lightning .ckpt files can carry arbitrary pickled objects; weights_only loading refuses them -- the tool must say what to do."""
+    import pytest
+    import torch
+    from cvvae_amd.checkpoint import load_any
+
+    p = tmp_path / "last.ckpt"
+    torch.save({"state_dict": {"w": torch.zeros(1)}, "hyper_parameters": Opaque()}, p)
+    with pytest.raises(RuntimeError, match="add_safe_globals"):
+        load_any(str(p))
