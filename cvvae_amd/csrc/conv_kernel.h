@@ -880,16 +880,21 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   constexpr int TWm = TW < 32 ? TW : 32;
   static_assert(TW % 32 == 0 || (32 % TW == 0 && TH % (32 / TW) == 0), "fragment rows must tile the workgroup tile");
   const bool tile_full = (t0 + TT <= p.To) && (y0 + TH <= p.Ho) && (x0 + TW <= p.Wo) && ((nb + 1) * 32 <= p.Cout) &&
-                         !p.out_f32 && !XP && (p.out_mode != 2 || (C2 & 31) == 0);
-  if (tile_full) {
+                         (p.out_mode != 2 || (C2 & 31) == 0);  // (geometry only: the element type is chosen below)
+  // The fast tail exists for the storage dtype T and -- split-precision instances and the 1x1x1 family, whose attention score
+  // product stores fp32 -- for float (32-byte runs per lane: two 16-byte accesses); `zero` selects the element type.
+  auto fast_tail = [&](auto zero) {
+    using TO = decltype(zero);
+    constexpr bool F32 = std::is_same<TO, float>::value;
+    constexpr int RBF = F32 ? (RB > 2 ? 2 : RB) : RB;  // fragments per batch (a float residual run is 8 registers)
     const int l31 = lane_e & 31;
     const int Wst = (UPS == 2 ? 2 : 1) * p.Wo, Hst = (UPS == 2 ? 2 : 1) * p.Ho;  // stored frame size
     const unsigned voff = (unsigned)((UPS == 2 ? 2 : 1) * ((l31 / TWm) * Wst + (l31 % TWm)) * p.out_ps + (lane_e >> 5) * 8);
     const int n_sh = (p.out_mode == 2 && nb * 32 >= C2) ? 1 : 0;  // time shuffle: my 32 channels land one frame later
     const int Tq = p.out_mode == 2 ? 2 * p.To - 1 : p.To;
     const int chan0 = nb * 32 - n_sh * C2;
-    T* __restrict__ outp = reinterpret_cast<T*>(p.out);
-    const T* __restrict__ resp = reinterpret_cast<const T*>(p.res);
+    TO* __restrict__ outp = reinterpret_cast<TO*>(p.out);
+    const TO* __restrict__ resp = reinterpret_cast<const TO*>(p.res);
     // element offset of fragment r (its lane 0, my channel block), wave-uniform; drop = the discarded frame -1
     auto row_of = [&](int r, bool& drop) -> long long {
       const int f = wave_m * MREP + r;
@@ -903,22 +908,22 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       return S * (long long)p.out_ps + chan0;
     };
 #pragma unroll
-    for (int r0 = 0; r0 < MREP; r0 += RB) {
-      uint4 rres[RB][2];
-      long long rowe[RB];
-      bool drop[RB];
+    for (int r0 = 0; r0 < MREP; r0 += RBF) {
+      Raw8<TO> rres[RBF][2];
+      long long rowe[RBF];
+      bool drop[RBF];
 #pragma unroll
-      for (int ri = 0; ri < RB; ++ri) rowe[ri] = row_of(r0 + ri, drop[ri]);
+      for (int ri = 0; ri < RBF; ++ri) rowe[ri] = row_of(r0 + ri, drop[ri]);
       if (p.res && !res_pre) {
 #pragma unroll
-        for (int ri = 0; ri < RB; ++ri) {
+        for (int ri = 0; ri < RBF; ++ri) {
           if (KG == 2 && (((r0 + ri) < MREP / 2) != (kgrp == 0))) continue;
 #pragma unroll
-          for (int pr = 0; pr < 2; ++pr) rres[ri][pr] = *reinterpret_cast<const uint4*>(resp + rowe[ri] + pr * 16 + voff);
+          for (int pr = 0; pr < 2; ++pr) rres[ri][pr] = ldraw8<TO>(resp + rowe[ri] + pr * 16 + voff);
         }
       }
 #pragma unroll
-      for (int ri = 0; ri < RB; ++ri) {
+      for (int ri = 0; ri < RBF; ++ri) {
         const int r = r0 + ri;
         if (KG == 2 && ((r < MREP / 2) != (kgrp == 0))) continue;  // each K-group stores the half it reduced
 #pragma unroll
@@ -938,20 +943,31 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           }
           if (p.res && !res_pre) {
             float rf[8];
-            unpack8<T>(rres[ri][pr], rf);
+            unraw8<TO>(rres[ri][pr], rf);
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += rf[j];
           }
-          const uint4 pk = pack8<T>(v);
+          float rv[8];  // the values as stored (rounded to the storage dtype; float: as they are): what the statistics see
+          if constexpr (F32) {
 #ifdef CVVAE_CONV_PROBE
-          if (!p.probe_nostore)
+            if (!p.probe_nostore)
 #endif
-          *reinterpret_cast<uint4*>(outp + rowe[ri] + pr * 16 + voff) = pk;
+            st8<float>(outp + rowe[ri] + pr * 16 + voff, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) rv[j] = v[j];
+          } else {
+            const uint4 pk = pack8<T>(v);
+#ifdef CVVAE_CONV_PROBE
+            if (!p.probe_nostore)
+#endif
+            *reinterpret_cast<uint4*>(outp + rowe[ri] + pr * 16 + voff) = pk;
+            if (p.gnp) {
+              uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
+              asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
+              unpack8<T>(pq, rv);
+            }
+          }
           if (p.gnp) {
-            float rv[8];
-            uint4 pq = pk;  // opaque copy: the ROUNDED values are unpacked from the packed registers (one shift / and
-            asm volatile("" : "+v"(pq.x), "+v"(pq.y), "+v"(pq.z), "+v"(pq.w));  // per value; hipcc otherwise re-converts each float)
-            unpack8<T>(pq, rv);
             if (!gk_set) {  // first stored fragment of the tile: every lane shifts by ITS OWN first value of the slot (made common
               // to the half-wave just before the reduction -- no cross-lane traffic at the start of the tail)
               gk[pr][0] = p.stats_noshift == 1 ? 0.f : rv[0];
@@ -971,6 +987,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         }
       }
     }
+  };
+  constexpr bool F32TAIL = XP || (KT * KH * KW == 1);  // instances that can store float from the fast tail
+  const bool f32out = XP || p.out_f32;
+  if (tile_full && !f32out) {
+    fast_tail((T)0.f);
+  } else if (F32TAIL && tile_full && f32out) {
+    if constexpr (F32TAIL) fast_tail(0.0f);
   } else {
   #pragma unroll
     for (int r0 = 0; r0 < MREP; r0 += RB) {
