@@ -369,6 +369,10 @@ def main():
             "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": traffic,
             "traffic_unit": "bytes/launch (PMC, profiles/pmc_traffic.json)",
         }
+        pk = profile_json("peak_probe.json")
+        if pk:  # what dense bf16 matrix code sustains on this pool's MI355X (vendor GEMM, register-only MFMA stream)
+            out["roofline"]["on_box_denominators"] = pk
+            out["roofline"]["executed_frac_of_hipblaslt_gemm"] = round(fx / sec / 1e12 / max(pk["hipblaslt_bf16_gemm_tflops"]), 3)
         sq = profile_json("pmc_sq.json") if profiled else None
         if sq and short in sq.get("kernels", {}):
             out["mfma_busy"] = dict(sq["kernels"][short], source="profiles/pmc_sq.json (SQ counters, separate --pmc passes)")
