@@ -154,7 +154,11 @@ struct Geo {
   // pixels staged by group X (NWV == 8: the two wave groups split the halo; NWV == 4: the single group stages all of it)
   static constexpr int NPH = NWV == 4 ? (NPIX + PPP - 1) / PPP * PPP : ((NPIX + 1) / 2 + PPP - 1) / PPP * PPP;
   static constexpr int NPASS = NWV == 4 ? NPH / PPP : (cmax(NPH, NPIX - NPH) + PPP - 1) / PPP;
-  static constexpr int SBATCH = NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4);
+  // B fragments: two register sets (the reads of step st+1 fly under the MFMAs of step st), or -- MREP >= 8 -- ONE set updated in
+  // place: the read for (st+1, r) is issued right after the MFMA of (st, r) and is needed MREP MFMAs (>= 256 cycles) later.  The
+  // 32 registers this frees hold ALL staging loads of a chunk at once (one exposed memory latency per chunk instead of two).
+  static constexpr int NAB = MREP >= 8 ? 1 : 2;
+  static constexpr int SBATCH = (NAB == 1 && NPASS <= 6) ? NPASS : (NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4));
   static constexpr int STEPS = NTAPS * KSUB * XPM;   // k16 steps per chunk, ordered ks-major: st = (ks * NTAPS + tap) * XPM + part
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
   // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
@@ -597,7 +601,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         const unsigned lb = (unsigned)(cur * G::BUFB);
         const T* wcb = wq + (size_t)c * (size_t)w_cs;
         const T* wnx = more ? wcb + w_cs : wcb;  // the last chunk's read-ahead re-reads its own records (never past the buffer)
-        v8 ab[2][MREP];
+        constexpr int NAB = G::NAB;
+        v8 ab[NAB][MREP];
 #pragma unroll
         for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + tf_l0 + aoff[r]]);
         for (int g = 0; g < tf_ng; ++g) {
@@ -614,11 +619,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
-              acc[r] = Tr<T>::mfma(wv, ab[i & 1][r], acc[r]);
+              acc[r] = Tr<T>::mfma(wv, ab[i & (NAB - 1)][r], acc[r]);
               if (i + 1 < GS)
-                ab[(i + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
+                ab[(i + 1) & (NAB - 1)][r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
+              else if (NAB == 1 && !lastg)  // (in place) first fragments of the next time group
+                ab[0][r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
-            if (i + 1 == GS && !lastg) {  // first fragments of the next time group (set 0: its step 0)
+            if (NAB == 2 && i + 1 == GS && !lastg) {  // first fragments of the next time group (set 0: its step 0)
 #pragma unroll
               for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
@@ -632,7 +639,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       const T* wc = wq + (size_t)c * (STEPS * 512);
       // software-pipelined LDS reads: the activation fragments of step st+1 are requested while the MFMAs of
       // step st issue (two register sets), so an MFMA never waits on the ds_read issued right before it.
-      v8 ab[2][MREP];
+      constexpr int NAB = G::NAB;
+      v8 ab[NAB][MREP];
 #pragma unroll
       for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r]]);
       if constexpr (RES_PRE) {
@@ -662,9 +670,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
 #pragma unroll
         for (int r = 0; r < MREP; ++r) {
-          acc[r] = Tr<T>::mfma(wv, ab[st & 1][r], acc[r]);
+          acc[r] = Tr<T>::mfma(wv, ab[st & (NAB - 1)][r], acc[r]);
           if (st + 1 < STEPS_W)
-            ab[(st + 1) & 1][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
+            ab[(st + 1) & (NAB - 1)][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
         }
         // ring refill: my record st+PF of this chunk, or (wrapping) record st+PF-STEPS_W of the next chunk
         wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512);
