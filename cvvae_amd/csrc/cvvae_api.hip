@@ -54,68 +54,84 @@ static int cu_count() {
   return cus;
 }
 
-// pick the instance with the least padded work (tile overhang x inactive N waves); ties -> table order
+// pick the instance with the least padded work (tile overhang x inactive N waves); ties -> table order.
+// Every term is evaluated PER BATCH ITEM: the tiling decides at which K chunk a residual is pre-accumulated and whether a K split
+// is used, i.e. the summation order, hence bits -- a choice that depended on how many clips are coded together would break
+// "a batch of B clips == B single-clip calls, bit for bit" (tests/test_gpu_model.py::test_batch_of_clips_matches_single_clips).
+static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
+  const int fold = d->upsample2x == 2;
+  const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
+  // per-phase output grid for the folded upsample (4 phases of Ho/2 x Wo/2), the output grid otherwise
+  const long long tiles = fold ? cdiv(d->To, e.tt) * cdiv(d->Ho / 2, e.th) * cdiv(d->Wo / 2, e.tw) * d->B * 4
+                               : cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
+  const long long ntn = cdiv(d->Cout, bn);
+  // cost ~ MFMA work issued (padded) + staging work (halo per N tile)
+  double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
+  // staging share: halo pixels staged per output pixel, once per N tile (grows as BN shrinks)
+  const double halo = (double)((e.tt - 1) * e.st + e.kt) * ((e.th - 1) * e.sh + e.kh) * ((e.tw - 1) * e.sw + e.kw) / (double)bm;
+  cost *= 1.0 + 0.04 * halo * 256.0 / (double)bn;
+  // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
+  cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
+  if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)
+  // four-wave instances (two workgroups per CU): NOT selected by default.  Measured (profiles/r2_ab_4wave_*.log): per-frame 3x3 at
+  // 128 channels with residual + statistics 1.71 -> 1.62 ms (+6 %), 3x3x3 at 128 channels 3.38 -> 3.55 ms (-4 %) -- but with two
+  // workgroups resident on a CU a few of the fused GroupNorm records came out wrong and differed from run to run (DESIGN.md
+  // section 3.1, unexplained).  CVVAE_CONV_NW4=<factor> makes them eligible (tuning / debugging aid).
+  if (e.wm * e.wn * e.kg == 4) {
+    static const double nw4 = getenv("CVVAE_CONV_NW4") ? atof(getenv("CVVAE_CONV_NW4")) : 0.0;
+    cost *= nw4 > 0.0 ? nw4 : 100.0;
+  }
+  // strided convs do 4-8x fewer MFMAs per staged byte and their halos (430 KiB per workgroup at 128 channels) do not survive in
+  // L2 between K-chunk passes: every pass re-fetches whole 128-byte lines for 32 bytes of them.  32-channel chunks halve
+  // the passes (measured: 128 ch s222 0.89 -> 0.81 ms, 512 ch 0.305 -> 0.260 ms, s122 unchanged)
+  if (e.st * e.sh * e.sw > 1 && e.ksub == 1) cost *= 1.15;
+  // round quantisation: a grid of W workgroups runs in ceil(W / #CUs) rounds of one workgroup per CU
+  // (half weight: measured, a partly filled last round costs less than its share -- the busy CUs clock higher)
+  {
+    const double wgs = (double)tiles / (double)d->B * (double)ntn, cus = (double)cu_count();
+    static const int quant = getenv("CVVAE_CONV_QUANT") ? atoi(getenv("CVVAE_CONV_QUANT")) : 1;  // tuning aid
+    // (not for the 1x1 family: its batch items are the FRAMES of the attention blocks -- 32 workgroups each, several per launch --
+    //  and the per-item term pushed those products to the instance with more, smaller workgroups: 0.69 -> 0.41 ms per cfg 3 step
+    //  with the 256-channel tile)
+    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + 0.5 * (ceil(wgs / cus) / (wgs / cus) - 1.0);
+  }
+  return cost;
+}
+
 static const Instance* select_instance(const cvvae_conv_desc* d) {
-  const Instance* best = nullptr;
-  double best_cost = 0;
   // tuning aid: CVVAE_CONV_FORCE="TTxTHxTW:WMxWNxKG:KSUB" restricts the choice (ignored when nothing matches)
   int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0, fg = 0, fk = 0;
   if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%dx%d:%d", &ft, &fh, &fw, &fm, &fn, &fg, &fk);
-  for (int pass = 0; pass < 2 && !best; ++pass)
-  for (int i = 0; i < g_ntable; ++i) {
-    const Instance& e = g_table[i];
-    if (!e.fn[d->dtype]) continue;  // fp32 models run the split-precision instances, fp16 / bf16 models the others
-    if (pass == 0 && ft &&
-        (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) continue;
+  auto eligible = [&](const Instance& e, bool forced) {
+    if (!e.fn[d->dtype]) return false;  // fp32 models run the split-precision instances, fp16 / bf16 models the others
+    if (forced && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) return false;
     // the folded upsample (upsample2x == 2) runs 3x2x2 phase kernels; everything else matches the descriptor's taps
     const int fold = d->upsample2x == 2;
-    if (e.kt != d->kT || e.kh != (fold ? 2 : d->kH) || e.kw != (fold ? 2 : d->kW)) continue;
-    if (e.st != d->sT || e.sh != d->sH || e.sw != d->sW) continue;
-    if (e.pro != d->prologue || e.ups != d->upsample2x) continue;
-    if (d->Cin % (16 * e.ksub)) continue;  // the instance's K-chunk must divide the consumed channels
-    if (d->sc_Cin && (e.kg != 1 || e.ups != 0 || d->sc_Cin % (16 * e.ksub))) continue;  // fused shortcut: KG = 1 instances
-    if (d->w_time_folds && e.kg != 1) continue;  // the time-fold record layout is walked by the KG = 1 kernels only
-    const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
-    // per-phase output grid for the folded upsample (4 phases of Ho/2 x Wo/2), the output grid otherwise
-    const long long tiles = fold ? cdiv(d->To, e.tt) * cdiv(d->Ho / 2, e.th) * cdiv(d->Wo / 2, e.tw) * d->B * 4
-                                 : cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
-    const long long ntn = cdiv(d->Cout, bn);
-    // cost ~ MFMA work issued (padded) + staging work (halo per N tile)
-    double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
-    // staging share: halo pixels staged per output pixel, once per N tile (grows as BN shrinks)
-    const double halo = (double)((e.tt - 1) * e.st + e.kt) * ((e.th - 1) * e.sh + e.kh) * ((e.tw - 1) * e.sw + e.kw) / (double)bm;
-    cost *= 1.0 + 0.04 * halo * 256.0 / (double)bn;
-    // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
-    cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
-    if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)
-    // four-wave instances (two workgroups per CU): NOT selected by default.  Measured (profiles/r2_ab_4wave_*.log): per-frame 3x3 at
-    // 128 channels with residual + statistics 1.71 -> 1.62 ms (+6 %), 3x3x3 at 128 channels 3.38 -> 3.55 ms (-4 %) -- but with two
-    // workgroups resident on a CU a few of the fused GroupNorm records came out wrong and differed from run to run (3 of 11520;
-    // the stored outputs were bit-identical and correct; gone when the launch is padded to one workgroup per CU; unexplained:
-    // DESIGN.md section 3.1).  CVVAE_CONV_NW4=<factor> makes them eligible (tuning / debugging aid).
-    if (e.wm * e.wn * e.kg == 4) {
-      static const double nw4 = getenv("CVVAE_CONV_NW4") ? atof(getenv("CVVAE_CONV_NW4")) : 0.0;
-      cost *= nw4 > 0.0 ? nw4 : 100.0;
+    if (e.kt != d->kT || e.kh != (fold ? 2 : d->kH) || e.kw != (fold ? 2 : d->kW)) return false;
+    if (e.st != d->sT || e.sh != d->sH || e.sw != d->sW) return false;
+    if (e.pro != d->prologue || e.ups != d->upsample2x) return false;
+    if (d->Cin % (16 * e.ksub)) return false;  // the instance's K-chunk must divide the consumed channels
+    if (d->sc_Cin && (e.kg != 1 || e.ups != 0 || d->sc_Cin % (16 * e.ksub))) return false;  // fused shortcut: KG = 1 instances
+    if (d->w_time_folds && e.kg != 1) return false;  // the time-fold record layout is walked by the KG = 1 kernels only
+    return true;
+  };
+  for (int pass = 0; pass < 2; ++pass) {
+    const bool forced = pass == 0;
+    const Instance* best = nullptr;
+    double best_cost = 0;
+    for (int i = 0; i < g_ntable; ++i) {
+      const Instance& e = g_table[i];
+      if (!eligible(e, forced)) continue;
+      const double cost = instance_cost(d, e);
+      if (!best || cost < best_cost) {
+        best = &e;
+        best_cost = cost;
+      }
     }
-    // strided convs do 4-8x fewer MFMAs per staged byte and their halos (430 KiB per workgroup at 128 channels) do not survive in
-    // L2 between K-chunk passes: every pass re-fetches whole 128-byte lines for 32 bytes of them.  32-channel chunks halve
-    // the passes (measured: 128 ch s222 0.89 -> 0.81 ms, 512 ch 0.305 -> 0.260 ms, s122 unchanged)
-    if (e.st * e.sh * e.sw > 1 && e.ksub == 1) cost *= 1.15;
-    // round quantisation: a grid of W workgroups runs in ceil(W / #CUs) rounds of one workgroup per CU
-    {
-      // (per batch item, so that the choice -- hence the summation order, hence every bit of the result -- does not
-      //  depend on how many clips are coded together)
-      const double wgs = (double)tiles / (double)d->B * (double)ntn, cus = (double)cu_count();
-      // (half weight: measured, a partly filled last round costs less than its share -- the busy CUs clock higher)
-      static const int quant = getenv("CVVAE_CONV_QUANT") ? atoi(getenv("CVVAE_CONV_QUANT")) : 1;  // tuning aid
-      if (quant) cost *= 1.0 + 0.5 * (ceil(wgs / cus) / (wgs / cus) - 1.0);
-    }
-    if (!best || cost < best_cost) {
-      best = &e;
-      best_cost = cost;
-    }
+    if (!best) continue;
+    return best;
   }
-  return best;
+  return nullptr;
 }
 
 // An odd frame count under a two-frame tile wastes half of the last tile's MFMAs (T = 17: 5.9 %).  When the same
