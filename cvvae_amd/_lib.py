@@ -12,7 +12,7 @@ F16, BF16, F32 = 0, 1, 2
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class ConvDesc(ctypes.Structure):
@@ -62,6 +62,10 @@ PROTOTYPES = {
     "cvvae_gn_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cvvae_gn_stats": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_gn_silu_apply": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp]),
+    "cvvae_gn_bwd_workspace_bytes": (_i64, [_i32, _i32, _i64]),
+    "cvvae_gn_bwd_input": (_i32, [_i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "cvvae_softmax_bwd_rows": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),
+    "cvvae_upsample2x_sum": (_i32, [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_layernorm": (_i32, [_i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "cvvae_softmax_rows": (_i32, [_i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "cvvae_transpose": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp]),

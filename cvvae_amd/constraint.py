@@ -4,7 +4,9 @@ Reference: `DecoderWith3DWrapper(Decoder)` in lvdm/modules/diffusionmodules/vae_
 lvdm/modules/diffusionmodules/vae_blocks_sd3.py) -- the SD3 image VAE decoder, frozen
 (`self.constraint_decoder.requires_grad_(False)`, lvdm/models/autoencoder.py:1057-1058), applied frame by frame to the 3-D VAE's
 latents to produce `xrec_2d` for the latent-compatibility loss (autoencoder.py:1069; configs/cvvae_sd3_constraint_training.yaml:40-51).
-Same constructor keywords, same state-dict names and shapes, forward only (the decoder is never trained).
+Same constructor keywords, same state-dict names and shapes.  The decoder is never trained, but the loss back-propagates THROUGH
+it into the latents: when the input requires grad (and autograd is enabled) the call is recorded as one autograd node whose
+backward is the frozen decoder's input gradient on the same kernels (cvvae_amd/grad.py).  Weight gradients are not built.
 """
 from typing import Tuple
 
@@ -63,12 +65,23 @@ class Decoder(_Net):
         self._cfg = dict(block_out_channels=boc, layers_per_block=layers_per_block,
                          mid_block_add_attention=bool(mid_block_add_attention))
 
+    def _run(self, z: torch.Tensor) -> torch.Tensor:
+        """z [b,c,t,h,w] -> pixels; differentiable w.r.t. z when z requires grad (input gradient only: the module is frozen)"""
+        if torch.is_grad_enabled() and z.requires_grad:
+            self._check_input(z)
+            if any(p.requires_grad for p in self.parameters()):
+                raise NotImplementedError("only the frozen decoder's input gradient is built (the reference calls "
+                                          "constraint_decoder.requires_grad_(False)); weight gradients are not")
+            from .grad import ConstraintDecoderFn
+            return ConstraintDecoderFn.apply(z, self)
+        return _Net.forward(self, z)
+
     def forward(self, sample: torch.Tensor, latent_embeds=None) -> torch.Tensor:
         if latent_embeds is not None:
             raise NotImplementedError("norm_type='spatial' (latent_embeds) is not part of the shipped configuration")
         if sample.dim() != 4:
             raise ValueError(f"expected a [N,C,H,W] tensor, got shape {tuple(sample.shape)}")
-        return super().forward(sample.unsqueeze(2)).squeeze(2)
+        return self._run(sample.unsqueeze(2)).squeeze(2)
 
 
 class DecoderWith3DWrapper(Decoder):
@@ -78,5 +91,5 @@ class DecoderWith3DWrapper(Decoder):
         if z.dim() == 5:
             if kwargs.get("latent_embeds") is not None:
                 raise NotImplementedError("norm_type='spatial' (latent_embeds) is not part of the shipped configuration")
-            return _Net.forward(self, z)
+            return self._run(z)
         return super().forward(z, **kwargs)

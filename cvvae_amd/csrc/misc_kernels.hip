@@ -486,6 +486,185 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Input gradient of GroupNorm (+ SiLU) -- the frozen-module backward of the training path (cvvae_amd/grad.py).
+//   xh = (x - mean) * rstd = x * rs[c] + nm[c]      (rs = rstd, nm = -mean * rstd: cvvae_gn_finalize with gamma 1, beta 0)
+//   a  = xh * gamma[c] + beta[c],  y = act(a)       (the forward value the next conv consumed)
+//   gh = gy * act'(a) * gamma[c]                    (gradient w.r.t. xh)
+//   gx = rs * (gh - mean_grp(gh) - xh * mean_grp(gh * xh))  [+ add]
+// Pass 1 (gn_bwd_reduce_kernel) writes, per (row, pixel split, group), sum(gh) and sum(gh * xh); pass 2 (gn_bwd_apply_kernel) sums
+// the splits in index order (deterministic) and applies.  Channel quads never straddle a group (C / G a multiple of 4).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_grad_f(float a) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+  return sg * (1.0f + a * (1.0f - sg));
+}
+
+struct GnBwdTab {  // the per-channel tables of my 8 channels
+  float rs[8], nm[8], ga[8], be[8];
+};
+__device__ __forceinline__ void gn_bwd_load_tab(GnBwdTab& t, const float* __restrict__ rs, const float* __restrict__ nm,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta, long long row,
+                                                int C, int c0) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    t.rs[j] = rs[row * C + c0 + j];
+    t.nm[j] = nm[row * C + c0 + j];
+    t.ga[j] = gamma[c0 + j];
+    t.be[j] = beta[c0 + j];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ gy, long long S, int C,
+                                                            int G, int nsplit, const float* __restrict__ rs,
+                                                            const float* __restrict__ nm, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, int silu, float* __restrict__ ws) {
+  const int split = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int cv = C >> 3, ppp = 256 / cv;
+  const int myv = tid % cv, mypl = tid / cv;
+  const long long per = (S + nsplit - 1) / nsplit;
+  const long long p0 = (long long)split * per;
+  long long p1 = p0 + per;
+  if (p1 > S) p1 = S;
+  GnBwdTab t;
+  gn_bwd_load_tab(t, rs, nm, gamma, beta, row, C, myv * 8);
+  float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+  const T* xb = x + (long long)row * S * C + myv * 8;
+  const T* gb = gy + (long long)row * S * C + myv * 8;
+  for (long long px = p0 + mypl; px < p1; px += ppp) {
+    float f[8], g[8];
+    ld8<T>(xb + px * C, f);
+    ld8<T>(gb + px * C, g);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = __builtin_fmaf(f[j], t.rs[j], t.nm[j]);
+      const float a = __builtin_fmaf(xh, t.ga[j], t.be[j]);
+      const float gh = g[j] * (silu ? silu_grad_f(a) : 1.0f) * t.ga[j];
+      a1[j >> 2] += gh;
+      a2[j >> 2] += gh * xh;
+    }
+  }
+  __shared__ float sh1[256][2], sh2[256][2];
+  sh1[tid][0] = a1[0]; sh1[tid][1] = a1[1];
+  sh2[tid][0] = a2[0]; sh2[tid][1] = a2[1];
+  __syncthreads();
+  if (tid < G) {  // group tid: its channel quads q, every pixel lane, in index order
+    const int qpg = (C / G) >> 2;
+    float s1 = 0.f, s2 = 0.f;
+    for (int q = tid * qpg; q < (tid + 1) * qpg; ++q)
+      for (int pl = 0; pl < ppp; ++pl) {
+        const int th = pl * cv + (q >> 1);
+        s1 += sh1[th][q & 1];
+        s2 += sh2[th][q & 1];
+      }
+    float* o = ws + (((long long)row * nsplit + split) * G + tid) * 2;
+    o[0] = s1;
+    o[1] = s2;
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ gy,
+                                                           const T* __restrict__ add, T* __restrict__ out, long long S, int C, int G,
+                                                           int nsplit, const float* __restrict__ rs, const float* __restrict__ nm,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+                                                           const float* __restrict__ ws) {
+  const int row = blockIdx.y, tid = threadIdx.x;
+  __shared__ float c1[64], c2[64];
+  if (tid < G) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) {
+      const float* o = ws + (((long long)row * nsplit + sp) * G + tid) * 2;
+      s1 += o[0];
+      s2 += o[1];
+    }
+    const float invd = 1.0f / ((float)(C / G) * (float)S);
+    c1[tid] = s1 * invd;
+    c2[tid] = s2 * invd;
+  }
+  __syncthreads();
+  const int cv = C >> 3;
+  const int myv = tid % cv;  // 256 % cv == 0 and the stride below is a multiple of 256: my channel vector is fixed
+  GnBwdTab t;
+  gn_bwd_load_tab(t, rs, nm, gamma, beta, row, C, myv * 8);
+  const int cpg = C / G;
+  const float m1a = c1[(myv * 8) / cpg], m2a = c2[(myv * 8) / cpg], m1b = c1[(myv * 8 + 4) / cpg], m2b = c2[(myv * 8 + 4) / cpg];
+  const long long nvec = S * cv, base = (long long)row * S * C;
+  for (long long v = (long long)blockIdx.x * 256 + tid; v < nvec; v += (long long)gridDim.x * 256) {
+    const long long off = base + v * 8;  // v = pixel * cv + myv
+    float f[8], g[8], ad[8];
+    ld8<T>(x + off, f);
+    ld8<T>(gy + off, g);
+    if (add) ld8<T>(add + off, ad);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float xh = __builtin_fmaf(f[j], t.rs[j], t.nm[j]);
+      const float a = __builtin_fmaf(xh, t.ga[j], t.be[j]);
+      const float gh = g[j] * (silu ? silu_grad_f(a) : 1.0f) * t.ga[j];
+      const float r = t.rs[j] * (gh - (j < 4 ? m1a : m1b) - xh * (j < 4 ? m2a : m2b));
+      f[j] = add ? r + ad[j] : r;
+    }
+    st8<T>(out + off, f);
+  }
+}
+
+// gradient of the row softmax: gs = alpha * p * (gp - sum_j p_j gp_j); columns >= n_valid (up to ld_o) are written as 0
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_bwd_rows_kernel(const T* __restrict__ p, long long ld_p, const float* __restrict__ gp,
+                                                               long long ld_g, int n_valid, float alpha, T* __restrict__ out,
+                                                               long long ld_o) {
+  __shared__ float sh[4];
+  const T* pr = p + (long long)blockIdx.x * ld_p;
+  const float* gr = gp + (long long)blockIdx.x * ld_g;
+  T* orow = out + (long long)blockIdx.x * ld_o;
+  float dot = 0.f;
+  for (int i = threadIdx.x; i < n_valid; i += 256) dot += (float)pr[i] * gr[i];
+  dot = block_reduce(dot, false, sh);
+  for (int i = threadIdx.x; i < (int)ld_o; i += 256) orow[i] = (T)(i < n_valid ? alpha * (float)pr[i] * (gr[i] - dot) : 0.f);
+}
+
+// gradient of the nearest-neighbour x2 upsample (H and W): out[n][y][x][c] = sum of the 2x2 block of g [n][2H][2W][C]
+template <typename T>
+__global__ __launch_bounds__(256) void upsample2x_sum_kernel(const T* __restrict__ g, long long N, int H, int W, int C,
+                                                             T* __restrict__ out) {
+  const int cv = C >> 3;
+  const long long nvec = N * H * W * cv;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+    const int c0 = (int)(v % cv) * 8;
+    long long pix = v / cv;
+    const int xo = (int)(pix % W);
+    pix /= W;
+    const int yo = (int)(pix % H);
+    const long long n = pix / H;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      float f[8];
+      ld8<T>(g + (((n * 2 * H + 2 * yo + (d >> 1)) * 2 * W) + 2 * xo + (d & 1)) * C + c0, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    st8<T>(out + ((n * H + yo) * W + xo) * C + c0, acc);
+  }
+}
+
+static inline int gn_bwd_splits(long long S) {  // >= 2048 pixels per split: the per-split reduction stays a small share
+  const long long n = (S + 2047) / 2048;
+  return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+}
+template <typename T>
+static void gn_bwd_launch(const void* x, const void* gy, const void* add, int rows, long long S, int C, int G, const float* rs,
+                          const float* nm, const float* gamma, const float* beta, int silu, void* gx, float* ws, hipStream_t s) {
+  const int nsplit = gn_bwd_splits(S);
+  hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(nsplit, rows), dim3(256), 0, s, (const T*)x, (const T*)gy, S, C, G, nsplit, rs, nm,
+                     gamma, beta, silu, ws);
+  long long blocks = (S * (C / 8) + 255) / 256;
+  if (blocks > 2048) blocks = 2048;  // grid-stride beyond 8 blocks per CU and row
+  hipLaunchKernelGGL(gn_bwd_apply_kernel<T>, dim3((unsigned)blocks, rows), dim3(256), 0, s, (const T*)x, (const T*)gy, (const T*)add,
+                     (T*)gx, S, C, G, nsplit, rs, nm, gamma, beta, silu, ws);
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // transpose of 2-byte elements, 32x32 LDS tiles
 // ---------------------------------------------------------------------------------------------------------
 template <typename E>  // E = uint16_t (fp16 / bf16 elements) or uint32_t (float)
@@ -955,6 +1134,66 @@ int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_
     return CVVAE_EINVAL;
   hipLaunchKernelGGL(gn_finalize_slabs_kernel, dim3(groups, rows), dim3(256), 0, (hipStream_t)stream, partials, (long long)slabs,
                      groups, C, eps, gamma, beta, scale, shift);
+  CHECK_LAUNCH();
+}
+
+int64_t cvvae_gn_bwd_workspace_bytes(int32_t rows, int32_t groups, int64_t S) {
+  if (rows <= 0 || groups <= 0 || S <= 0) return 0;
+  return (int64_t)rows * gn_bwd_splits(S) * groups * 2 * (int64_t)sizeof(float);
+}
+
+int cvvae_gn_bwd_input(int32_t dtype, const void* x, const void* gy, const void* add, int32_t rows, int64_t S, int32_t C,
+                       int32_t groups, const float* rstd, const float* nmean, const float* gamma, const float* beta, int32_t silu,
+                       void* gx, void* workspace, void* stream) {
+  if (!x || !gy || !gx || !rstd || !nmean || !gamma || !beta || !workspace || rows <= 0 || S <= 0 || C <= 0) return CVVAE_EINVAL;
+  // 8-channel vectors that tile a 256-thread block; channel quads inside one group
+  if (groups <= 0 || groups > 64 || C % groups || (C / groups) % 4 || C % 8 || C > 2048 || 256 % (C / 8)) return CVVAE_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    gn_bwd_launch<__bf16>(x, gy, add, rows, S, C, groups, rstd, nmean, gamma, beta, silu, gx, (float*)workspace, s);
+  else if (dtype == CVVAE_F16)
+    gn_bwd_launch<_Float16>(x, gy, add, rows, S, C, groups, rstd, nmean, gamma, beta, silu, gx, (float*)workspace, s);
+  else if (dtype == CVVAE_F32)
+    gn_bwd_launch<float>(x, gy, add, rows, S, C, groups, rstd, nmean, gamma, beta, silu, gx, (float*)workspace, s);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_softmax_bwd_rows(int32_t dtype, const void* p, int64_t ld_p, const float* gp, int64_t ld_g, int64_t rows, int32_t n_valid,
+                           float alpha, void* gs, int64_t ld_o, void* stream) {
+  if (!p || !gp || !gs || rows <= 0 || n_valid <= 0 || ld_p < n_valid || ld_g < n_valid || ld_o < n_valid) return CVVAE_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<__bf16>, dim3((unsigned)rows), dim3(256), 0, s, (const __bf16*)p, (long long)ld_p, gp,
+                       (long long)ld_g, n_valid, alpha, (__bf16*)gs, (long long)ld_o);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<_Float16>, dim3((unsigned)rows), dim3(256), 0, s, (const _Float16*)p, (long long)ld_p,
+                       gp, (long long)ld_g, n_valid, alpha, (_Float16*)gs, (long long)ld_o);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(softmax_bwd_rows_kernel<float>, dim3((unsigned)rows), dim3(256), 0, s, (const float*)p, (long long)ld_p, gp,
+                       (long long)ld_g, n_valid, alpha, (float*)gs, (long long)ld_o);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_upsample2x_sum(int32_t dtype, const void* g, int64_t N, int32_t H, int32_t W, int32_t C, void* out, void* stream) {
+  if (!g || !out || N <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return CVVAE_EINVAL;
+  long long blocks = ((long long)N * H * W * (C / 8) + 255) / 256;
+  if (blocks > 256LL * 64) blocks = 256LL * 64;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(upsample2x_sum_kernel<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, (const __bf16*)g, (long long)N, H, W, C,
+                       (__bf16*)out);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL(upsample2x_sum_kernel<_Float16>, dim3((unsigned)blocks), dim3(256), 0, s, (const _Float16*)g, (long long)N, H, W,
+                       C, (_Float16*)out);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL(upsample2x_sum_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)g, (long long)N, H, W, C,
+                       (float*)out);
+  else
+    return CVVAE_EINVAL;
   CHECK_LAUNCH();
 }
 

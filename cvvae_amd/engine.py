@@ -51,6 +51,24 @@ class WeightCache:
         self._c[tag] = (key, pw)
         return pw
 
+    def conv_dgrad(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None) -> ops.PackedConv:
+        """The weights of the INPUT-GRADIENT convolution of a stride-1, zero-padded conv (or linear layer) `pre`: taps flipped,
+        Cin and Cout exchanged, no bias -- conv(gy, conv_dgrad(pre)) with the forward's padding is autograd's grad_input
+        (cvvae_amd/grad.py).  k: the forward kernel, (1,1,1) for nn.Linear / 1x1 weights."""
+        w = self.m.get_parameter(pre + ".weight")
+        key = self._key(w)
+        tag = f"{pre}#dgrad"
+        hit = self._c.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        taps = k[0] * k[1] * k[2]
+        co, ci = w.shape[0], w.shape[1]
+        assert w.numel() == co * ci * taps, f"{pre}: weight {tuple(w.shape)} is not a {k} kernel"
+        wt = w.detach().reshape(co, ci, taps).flip(2).transpose(0, 1).contiguous()  # [ci, co, taps], taps reversed = flipped in every axis
+        pw = ops.pack_weight(wt, None, k, cin_pad=cin_pad)
+        self._c[tag] = (key, pw)
+        return pw
+
     def conv_upfold(self, pre: str, tfold: int = 0, time_folds: bool = False) -> ops.PackedConv:
         """Upsample3D conv weights folded into the four 3x2x2 (tfold: 1x2x2) phase kernels (ops.pack_weight_upfold)."""
         w = self.m.get_parameter(pre + ".weight")
@@ -261,7 +279,7 @@ def _norm(wc: WeightCache, x: torch.Tensor, part, pre: str, eps: float):
 # single-head spatial self-attention per frame (both families)
 # --------------------------------------------------------------------------------------------------------
 def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: str, v: str, proj: str, eps: float,
-                      residual: bool, gn_out: int = 0):
+                      residual: bool, gn_out: int = 0, tape: Optional[list] = None):
     """sd3: AttentionWithExtraDim (vae_blocks3d_sd3.py:119-147) over diffusers Attention.
     vae3d: MemoryEfficientAttnBlock.attention + proj_out (vae_models.py:500-537).
     Per frame: GN(32) over (C/32, H*W) -> q,k,v (1x1) -> softmax(q k^T / sqrt(C)) v -> proj (+ x)."""
@@ -283,6 +301,8 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
     p = ops.softmax_rows(s.view(B * T * N, npad), N, x.dtype)                                  # [BT*N, npad]
     vp = ops.pack_weight_batched(vt, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
     o = ops.conv(p.view(B * T, 1, 1, N, npad), vp)                                             # [BT,1,1,N,C]
+    if tape is not None:  # what the input-gradient pass (grad.py) needs again
+        tape.append(dict(op="attn", x=x, qq=qq, kk=kk, vv=vv, p=p, names=(norm, q, k, v, proj), eps=eps, residual=residual))
     return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 
@@ -370,20 +390,23 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------------
 # the frozen 2-D "constraint" decoder of the training path (SD3 image VAE decoder per frame)
 # --------------------------------------------------------------------------------------------------------
-def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool = True):
+def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool = True, tape: Optional[list] = None):
     """ResnetBlock2D.forward, lvdm/modules/diffusionmodules/vae_blocks_sd3.py:368-421, on [frames,1,H,W,C]: GN(eps 1e-6)+SiLU
     fused into conv1 and conv2 (per-frame 3x3, zero pad), 1x1 shortcut and residual add in conv2's launch."""
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
     h, hp = ops.conv(x, wc.conv(pre + ".conv1", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g1,
                      gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
+    if tape is not None:
+        tape.append(dict(op="resnet", pre=pre, x=x, xp=xp, h=h, hp=hp))
     return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
 
 
-def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
+def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
     """DecoderWith3DWrapper.forward over Decoder.forward (lvdm/modules/diffusionmodules/vae_models_sd3.py:297-362, 390-398):
     z NCDHW [b,c,t,h,w] -> pixels [b,3,t,8h,8w], every frame decoded on its own ("b c t h w -> (b t) c h w": frames are the
-    batch rows here, so every GroupNorm is per frame as in the reference)."""
+    batch rows here, so every GroupNorm is per frame as in the reference).  tape: a list that receives what the input-gradient
+    pass of the frozen decoder (grad.constraint_decoder2d_backward) reads again."""
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     boc = cfg["block_out_channels"]
     B, zin, T = z.shape[0], z.shape[1], z.shape[2]
@@ -392,19 +415,23 @@ def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.T
     h = h.view(B * T, 1, h.shape[2], h.shape[3], cpad)
     h, hp = ops.conv(h, wc.conv("conv_in", (1, 3, 3), cin_pad=cpad), pad=P2D, pad_mode_hw=ZERO, gn_out=G32)
     attn = cfg["mid_block_add_attention"]
-    h, hp = c2d_resnet(wc, h, hp, "mid_block.resnets.0", want_stats=not attn)  # UNetMidBlock2D.forward, vae_blocks_sd3.py:669-681
+    h, hp = c2d_resnet(wc, h, hp, "mid_block.resnets.0", want_stats=not attn, tape=tape)  # UNetMidBlock2D.forward, vae_blocks_sd3.py:669-681
     if attn:
         a = "mid_block.attentions.0"
         h, hp = spatial_attention(wc, h, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True,
-                                  gn_out=G32)
-    h, hp = c2d_resnet(wc, h, hp, "mid_block.resnets.1")
+                                  gn_out=G32, tape=tape)
+    h, hp = c2d_resnet(wc, h, hp, "mid_block.resnets.1", tape=tape)
     for i in range(len(boc)):  # UpDecoderBlock2D.forward, vae_blocks_sd3.py:536-547
         for j in range(cfg["layers_per_block"] + 1):
-            h, hp = c2d_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}")
+            h, hp = c2d_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}", tape=tape)
         if i != len(boc) - 1:  # Upsample2D.forward :178-230: nearest x2 + conv 3x3 (zero pad), as four folded 1x2x2 phase convs
+            if tape is not None:
+                tape.append(dict(op="up", pre=f"up_blocks.{i}.upsamplers.0.conv"))
             h, hp = ops.conv(h, wc.conv_upfold2d(f"up_blocks.{i}.upsamplers.0.conv"), pad=P2D, pad_mode_hw=ZERO, upsample2x=2,
                              gn_out=G32)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
+    if tape is not None:
+        tape.append(dict(op="out", x=h, xp=hp, B=B, T=T, zin=zin))
     y = ops.conv(h, wc.conv("conv_out", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g,
                  out_mode=L.OUT_NCDHW)                      # [b*t, 3, 1, H, W]
     return y.view(B, T, y.shape[1], y.shape[3], y.shape[4]).transpose(1, 2).contiguous()

@@ -74,8 +74,7 @@ class _Net(nn.Module):
             object.__setattr__(self, "_wc", engine.WeightCache(self))
         return self._wc
 
-    @torch.no_grad()
-    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+    def _check_input(self, x: torch.Tensor):
         if x.dim() != 5:
             raise ValueError(f"expected a [B,C,T,H,W] tensor, got shape {tuple(x.shape)}")
         if self._unsupported:
@@ -86,6 +85,10 @@ class _Net(nn.Module):
         pdev = self.conv_in.weight.device
         if pdev != x.device:
             raise RuntimeError(f"input on {x.device} but the network's parameters are on {pdev}")
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
+        self._check_input(x)
         # every launch of the pass goes to x's device and its current stream, whatever the caller's current device is
         with torch.cuda.device(x.device):
             if self._graphs is not None and not torch.cuda.is_current_stream_capturing():

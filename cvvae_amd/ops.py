@@ -398,15 +398,70 @@ def softmax_rows(s: torch.Tensor, n_valid: int, dtype: torch.dtype, ld_p: Option
     return p
 
 
-def transpose(x: torch.Tensor) -> torch.Tensor:
-    """x: [batch, R, C] contiguous -> [batch, C, R]."""
+def transpose(x: torch.Tensor, ncols: Optional[int] = None, ld_out: Optional[int] = None) -> torch.Tensor:
+    """x: [batch, R, ld] contiguous -> [batch, ncols, ld_out]: the transpose of x[:, :, :ncols] (default: all columns) with rows
+    padded to ld_out >= R elements (default R); the padding reads as zero."""
     lib = L.load()
     _need_gpu(x)
     assert x.dim() == 3 and x.is_contiguous()
-    b, R, C = x.shape
-    out = torch.empty((b, C, R), dtype=x.dtype, device=x.device)
-    L.check(lib.cvvae_transpose(_dt(x.dtype), x.data_ptr(), b, R, C, C, R * C, out.data_ptr(), R, R * C, _stream(x)),
+    b, R, ld = x.shape
+    C = ld if ncols is None else ncols
+    ldo = R if ld_out is None else ld_out
+    assert 0 < C <= ld and ldo >= R
+    out = (torch.empty if ldo == R else torch.zeros)((b, C, ldo), dtype=x.dtype, device=x.device)
+    L.check(lib.cvvae_transpose(_dt(x.dtype), x.data_ptr(), b, R, C, ld, R * ld, out.data_ptr(), ldo, C * ldo, _stream(x)),
             "cvvae_transpose")
+    return out
+
+
+def gn_bwd_input(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Tensor, torch.Tensor], gamma: torch.Tensor,
+                 beta: torch.Tensor, silu: bool, add: Optional[torch.Tensor] = None, per_frame: bool = False,
+                 groups: int = 32) -> torch.Tensor:
+    """Gradient w.r.t. x of act(GroupNorm(x)) given gy = dL/d(act(...)) (cvvae_gn_bwd_input): x, gy, add [B,T,H,W,C];
+    tabs = (rstd, -mean*rstd) fp32 tables [rows, C] = gn_finalize / gn_stats with gamma 1, beta 0; gamma / beta fp32 [C].
+    `add` is summed into the result (the skip branch of a residual block)."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape and gy.dtype == x.dtype
+    B, T, H, W, C = x.shape
+    rows, S = (B * T, H * W) if per_frame else (B, T * H * W)
+    rs, nm = tabs
+    assert rs.dtype == torch.float32 and tuple(rs.shape) == (rows, C) and tuple(nm.shape) == (rows, C)
+    assert rs.is_contiguous() and nm.is_contiguous() and gamma.dtype == torch.float32 and gamma.numel() == C and beta.numel() == C
+    if add is not None:
+        assert add.shape == x.shape and add.dtype == x.dtype and add.is_contiguous()
+    out = torch.empty_like(x)
+    ws = torch.empty(max(int(lib.cvvae_gn_bwd_workspace_bytes(rows, groups, S)), 16), dtype=torch.uint8, device=x.device)
+    L.check(lib.cvvae_gn_bwd_input(_dt(x.dtype), x.data_ptr(), gy.data_ptr(), add.data_ptr() if add is not None else None, rows, S, C,
+                                   groups, rs.data_ptr(), nm.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0,
+                                   out.data_ptr(), ws.data_ptr(), _stream(x)), "cvvae_gn_bwd_input")
+    return out
+
+
+def softmax_bwd_rows(p: torch.Tensor, gp: torch.Tensor, n_valid: int, alpha: float, ld_o: Optional[int] = None) -> torch.Tensor:
+    """p: [rows, ld_p] probabilities (softmax_rows), gp: [rows, ld_g] fp32 -> alpha * p * (gp - rowsum(p * gp)) as [rows, ld_o] of
+    p's dtype, columns >= n_valid written as 0."""
+    lib = L.load()
+    _need_gpu(p)
+    assert p.dim() == 2 and gp.dim() == 2 and p.is_contiguous() and gp.is_contiguous() and gp.dtype == torch.float32
+    assert p.shape[0] == gp.shape[0]
+    rows, ld_p = p.shape
+    ld_o = ld_p if ld_o is None else ld_o
+    out = torch.empty((rows, ld_o), dtype=p.dtype, device=p.device)
+    L.check(lib.cvvae_softmax_bwd_rows(_dt(p.dtype), p.data_ptr(), ld_p, gp.data_ptr(), gp.shape[1], rows, n_valid, float(alpha),
+                                       out.data_ptr(), ld_o, _stream(p)), "cvvae_softmax_bwd_rows")
+    return out
+
+
+def upsample2x_sum(g: torch.Tensor) -> torch.Tensor:
+    """g: [N,1,2H,2W,C] -> [N,1,H,W,C]: the gradient of the nearest-neighbour x2 upsample (sum over every 2x2 block)."""
+    lib = L.load()
+    _need_gpu(g)
+    assert g.dim() == 5 and g.shape[1] == 1 and g.is_contiguous() and g.shape[2] % 2 == 0 and g.shape[3] % 2 == 0
+    N, _, H2, W2, C = g.shape
+    out = torch.empty((N, 1, H2 // 2, W2 // 2, C), dtype=g.dtype, device=g.device)
+    L.check(lib.cvvae_upsample2x_sum(_dt(g.dtype), g.data_ptr(), N, H2 // 2, W2 // 2, C, out.data_ptr(), _stream(g)),
+            "cvvae_upsample2x_sum")
     return out
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 6
+#define CVVAE_ABI_VERSION 7
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
@@ -201,6 +201,41 @@ int cvvae_gn_stats(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_
  */
 int cvvae_gn_silu_apply(int32_t dtype, const void* x, int32_t rows, int64_t S, int32_t C, int64_t pix_stride,
                         const float* scale, const float* shift, int32_t silu, void* out, void* stream);
+
+/*
+ * Input gradients through a FROZEN module (training-side codec use): the reference back-propagates the
+ * latent-compatibility loss through the frozen 2-D constraint decoder into the latents (lvdm/models/autoencoder.py:1057-1069:
+ * `self.constraint_decoder.requires_grad_(False)`, `xrec_2d = self.constraint_decoder(z)`), i.e. autograd's input-gradient
+ * formulas of the decoder's ops with no weight gradients.  The convolutions' input gradients run on cvvae_conv_fwd* with
+ * transposed, tap-flipped weights (cvvae_amd/grad.py); the three entries below are the remaining pieces.
+ *
+ * cvvae_gn_bwd_input: gradient w.r.t. x of  y = act(GroupNorm(x))  (act = SiLU when silu != 0), replacing
+ * aten::native_group_norm_backward's input gradient (+ aten::silu_backward).  x, gy, gx (and the optional `add`, summed into the
+ * result: the skip branch of a residual block) are [rows][S][C] tensors of `dtype`; rstd / nmean are the fp32 tables [rows][C]
+ * cvvae_gn_finalize / cvvae_gn_stats produce with gamma = 1, beta = 0 (scale = rstd, shift = -mean * rstd); gamma / beta [C] the
+ * module's affine parameters.  Statistics are taken per row over its S pixels and C / groups channels.  Deterministic (two passes,
+ * partial sums merged in index order).  workspace: cvvae_gn_bwd_workspace_bytes(rows, groups, S) bytes.
+ * Constraints: C % 8 == 0, (C / groups) % 4 == 0, 256 % (C / 8) == 0, groups <= 64 (else CVVAE_EUNSUPPORTED).
+ */
+int64_t cvvae_gn_bwd_workspace_bytes(int32_t rows, int32_t groups, int64_t S);
+int cvvae_gn_bwd_input(int32_t dtype, const void* x, const void* gy, const void* add, int32_t rows, int64_t S, int32_t C,
+                       int32_t groups, const float* rstd, const float* nmean, const float* gamma, const float* beta, int32_t silu,
+                       void* gx, void* workspace, void* stream);
+
+/*
+ * Gradient of the row softmax of the attention blocks (aten::_softmax_backward_data + the score scale):
+ * gs[r][j] = alpha * p[r][j] * (gp[r][j] - sum_k p[r][k] * gp[r][k]) for j < n_valid, 0 for n_valid <= j < ld_o.
+ * p: probabilities [rows][ld_p] of `dtype` (cvvae_softmax_rows' output), gp: fp32 [rows][ld_g], gs: [rows][ld_o] of `dtype`.
+ */
+int cvvae_softmax_bwd_rows(int32_t dtype, const void* p, int64_t ld_p, const float* gp, int64_t ld_g, int64_t rows, int32_t n_valid,
+                           float alpha, void* gs, int64_t ld_o, void* stream);
+
+/*
+ * Gradient of the nearest-neighbour x2 upsample in H and W (aten::upsample_nearest2d_backward, Upsample2D of
+ * lvdm/modules/diffusionmodules/vae_blocks_sd3.py:178-230): out[n][y][x][c] = sum of g[n][2y+{0,1}][2x+{0,1}][c]; g is
+ * [N][2H][2W][C], out [N][H][W][C], C % 8 == 0.
+ */
+int cvvae_upsample2x_sum(int32_t dtype, const void* g, int64_t N, int32_t H, int32_t W, int32_t C, void* out, void* stream);
 
 /* LayerNorm over C for every pixel (vae3d temporal attention, models/vae_models.py:571,575). in/out [P][C]. */
 int cvvae_layernorm(int32_t dtype, const void* x, int64_t P, int32_t C, float eps, const float* gamma, const float* beta,
