@@ -1,7 +1,9 @@
-"""Test infrastructure: a plain-PyTorch (CPU, fp32) stand-in for the subset of `cvvae_amd.ops` that the 2-D constraint decoder
-and its input-gradient pass call, so that the HOST logic of engine.constraint_decoder2d / grad.constraint_decoder2d_backward
-(what is taped, which weights are transposed, which tensor feeds which launch) is checked against torch.autograd without a GPU.
-It emulates each op's documented arithmetic -- it is not a fallback: nothing in the product imports it (tests only)."""
+"""Test infrastructure: a plain-PyTorch (CPU, fp32) stand-in for `cvvae_amd.ops`, so that the HOST logic above the C ABI -- the
+launch programs of engine.py (which tensor, weight form, padding, prologue, epilogue and output mode every launch gets), the
+window / tile wrappers of modeling.py and the input-gradient pass of grad.py -- is checked without a GPU against the reference's
+golden vectors and torch.autograd.  Each function restates the documented arithmetic of one op (include/cvvae.h); the folded
+weight forms (time folds, single-frame folds, folded upsample) are emulated by the unfolded convolution they equal.
+It is not a fallback: nothing in the product imports it (tests only)."""
 import contextlib
 from dataclasses import dataclass
 from typing import Optional
@@ -52,11 +54,33 @@ def pack_weight(w, bias, k, cin_pad=None, strides=None, cout=None, cin=None, fol
     return FakePacked(w.detach().float().reshape(co, ci, taps), _bias(co, bias, w.device), co, cp, tuple(k), ci)
 
 
+def pack_weight_tfolds(w, bias, cin_pad=None):
+    """the summed time slots only change HOW boundary frames are multiplied, not the result: the plain weight"""
+    co, ci, _, kh, kw = w.shape
+    pw = pack_weight(w.reshape(co, ci, 3 * kh * kw), bias, (3, kh, kw), cin_pad=cin_pad)
+    pw.time_folds = True
+    return pw
+
+
+def pack_weight_t1(w, bias, mode, cin_pad=None):
+    """a single-frame input under replicate ('sum': all three time taps read the frame) / zero ('center') time padding"""
+    co, ci, _, kh, kw = w.shape
+    w2 = w.detach().float().sum(2) if mode == "sum" else w.detach().float()[:, :, 1]
+    pw = pack_weight(w2.reshape(co, ci, kh * kw), bias, (1, kh, kw), cin_pad=cin_pad)
+    pw.alg_taps = 3 * kh * kw
+    return pw
+
+
 def pack_weight_upfold(w, bias, tfold=0, time_folds=False):
-    assert tfold == 2 and not time_folds  # Upsample2D: the centre time tap of an otherwise zero 3x3x3 weight
+    """nearest-2x + conv with the phase-folded weights == the conv of the upsampled tensor with the plain weight"""
     co, ci = w.shape[0], w.shape[1]
-    return FakePacked(w.detach().float()[:, :, 1].reshape(co, ci, 9), _bias(co, bias, w.device), co, ops.round_up(ci, 32), (1, 3, 3),
-                      ci, folded=True)
+    wf = w.detach().float().reshape(co, ci, 3, 3, 3)
+    if tfold == 0:
+        raw, k = wf.reshape(co, ci, 27), (3, 3, 3)
+    else:
+        raw, k = (wf.sum(2) if tfold == 1 else wf[:, :, 1]).reshape(co, ci, 9), (1, 3, 3)
+    return FakePacked(raw, _bias(co, bias, w.device), co, ops.round_up(ci, 32), k, ci, folded=True, time_folds=time_folds,
+                      alg_taps=27)
 
 
 def pack_weight_batched(w, k, cin_pad, strides, cout, cin):
@@ -95,10 +119,20 @@ def gn_finalize(part, gamma, beta, eps):
     return _tables(part.x, gamma, beta, eps, part.groups, False)
 
 
+def _pad3(f, pad, mode_t, mode_hw):
+    """f [B,C,T,H,W]: pad H and W (zero / replicate), then T (zero / replicate) -- the order of the reference's F.pad calls"""
+    (tf, tb), (hf, hb), (wf, wb) = pad
+    if hf or hb or wf or wb:
+        f = F.pad(f, (wf, wb, hf, hb, 0, 0), mode="replicate") if mode_hw == L.PAD_REPLICATE else F.pad(f, (wf, wb, hf, hb))
+    if tf or tb:
+        f = F.pad(f, (0, 0, 0, 0, tf, tb), mode="replicate") if mode_t == L.PAD_REPLICATE else F.pad(f, (0, 0, 0, 0, tf, tb))
+    return f
+
+
 def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO,
          prologue=L.PRO_NONE, gn=None, gn_per_frame=False, residual=None, upsample2x=False, out_mode=L.OUT_NDHWC, shortcut=None,
          bias=None, out_f32=False, alpha=1.0, out=None, cout_pad=None, gn_out=0):
-    assert stride == (1, 1, 1) and pad_mode_hw == L.PAD_ZERO and pw.folded == (upsample2x == 2)
+    assert pw.folded == (upsample2x == 2)
     B, T, H, W, Cs = x.shape
     assert Cs >= pw.cin, (Cs, pw.cin)
     a = x.float()[..., :pw.cin_real]
@@ -111,20 +145,15 @@ def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.
         if prologue == L.PRO_GN_SILU:
             a = F.silu(a)
         a = a.to(x.dtype).float()  # the kernel stages the activation in the storage dtype
-    if pw.k == (1, 3, 3):
-        assert pad == ((0, 0), (1, 1), (1, 1)) and pw.batch_stride == 0
-        f = a.reshape(B * T, H, W, -1).permute(0, 3, 1, 2)
-        if upsample2x:
-            f = F.interpolate(f, scale_factor=2.0, mode="nearest")
-        y = F.conv2d(f, pw.w.reshape(pw.cout, pw.cin_real, 3, 3), None, padding=1).permute(0, 2, 3, 1)
-        y = y.reshape(B, T, y.shape[1], y.shape[2], pw.cout)
+    if pw.batch_stride:
+        assert pw.k == (1, 1, 1) and pw.w.shape[0] == B
+        y = torch.einsum("bthwc,boc->bthwo", a, pw.w)
     else:
-        assert pw.k == (1, 1, 1) and pad == ((0, 0), (0, 0), (0, 0))
-        if pw.batch_stride:
-            assert pw.w.shape[0] == B
-            y = torch.einsum("bthwc,boc->bthwo", a, pw.w)
-        else:
-            y = a @ pw.w[:, :, 0].t()
+        f = a.permute(0, 4, 1, 2, 3)
+        if upsample2x:
+            f = F.interpolate(f, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+        f = _pad3(f, pad, pad_mode_t, pad_mode_hw)
+        y = F.conv3d(f, pw.w.reshape(pw.cout, pw.cin_real, *pw.k), None, stride=stride).permute(0, 2, 3, 4, 1)
     y = y * alpha + (pw.bias if bias is None else bias)[:pw.cout]
     if shortcut is not None:
         x2, pw2 = shortcut
@@ -132,16 +161,67 @@ def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.
     if residual is not None:
         y = y + residual.float()
     odt = torch.float32 if out_f32 else x.dtype
+    cst = pw.cout
     if out_mode == L.OUT_NCDHW:
         res = y.permute(0, 4, 1, 2, 3).contiguous().to(odt)
+    elif out_mode == L.OUT_TIME_SHUFFLE:  # "b (n c) t h w -> b c (t n) h w", then frame 0 dropped (vae_blocks3d_sd3.py:358-362)
+        cst = pw.cout // 2
+        Bo, To, Ho, Wo, _ = y.shape
+        res = y.reshape(Bo, To, Ho, Wo, 2, cst).permute(0, 1, 4, 2, 3, 5).reshape(Bo, 2 * To, Ho, Wo, cst)[:, 1:].contiguous().to(odt)
     else:
-        assert out_mode == L.OUT_NDHWC
         cp = pw.cout if cout_pad is None else cout_pad
         res = torch.zeros(*y.shape[:-1], cp, dtype=odt)
         res[..., :pw.cout] = y.to(odt)
     if gn_out:
-        return res, FakePart(res, B, pw.cout, gn_out)
+        return res, FakePart(res, B, cst, gn_out)
     return res
+
+
+def gn_silu_apply(x, gn, silu=True, per_frame=False):
+    B, T, H, W, C = x.shape
+    sc, sh = gn
+    shape = (B, T, 1, 1, C) if per_frame else (B, 1, 1, 1, C)
+    a = x.float() * sc.reshape(shape) + sh.reshape(shape)
+    return (F.silu(a) if silu else a).to(x.dtype)
+
+
+def layernorm(x, gamma, beta, eps):
+    return F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)
+
+
+def temporal_attention(q, k, v):
+    """[B,T,H,W,C]: softmax(q k^T / sqrt(C)) v over the T frames of every pixel"""
+    qf, kf, vf = (t.float().permute(0, 2, 3, 1, 4) for t in (q, k, v))  # [B,H,W,T,C]
+    p = torch.softmax(qf @ kf.transpose(-1, -2) * (q.shape[-1] ** -0.5), -1)
+    return (p @ vf).permute(0, 3, 1, 2, 4).contiguous().to(q.dtype)
+
+
+def ndhwc_to_ncdhw(x, c):
+    return x[..., :c].permute(0, 4, 1, 2, 3).contiguous()
+
+
+def frames_u8_to_ndhwc(frames, cpad, dtype):
+    """uint8 [T,H,W,3] -> [1,T,H,W,cpad]: u8 -> dtype, / 127.5, - 1.0 with the scripts' rounding steps (cvvae_inference_video.py:34)"""
+    T, H, W, _ = frames.shape
+    out = torch.zeros(1, T, H, W, cpad, dtype=dtype)
+    out[0, ..., :3] = frames.to(dtype) / 127.5 - 1.0
+    return out
+
+
+def ncdhw_to_frames_u8(x):
+    """[1,3,T,H,W] -> uint8 [T,H,W,3] = u8((clamp(x, -1, 1) + 1) * 127.5) (cvvae_inference_video.py:47-50)"""
+    return ((torch.clamp(x[0], -1.0, 1.0) + 1.0) * 127.5).to(torch.uint8).permute(1, 2, 3, 0).contiguous()
+
+
+def blend_(a, b, overlap, axis):
+    """in place on b (NCDHW): b[.., :o] = (1 - w) * a[.., -o:] + w * b[.., :o], w = arange(o) / o in fp32 (modeling_vae.py:321-341)"""
+    w = torch.arange(overlap, dtype=torch.float32) / overlap
+    if axis == 0:
+        w = w[:, None]
+        b[:, :, :, :overlap] = ((1 - w) * a[:, :, :, -overlap:].float() + w * b[:, :, :, :overlap].float()).to(b.dtype)
+    else:
+        b[..., :overlap] = ((1 - w) * a[..., -overlap:].float() + w * b[..., :overlap].float()).to(b.dtype)
+    return b
 
 
 def softmax_rows(s, n_valid, dtype, ld_p=None):
@@ -197,17 +277,36 @@ def upsample2x_sum(g):
     return g.float().reshape(N, 1, H2 // 2, 2, W2 // 2, 2, C).sum((3, 5)).to(g.dtype)
 
 
-_NAMES = ["pack_weight", "pack_weight_upfold", "pack_weight_batched", "gn_stats", "gn_finalize", "conv", "softmax_rows",
-          "transpose", "ncdhw_to_ndhwc", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
+_NAMES = ["pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
+          "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "temporal_attention", "ncdhw_to_ndhwc",
+          "ndhwc_to_ncdhw", "blend_", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
 
 
 @contextlib.contextmanager
-def patched():
+def patched(whole_model: bool = False):
+    """ops.* replaced by the emulations; whole_model: also lets the wrapper classes (modeling._Net / the tile blends) accept CPU
+    tensors -- their `is_cuda` guards and torch.cuda.device contexts are the only things between them and the emulated ops."""
+    from cvvae_amd import modeling
     saved = {n: getattr(ops, n) for n in _NAMES}
+    saved_check, saved_dev, saved_blend = modeling._Net._check_input, torch.cuda.device, modeling._CVVAEBase.__dict__["_blend"]
     try:
         for n in _NAMES:
             setattr(ops, n, globals()[n])
+        if whole_model:
+            modeling._Net._check_input = lambda self, x: None
+            torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
+
+            def _blend(a, b, o, axis):
+                bc = b.contiguous()
+                ops.blend_(a.contiguous(), bc, o, axis)
+                if bc is not b:
+                    b.copy_(bc)
+                return b
+            modeling._CVVAEBase._blend = staticmethod(_blend)
         yield
     finally:
         for n, f in saved.items():
             setattr(ops, n, f)
+        modeling._Net._check_input = saved_check
+        torch.cuda.device = saved_dev
+        modeling._CVVAEBase._blend = saved_blend

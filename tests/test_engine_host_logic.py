@@ -1,0 +1,94 @@
+"""CPU check of the HOST logic above the C ABI -- the window / tile wrappers of modeling.py and the launch programs of engine.py --
+against the reference's golden vectors: the real CVVAEModel / CVVAESD3Model classes run end to end with every kernel replaced by a
+plain-PyTorch emulation of its documented arithmetic (tests/emu_ops.py).  What this pins without a GPU: which tensor, weight form
+(plain / time folds / single-frame fold / folded upsample / fused shortcut), padding, prologue, epilogue and output mode every launch
+gets; the 17-frame windows, the 576/448 tiles and their blends; the posterior; the u8 pre/post-processing plumbing.  The kernels
+themselves are compared with the same fixtures on the GPU (tests/test_gpu_model.py)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle.golden_cases import CASES, CONSTRAINT_CASES
+from oracle.seeded import seeded_input, seeded_state_dict
+from tests import emu_ops
+
+TOL = 2e-4  # fp32 against the reference's fp32 fixtures: summation order only (measured <= 6e-5)
+
+
+_SD = {}
+
+
+def build(family, over, wseed):
+    import cvvae_amd
+    cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
+    m = cls(**over)
+    if (family, wseed) not in _SD:  # the seeded weights depend on names and shapes only
+        _SD[(family, wseed)] = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, wseed)
+    m.load_state_dict(_SD[(family, wseed)], strict=True)
+    return m.eval()
+
+
+@pytest.mark.parametrize("name", sorted(n for n in CASES if n != "vae3d_tiled_t5_160x200"))  # (tiles: the sd3 case; 18 s apiece)
+def test_models_match_reference_golden_through_emulated_kernels(name, golden_dir):
+    family, over, shape, wseed, xseed = CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = build(family, over, wseed)
+    x = seeded_input(shape, xseed)
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        post = m.encode(x).latent_dist
+        rec = m.decode(post.mode()).sample
+    assert np.abs(post.parameters.numpy() - gold["moments"]).max() <= TOL
+    assert np.abs(rec.numpy() - gold["recon"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name,env", [("sd3_t1_64", {"CVVAE_FOLD_T1": "0"}), ("sd3_t1_64", {"CVVAE_FOLD_UPSAMPLE": "0"}),
+                                      ("vae3d_t5_64", {"CVVAE_FUSE_SHORTCUT": "0"}), ("sd3_t5_64", {"CVVAE_FOLD_TIME": "0"}),
+                                      ("vae3d_t5_64", {"CVVAE_PREPASS": "1"}), ("sd3_t5_64", {"CVVAE_FOLD_UPSAMPLE": "0"})])
+def test_alternative_launch_programs_agree(name, env, golden_dir, monkeypatch):
+    """every tuning switch of engine.py selects another launch sequence for the same arithmetic"""
+    family, over, shape, wseed, xseed = CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    m = build(family, over, wseed)
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        post = m.encode(seeded_input(shape, xseed)).latent_dist
+        rec = m.decode(post.mode()).sample
+    assert np.abs(post.parameters.numpy() - gold["moments"]).max() <= TOL and np.abs(rec.numpy() - gold["recon"]).max() <= TOL
+
+
+@pytest.mark.parametrize("name", sorted(CONSTRAINT_CASES))
+def test_constraint_decoder_matches_reference_golden_through_emulated_kernels(name, golden_dir):
+    from cvvae_amd.constraint import DecoderWith3DWrapper
+    cfg, zshape, wseed, zseed = CONSTRAINT_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    m = DecoderWith3DWrapper(**cfg)
+    m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, wseed), strict=True)
+    m = m.eval().requires_grad_(False)
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        rec = m(seeded_input(zshape, zseed))
+    assert np.abs(rec.numpy() - gold["recon"]).max() <= TOL
+
+
+def test_forward_latents_and_u8_plumbing():
+    """forward(), encode_latents() and the u8 entry points are compositions of encode / decode: same numbers"""
+    m = build("sd3", {}, 4)
+    x = seeded_input((2, 3, 5, 32, 32), 12)
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        post = m.encode(x).latent_dist
+        assert torch.equal(m(x).sample, m.decode(post.mode()).sample)
+        g = torch.Generator().manual_seed(3)
+        zs = post.sample(generator=torch.Generator().manual_seed(3))
+        assert torch.equal(m(x, sample_posterior=True, generator=g, return_dict=False)[0], m.decode(zs).sample)
+        lat = m.encode_latents(x, sample=False, n_samples_a_time=1, scale_factor=0.5)
+        assert torch.allclose(lat, 0.5 * post.mode(), atol=1e-4)  # (per-sample rounds: another summation order on the CPU)
+        # u8 frames: the scripts' normalisation, then encode; decode, then the scripts' clamp/scale/u8
+        frames = (torch.rand(5, 32, 32, 3, generator=torch.Generator().manual_seed(1)) * 255).to(torch.uint8)
+        xs = (frames.permute(3, 0, 1, 2).unsqueeze(0).float() / 127.5 - 1.0)
+        zu = m.encode_frames_u8(frames).latent_dist.mode()
+        assert torch.allclose(zu, m.encode(xs).latent_dist.mode(), atol=1e-5)
+        out = m.decode_to_frames_u8(zu)
+        ref = ((torch.clamp(m.decode(zu).sample[0], -1, 1) + 1) * 127.5).to(torch.uint8).permute(1, 2, 3, 0)
+        assert out.dtype == torch.uint8 and tuple(out.shape) == (5, 32, 32, 3) and torch.equal(out, ref)
