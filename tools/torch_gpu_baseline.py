@@ -5,6 +5,7 @@ kernels (MIOpen convolutions, native GroupNorm / SiLU / SDPA) -- "what the refer
 A measurement aid only: nothing in the product imports this.   usage (GPU box): python tools/torch_gpu_baseline.py [--dtype bf16]
 """
 import argparse, json, os, sys, time
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")  # "fast" find: the exhaustive first-call search of the 3-D convs takes > 10 minutes
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch
