@@ -48,7 +48,7 @@ class WeightCache:
             pw = ops.pack_weight_tfolds(w.detach().reshape(co, ci, *k), b.detach(), cin_pad=cin_pad)
         else:
             pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad, wscale=wscale)
-        self._c[tag] = (key, pw)
+        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
     def conv_dgrad(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None) -> ops.PackedConv:
@@ -66,7 +66,7 @@ class WeightCache:
         assert w.numel() == co * ci * taps, f"{pre}: weight {tuple(w.shape)} is not a {k} kernel"
         wt = w.detach().reshape(co, ci, taps).flip(2).transpose(0, 1).contiguous()  # [ci, co, taps], taps reversed = flipped in every axis
         pw = ops.pack_weight(wt, None, k, cin_pad=cin_pad)
-        self._c[tag] = (key, pw)
+        self._c[tag] = (key, pw, (pre + ".weight",))
         return pw
 
     def conv_upfold(self, pre: str, tfold: int = 0, time_folds: bool = False) -> ops.PackedConv:
@@ -79,7 +79,7 @@ class WeightCache:
         if hit is not None and hit[0] == key:
             return hit[1]
         pw = ops.pack_weight_upfold(w.detach(), b.detach(), tfold, time_folds=time_folds)
-        self._c[tag] = (key, pw)
+        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
     def conv_upfold2d(self, pre: str) -> ops.PackedConv:
@@ -98,7 +98,7 @@ class WeightCache:
         w3[:, :, 1] = w.detach()
         pw = ops.pack_weight_upfold(w3, b.detach(), 2)
         pw.alg_taps = 9
-        self._c[tag] = (key, pw)
+        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
     def conv_t1(self, pre: str, mode: str, cin_pad: Optional[int] = None) -> ops.PackedConv:
@@ -111,8 +111,46 @@ class WeightCache:
         if hit is not None and hit[0] == key:
             return hit[1]
         pw = ops.pack_weight_t1(w.detach(), b.detach(), mode, cin_pad=cin_pad)
-        self._c[tag] = (key, pw)
+        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
+
+    # ---- persistent packed-weight cache: the packed forms built so far, keyed by a fingerprint of their source
+    #      parameters, so that a later process with the same checkpoint installs them instead of packing again
+    @staticmethod
+    def _fingerprint(p: torch.Tensor):
+        f = p.detach().double()
+        return (tuple(p.shape), str(p.dtype), float(f.sum()), float(f.abs().sum()), float((f * f).sum()))
+
+    def export_packed(self) -> dict:
+        """{tag: {"names": source parameter names, "fp": their fingerprints, "pw": PackedConv fields}} of every packed conv weight
+        in the cache (the forms a pass actually used: run the shapes of interest once before exporting)"""
+        import dataclasses
+        out = {}
+        for tag, ent in self._c.items():
+            if len(ent) < 3 or not dataclasses.is_dataclass(ent[1]):
+                continue  # norm tables / summed biases: cheaper to rebuild than to read
+            names = ent[2]
+            out[tag] = {"names": list(names), "fp": [self._fingerprint(self.m.get_parameter(n)) for n in names],
+                        "pw": {f.name: getattr(ent[1], f.name) for f in dataclasses.fields(ent[1])}}
+        return out
+
+    def import_packed(self, blob: dict) -> int:
+        """install the exported entries whose source parameters still have the recorded fingerprints (shape, dtype, three
+        moments) on this module; the rest is packed on demand as usual.  Returns the number installed."""
+        n = 0
+        for tag, e in blob.items():
+            try:
+                ps = [self.m.get_parameter(nm) for nm in e["names"]]
+            except AttributeError:
+                continue
+            if [self._fingerprint(p) for p in ps] != [tuple(fp) if not isinstance(fp, tuple) else fp for fp in e["fp"]]:
+                continue
+            f = dict(e["pw"])
+            dev = ps[0].device
+            f["w"], f["bias"], f["k"] = f["w"].to(dev), f["bias"].to(dev), tuple(f["k"])
+            self._c[tag] = (self._key(*ps), ops.PackedConv(**f), tuple(e["names"]))
+            n += 1
+        return n
 
     def bias_sum(self, pre_a: str, pre_b: str) -> torch.Tensor:
         """fp32 b_a + b_b padded to a multiple of 32: the bias of a conv with a fused 1x1 shortcut"""

@@ -643,6 +643,28 @@ class _CVVAEBase(nn.Module):
             return (x,)
         return DecoderOutput(sample=x)
 
+    # ---- persistent packed-weight cache ("weight pre-packing cache") ----------------------------------
+    def save_packed_weights(self, path: str) -> int:
+        """Write the packed (MFMA fragment order) weight forms both networks have built so far -- i.e. after a pass over the shapes
+        of interest -- to `path` (torch.save).  The packed format is private to the library version (ABI number stored)."""
+        from . import _lib as L
+        blob = {"abi": L.ABI_VERSION, "class": type(self).__name__,
+                "nets": {n: getattr(self, n)._cache().export_packed() for n in ("encoder", "decoder")}}
+        torch.save(blob, path)
+        return sum(len(v) for v in blob["nets"].values())
+
+    def load_packed_weights(self, path: str) -> int:
+        """Install packed weights written by `save_packed_weights` for every layer whose parameters still carry the recorded
+        fingerprint (shape, dtype, three moments) -- e.g. after `from_pretrained` of the same checkpoint and `.to(dtype).cuda()`;
+        anything else (another checkpoint, another library version) is packed on demand as usual.  Returns the number installed."""
+        from . import _lib as L
+        blob = torch.load(path, map_location="cpu", weights_only=True)
+        if blob.get("abi") != L.ABI_VERSION or blob.get("class") != type(self).__name__:
+            warnings.warn(f"{path}: packed weights of {blob.get('class')} / ABI {blob.get('abi')}, this is {type(self).__name__} / ABI "
+                          f"{L.ABI_VERSION}: ignored")
+            return 0
+        return sum(getattr(self, n)._cache().import_packed(blob["nets"].get(n, {})) for n in ("encoder", "decoder"))
+
     # ---- device-side pixel pre/post-processing of the inference scripts (SURVEY 8f row 1) ------------------------
     @torch.no_grad()
     def encode_frames_u8(self, frames: torch.Tensor, return_dict: bool = True):

@@ -92,3 +92,34 @@ def test_forward_latents_and_u8_plumbing():
         out = m.decode_to_frames_u8(zu)
         ref = ((torch.clamp(m.decode(zu).sample[0], -1, 1) + 1) * 127.5).to(torch.uint8).permute(1, 2, 3, 0)
         assert out.dtype == torch.uint8 and tuple(out.shape) == (5, 32, 32, 3) and torch.equal(out, ref)
+
+
+def test_packed_weight_cache_roundtrip(tmp_path, monkeypatch):
+    """save_packed_weights / load_packed_weights: a second instance of the same checkpoint installs the packed forms
+    and runs without packing anything; a changed parameter falls back to packing for its layer only"""
+    from cvvae_amd import ops
+    m = build("sd3", {}, 4)
+    x = seeded_input((1, 3, 5, 32, 32), 2)
+    path = str(tmp_path / "packed.pt")
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        z = m.encode(x).latent_dist.mode()
+        y = m.decode(z).sample
+        n = m.save_packed_weights(path)
+        assert n > 60
+        m2 = build("sd3", {}, 4)
+        assert m2.load_packed_weights(path) == n
+
+        def no_pack(*a, **k):
+            raise AssertionError("a weight was packed although the cache holds it")
+        for name in ("pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold"):
+            monkeypatch.setattr(ops, name, no_pack)
+        assert torch.equal(m2.encode(x).latent_dist.mode(), z) and torch.equal(m2.decode(z).sample, y)
+        monkeypatch.undo()
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        m3 = build("sd3", {}, 4)
+        m3.encoder.conv_in.weight.data.mul_(1.5)
+        assert m3.load_packed_weights(path) == n - 1
+        assert not torch.equal(m3.encode(x).latent_dist.mode(), z)
+        m4 = build("vae3d", {}, 4)
+        with pytest.warns(UserWarning):
+            assert m4.load_packed_weights(path) == 0

@@ -391,3 +391,28 @@ def test_gn_silu_apply_pass_is_bit_identical_to_the_fused_prologue(dtype, monkey
     # i.e. another summation order), so the comparison is at the storage dtype's noise level, not bit for bit
     tolz, toly = {torch.float32: (2e-5, 1e-4), torch.float16: (4e-3, 1.5e-2), torch.bfloat16: (3.5e-2, 1e-1)}[dtype]
     assert (z0.float() - z1.float()).abs().max().item() <= tolz and (y0.float() - y1.float()).abs().max().item() <= toly
+
+
+def test_packed_weight_cache(tmp_path, monkeypatch):
+    """save_packed_weights / load_packed_weights: a second model instance of the same checkpoint installs the
+    packed MFMA-order weights from the file and produces the same bits without launching a single pack kernel"""
+    from cvvae_amd import ops
+    dtype = torch.float16
+    m, _ = build("sd3", {}, dtype, 4)
+    x = seeded_input((1, 3, 5, 64, 64), 5).to(dtype).cuda()
+    z = m.encode(x).latent_dist.mode()
+    y = m.decode(z).sample
+    path = str(tmp_path / "packed.pt")
+    n = m.save_packed_weights(path)
+    assert n > 60
+    m2, _ = build("sd3", {}, dtype, 4)
+    assert m2.load_packed_weights(path) == n
+
+    def no_pack(*a, **k):
+        raise AssertionError("a weight was packed although the cache holds it")
+    for name in ("pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold"):
+        monkeypatch.setattr(ops, name, no_pack)
+    assert torch.equal(m2.encode(x).latent_dist.mode(), z) and torch.equal(m2.decode(z).sample, y)
+    monkeypatch.undo()
+    m3, _ = build("sd3", {}, torch.bfloat16, 4)  # another dtype: nothing matches, everything is packed as usual
+    assert m3.load_packed_weights(path) == 0
