@@ -71,3 +71,47 @@ def test_partition_helpers():
     # cfg 4: T=129 over 8 ranks -> rank 0 owns frames 0..16, rank r owns 16r+1..16r+16
     assert [D.owned_frames(129, 16, 8, r) for r in range(8)] == [(0, 17)] + [(16 * r + 1, 16 * r + 17) for r in range(1, 8)]
     assert D.owned_frames(17, 16, 2, 1) == (0, 0)  # fewer windows than ranks
+
+
+def _worker_real(rank, world, port, q):
+    """the REAL CVVAESD3Model (full-size networks) sharded over gloo ranks, its kernels emulated on the CPU (tests/emu_ops.py)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cvvae_amd
+        from cvvae_amd import dist as D
+        from oracle.seeded import seeded_input, seeded_state_dict
+        from tests import emu_ops
+        torch.set_num_threads(4)
+        m = cvvae_amd.CVVAESD3Model()
+        m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 0), strict=True)
+        m = m.eval()
+        x = seeded_input((1, 3, 33, 32, 32), 2)
+        with emu_ops.patched(whole_model=True), torch.no_grad():
+            full = m.encode(x).latent_dist.parameters
+            a, b = D.owned_frames(33, 16, world, rank)
+            got = D.encode_windows_sharded(m, x[:, :, a:b].contiguous(), T_total=33, time_sharded=True)
+            z = full[:, :16]
+            ref_y = m.decode(z).sample
+            a, b = D.owned_frames(z.shape[2], 4, world, rank)
+            y = D.decode_windows_sharded(m, z[:, :, a:b].contiguous(), T_total=z.shape[2], time_sharded=True)
+        q.put((rank, torch.equal(got, full), torch.equal(y, ref_y), tuple(got.shape), tuple(y.shape)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_real_model_window_sharding_on_emulated_kernels():
+    """cfg 4's partition on the real model classes: two ranks, one 17-frame window each, the boundary frame exchanged point-to-point,
+    results all-gathered -- equal to the single-process wrapper bit for bit"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_real, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_e, ok_d, se, sy in res:
+        assert ok_e and ok_d, (rank, se, sy)
