@@ -118,8 +118,9 @@ class WeightCache:
     #      parameters, so that a later process with the same checkpoint installs them instead of packing again
     @staticmethod
     def _fingerprint(p: torch.Tensor):
-        f = p.detach().double()
-        return (tuple(p.shape), str(p.dtype), float(f.sum()), float(f.abs().sum()), float((f * f).sum()))
+        f = p.detach().reshape(-1)  # (reductions accumulate in fp64 without materialising a converted copy)
+        return (tuple(p.shape), str(p.dtype), float(f.sum(dtype=torch.float64)),
+                float(torch.linalg.vector_norm(f, 1, dtype=torch.float64)), float(torch.linalg.vector_norm(f, 2, dtype=torch.float64)))
 
     def export_packed(self) -> dict:
         """{tag: {"names": source parameter names, "fp": their fingerprints, "pw": PackedConv fields}} of every packed conv weight
