@@ -8,11 +8,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CVVAE_LIB: tuning aid -- load another build of the same ABI (A/B of kernel variants); the product path is the in-tree file
 LIB_PATH = os.environ.get("CVVAE_LIB") or os.path.join(_HERE, "libcvvae_hip.so")
 
-F16, BF16, F32 = 0, 1, 2
+F16, BF16, F32, F32Q = 0, 1, 2, 3
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class ConvDesc(ctypes.Structure):

@@ -3,6 +3,6 @@
 #include "conv_table.h"
 namespace cvvae {
 #define CVVAE_INST(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,true>(const ConvArgs&, int, hipStream_t);
+  template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_XP_B(CVVAE_INST)
 }  // namespace cvvae

@@ -43,6 +43,8 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
 
 template <typename T>
 struct Tr;
@@ -62,6 +64,26 @@ struct Tr<_Float16> {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
   }
 };
+
+// v_mfma_f32_32x32x64_f8f6f4 with both operands bf8 (OCP e5m2) and no block scales: K = 64 at TWICE the fp16 rate per K
+// element.  An operand is 32 bytes per lane, given here as its two 16-byte halves (bytes 0-15 | 16-31 of the lane): lanes 0-31
+// carry k = 0..31, lanes 32-63 k = 32..63 of row / column (lane & 31) -- the same map for A and B.
+__device__ __forceinline__ f32x16 mfma_bf8_k64(f16x8 a_lo, f16x8 a_hi, f16x8 b_lo, f16x8 b_hi, f32x16 c) {
+  const i32x4 al = __builtin_bit_cast(i32x4, a_lo), ah = __builtin_bit_cast(i32x4, a_hi);
+  const i32x4 bl = __builtin_bit_cast(i32x4, b_lo), bh = __builtin_bit_cast(i32x4, b_hi);
+  const i32x8 a = __builtin_shufflevector(al, ah, 0, 1, 2, 3, 4, 5, 6, 7);
+  const i32x8 b = __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0);  // cbsz = blgp = 1: bf8; scales 0: unscaled form
+}
+// 8 floats -> 8 bf8 (e5m2, round to nearest even), packed in two dwords
+__device__ __forceinline__ uint2 pack8_bf8(const float (&f)[8]) {
+  int a = 0, b = 0;
+  a = __builtin_amdgcn_cvt_pk_bf8_f32(f[0], f[1], a, false);
+  a = __builtin_amdgcn_cvt_pk_bf8_f32(f[2], f[3], a, true);
+  b = __builtin_amdgcn_cvt_pk_bf8_f32(f[4], f[5], b, false);
+  b = __builtin_amdgcn_cvt_pk_bf8_f32(f[6], f[7], b, true);
+  return make_uint2((unsigned)a, (unsigned)b);
+}
 
 struct ConvArgs {
   const void* in;
@@ -134,7 +156,9 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // to PF KiB past the last real fragment: cvvae_packed_weight_bytes() appends this many readable bytes.
 constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
 
-template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, bool XP = false>
+// XP: 0 = 16-bit model; 1 = fp32 model, three fp16 MFMAs per product ("exact"); 2 = fp32 model, one fp16 MFMA + bf8 correction
+// terms on the K = 64 fp8 MFMA ("fast", see conv_fwd_kernel)
+template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int XP = 0>
 struct Geo {
   static constexpr int NTAPS = KT * KH * KW;
   static constexpr int BM = TT * TH * TW;
@@ -143,9 +167,10 @@ struct Geo {
   static constexpr int FT = (TT - 1) * ST + KT, FH = (TH - 1) * SH + KH, FW = (TW - 1) * SW + KW;
   static constexpr int NPIX = FT * FH * FW;
   static constexpr int CK = 16 * KSUB;
-  // XP (fp32 activations, split-fp16 MFMA): a pixel holds, per 16 channels, hi[0..7] hi[8..15] lo[0..7] lo[8..15] (64 bytes)
+  // XP (fp32 activations, split-fp16 MFMA): a pixel holds, per 16 channels, hi[0..7] hi[8..15] lo[0..7] lo[8..15] (64 bytes);
+  // XP == 2: hi[0..15] (fp16, 32 bytes) | lo[0..15] (bf8, 16 bytes) | hi[0..15] (bf8, 16 bytes)
   static constexpr int PIXB = (XP ? CK * 4 : CK * 2) + 16;
-  static constexpr int XPM = XP ? 3 : 1;  // MFMAs (and weight records) per k16 sub-chunk and tap
+  static constexpr int XPM = XP ? 3 : 1;  // weight records per k16 sub-chunk and tap (XP == 1: one MFMA each)
   static constexpr int BUFB = NPIX * PIXB;
   static constexpr int LDSB = 2 * BUFB;
   static constexpr int NWV = WM * WN * KG;  // waves per workgroup: 8 (one workgroup per CU) or 4 (TWO workgroups per CU)
@@ -166,7 +191,7 @@ struct Geo {
   // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
   static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
   static constexpr int SMEMB = cmax(LDSB, REDB);
-  static_assert(!XP || KG == 1, "split-precision instances: no K-group split");
+  static_assert(XP == 0 || KG == 1, "split-precision instances: no K-group split");
   static_assert(NWV == 8 || (NWV == 4 && KG == 1), "8 waves per workgroup, or 4 (two workgroups per CU; no K-group split)");
   static_assert(NWV == 8 || LDSB <= 80 * 1024, "two resident workgroups share the CU's 160 KiB of LDS");
   static_assert(KG == 1 || (KG == 2 && KSUB % 2 == 0 && MREP % 2 == 0 && WM * WN == 4), "K-group split");
@@ -272,12 +297,21 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
 // arranged so that the K = 16 of one MFMA holds [Whi(c0..7) | Whi(c0..7)] x [hi(c0..7) | lo(c0..7)]  (parts 1, 2: channels
 // 0..7 / 8..15 of the sub-chunk) and [Wlo(c0..15)] x [hi(c0..15)] (part 0).  ~fp32 results (relative error ~1e-6) at 3x the
 // MFMA work: the reference's fp32 model path (from_pretrained without torch_dtype) and north_star's |delta| <= 1e-3 bound.
+//
+// XP == 2 ("fast" fp32, dtype CVVAE_F32Q): the two correction terms only have to be right to 3-4 bits, so they run on the fp8
+// matrix pipe, which has twice the rate per K element:   Whi.hi (fp16 MFMA)  +  bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi)  (ONE
+// v_mfma_f32_32x32x64_f8f6f4 per PAIR of taps: its K = 64 holds 16 channels x 2 taps x 2 terms -- lanes 0-31 carry
+// bf8(Whi) x bf8(lo), lanes 32-63 bf8(Wlo) x bf8(hi)).  e5m2 has fp16's exponent range, so nothing is scaled: bf8(v) is v with
+// its mantissa rounded to 2 bits.  Cost per pair of taps: 2 fp16 MFMAs + 1 fp8 MFMA of twice the duration = 4 units instead of
+// 6; error ~2^-14 relative per product (oracle/precision_ladder.py: latent max |delta| 1.3e-4 where the fp16 model has 2.6e-3
+// and the three-MFMA form 1.9e-5).  The packed weights keep three 1-KiB records per (k16, tap): [0] Whi (fp16), [1], [2] the
+// two halves of the pair's bf8 record (at the pair's FIRST tap; pairs never cross a run of KH*KW taps).
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS, bool XP = false>
+          int PRO, int UPS, int XP = 0>
 __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) void conv_fwd_kernel(const ConvArgs p) {
   using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, XP>;
-  using TIO = std::conditional_t<XP, float, T>;  // element type of the activation tensors in HBM
-  static_assert(!XP || std::is_same<T, _Float16>::value, "split precision runs on fp16 MFMA");
+  using TIO = std::conditional_t<XP != 0, float, T>;  // element type of the activation tensors in HBM
+  static_assert(XP == 0 || std::is_same<T, _Float16>::value, "split precision runs on fp16 MFMA");
   constexpr int XPM = G::XPM;
   // NWV == 4 (WM x WN = 4 waves, 256 threads, <= 256 VGPRs, <= 80 KiB of LDS): TWO workgroups are resident per CU, one wave of
   // each per SIMD.  Nothing couples them, so one workgroup's serial parts (first halo chunk, store tail, barrier waits, the
@@ -438,6 +472,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     if (__builtin_amdgcn_ballot_w64(sp != -2) != 0) passmask |= 1u << k;
   }
   const int lds_w0 = (pstart + spl) * PIXB + (XP ? (sq >> 1) * 64 + (sq & 1) * 16 : sq * 16);  // XP: my hi slice; lo = +32
+  // (XP == 2: my 8 bf8 lo values at +32 + (sq & 1) * 8 and my 8 bf8 hi values at +48 + (sq & 1) * 8 of the k16 group)
+  const int lds_q8 = (pstart + spl) * PIXB + (sq >> 1) * 64 + 32 + (sq & 1) * 8;
   const TIO* __restrict__ inp = reinterpret_cast<const TIO*>(p.in);
   const size_t gn_row = (size_t)(b * p.gn_rpb + (p.gn_rpb > 1 ? t0 : 0)) * (size_t)p.Cin;
 
@@ -481,7 +517,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         const int k = k0 + kk;
         if (k < NPASS && ((passmask >> k) & 1)) {
           if (srcpix[k] == -2) continue;
-          if constexpr (XP) {  // fp32 source -> (GroupNorm affine, SiLU in fp32) -> hi = fp16(x), lo = fp16(x - hi)
+          if constexpr (XP != 0) {  // fp32 source -> (GroupNorm affine, SiLU in fp32) -> hi = fp16(x), lo = fp16(x - hi)
             float f[8], fl[8];
             unraw8<float>(raw[kk], f);
             if (PRO_ != 0) {
@@ -497,10 +533,23 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               fl[j] = f[j] - h;
               f[j] = h;
             }
+            if constexpr (XP == 2) {  // hi fp16 | bf8(lo) | bf8(hi)
+              uint4 oh = pack8<T>(f);
+              uint2 l8 = pack8_bf8(fl), h8 = pack8_bf8(f);
+              if (srcpix[k] < 0) {
+                oh = make_uint4(0, 0, 0, 0);
+                l8 = h8 = make_uint2(0, 0);
+              }
+              char* d8 = smem + bufsel * G::BUFB + lds_q8 + k * (G::PPP * PIXB);
+              *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = oh;
+              *reinterpret_cast<uint2*>(d8) = l8;
+              *reinterpret_cast<uint2*>(d8 + 16) = h8;
+            } else {
             uint4 oh = pack8<T>(f), ol = pack8<T>(fl);
             if (srcpix[k] < 0) oh = ol = make_uint4(0, 0, 0, 0);  // zero padding is applied AFTER GroupNorm+SiLU
             *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = oh;
             *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB) + 32) = ol;
+            }
           } else {
           uint4 o = raw[kk].a;
           if (PRO_ != 0) {
@@ -547,10 +596,26 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                 (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
                 (TFOLD ? (size_t)(active ? nb : 0) * (size_t)p.nchunks * (size_t)w_cs
                        : (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512)) + lane * 8;
-  v8 wf[PF];
+  // XP == 2: the ring holds the FOUR records of one pair of taps -- [0] Whi of tap a, [1], [2] the halves of the pair's bf8
+  // record, [3] Whi of tap b -- each refilled with the next pair's right after its last use
+  constexpr int NWF = XP == 2 ? 4 : PF;
+  static_assert(XP != 2 || TFOLD || KT == 1, "fast-fp32 instances: 3-tap time kernels walk time groups, the others have KT = 1");
+  const long long wq_ks = (long long)(TFOLD ? p.w_taps : NTAPS * 3) * 512, wq_cs = wq_ks * KSUB;  // (XP == 2)
+  const T* wqx = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
+                 (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
+                 (size_t)(active ? nb : 0) * (size_t)p.nchunks * (size_t)wq_cs + lane * 8;
+  v8 wf[NWF];
+  if constexpr (XP == 2) {
+    const T* e = wqx + (TFOLD ? tf_w0 : 0);  // chunk 0, time group 0, pair 0 (taps 0 and 1 of k16 sub-chunk 0)
+    wf[0] = *reinterpret_cast<const v8*>(e);
+    wf[1] = *reinterpret_cast<const v8*>(e + 512);
+    wf[2] = *reinterpret_cast<const v8*>(e + 1024);
+    wf[3] = *reinterpret_cast<const v8*>(e + (KH * KW > 1 ? 3 * 512 : 0));
+  } else {
 #pragma unroll
-  for (int i = 0; i < PF; ++i)
-    wf[i] = *reinterpret_cast<const v8*>(TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512);
+    for (int i = 0; i < PF; ++i)
+      wf[i] = *reinterpret_cast<const v8*>(TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512);
+  }
 
   // The accumulators start from the BIAS (alpha == 1, i.e. every layer but the attention score product): 128 v_add per lane
   // leave the store tail -- which is VALU-issue bound -- for nothing (the zero fill cost the same moves).  K-group 1 of a
@@ -580,7 +645,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   //      residual of fragments 2c, 2c+1 before its MFMAs (16 VGPRs) and adds it to those accumulators afterwards: the loads
   //      fly under ~150 MFMAs (a 16-byte run = quads 2pr, 2pr+1 of the lane).  Measured: +1.3 % (128 ch) ... +2.7 %
   //      (512 ch) on the conv2 layers.
-  constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0 && !XP);
+  constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0 && XP == 0);
   const bool res_pre = RES_PRE && p.res != nullptr && p.res_pre != 0 && p.nchunks >= MREP / 2;
   uint4 rpre[2][2];
 
@@ -596,7 +661,69 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     const bool stage_first = grp == 0 && !p.phase_sync;
     if (stage_first && more) stage(c + 1, cur ^ 1);
     CVVAE_PROBE_MARK();
-    if constexpr (TFOLD) {
+    if constexpr (XP == 2) {
+      // ---- fast fp32: per pair of taps (a, b) of a run of R = KH*KW taps:  Whi.hi (a), Whi.hi (b) on the fp16 MFMA, then both
+      //      correction terms of both taps on ONE bf8 K = 64 MFMA.  A run with an odd tap count ends with a half-empty pair (the
+      //      packer zero-fills its second half; the B operand repeats tap a so that 0 x finite = 0).  LDS fragments and weight
+      //      records of the next sub-step are requested while the MFMAs of this one issue, as in the loops below.
+      if (active) {
+        constexpr int R = KH * KW, PR = (R + 1) / 2, NPAIR = PR * KSUB;
+        const unsigned lb = (unsigned)(cur * G::BUFB);
+        const T* wcb = wqx + (size_t)c * (size_t)wq_cs;
+        const T* wnx = more ? wcb + wq_cs : wcb;  // the last chunk's read-ahead re-reads its own records
+        const int ngq = TFOLD ? tf_ng : 1;
+        v8 fa[MREP], fb[MREP], qa[MREP], qb[MREP];
+#pragma unroll
+        for (int r = 0; r < MREP; ++r) fa[r] = *reinterpret_cast<const v8*>(&smem[lb + (TFOLD ? tf_l0 : 0u) + aoff[r]]);
+        for (int g = 0; g < ngq; ++g) {
+          const unsigned lbg = lb + (TFOLD ? (g == 0 ? tf_l0 : (g == 1 ? tf_l1 : tf_l2)) : 0u);
+          const T* wg = wcb + (TFOLD ? (g == 0 ? tf_w0 : (g == 1 ? tf_w1 : tf_w2)) : 0);
+          const bool lastg = g + 1 == ngq;
+          const T* wn = lastg ? wnx + (TFOLD ? tf_w0 : 0) : wcb + (g == 0 ? tf_w1 : tf_w2);  // pair 0 of the next group / chunk
+          const unsigned lbn = lb + (g == 0 ? tf_l1 : tf_l2);
+#pragma unroll
+          for (int q = 0; q < NPAIR; ++q) {
+            const int ks = q / PR, ta = 2 * (q % PR), tb = ta + 1;
+            const bool hasb = tb < R, lastq = q + 1 == NPAIR;
+            const unsigned oa = (unsigned)(((ta / KW) * G::FW + (ta % KW)) * PIXB + ks * 64);
+            const unsigned ob = (unsigned)(((tb / KW) * G::FW + (tb % KW)) * PIXB + ks * 64);
+            const int nks = (q + 1) / PR, nta = 2 * ((q + 1) % PR);
+            const T* ne = lastq ? wn : wg + (long long)nks * wq_ks + nta * (3 * 512);  // record [0] of the next pair
+            const bool nhasb = lastq ? (R > 1) : (nta + 1 < R);
+            const unsigned ona = (unsigned)(((nta / KW) * G::FW + (nta % KW)) * PIXB + nks * 64);
+            // Whi.hi of tap a
+#pragma unroll
+            for (int r = 0; r < MREP; ++r) {
+              acc[r] = Tr<T>::mfma(wf[0], fa[r], acc[r]);
+              if (hasb) fb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob]);
+              else qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
+            }
+            wf[0] = *reinterpret_cast<const v8*>(ne);
+            __builtin_amdgcn_sched_barrier(0);
+            if (hasb) {  // Whi.hi of tap b
+#pragma unroll
+              for (int r = 0; r < MREP; ++r) {
+                acc[r] = Tr<T>::mfma(wf[3], fb[r], acc[r]);
+                qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
+                qb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob + 32]);
+              }
+            }
+            wf[3] = *reinterpret_cast<const v8*>(ne + (nhasb ? 3 * 512 : 0));
+            __builtin_amdgcn_sched_barrier(0);
+            // bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi) of both taps
+#pragma unroll
+            for (int r = 0; r < MREP; ++r) {
+              acc[r] = mfma_bf8_k64(wf[1], wf[2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
+              if (!lastq) fa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ona]);
+              else if (!lastg) fa[r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
+            }
+            wf[1] = *reinterpret_cast<const v8*>(ne + 512);
+            wf[2] = *reinterpret_cast<const v8*>(ne + 1024);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    } else if constexpr (TFOLD) {
       if (active) {
         const unsigned lb = (unsigned)(cur * G::BUFB);
         const T* wcb = wq + (size_t)c * (size_t)w_cs;
@@ -710,7 +837,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   }
   // ---- fused 1x1 shortcut: more K chunks over the second input through the centre tap (the final barrier of the loop
   //      above has released both halo buffers)
-  if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0) {
+  if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0 && XP != 2) {
     if (p.in2 != nullptr) {
       const TIO* __restrict__ inp2 = reinterpret_cast<const TIO*>(p.in2);
       auto stage2 = [&](int chunk, int bufsel) {
@@ -996,8 +1123,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       }
     }
   };
-  constexpr bool F32TAIL = XP || (KT * KH * KW == 1);  // instances that can store float from the fast tail
-  const bool f32out = XP || p.out_f32;
+  constexpr bool F32TAIL = XP != 0 || (KT * KH * KW == 1);  // instances that can store float from the fast tail
+  const bool f32out = XP != 0 || p.out_f32;
   if (tile_full && !f32out) {
     fast_tail((T)0.f);
   } else if (F32TAIL && tile_full && f32out) {
@@ -1055,12 +1182,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           }
           const int c8 = c8v[pr];
           const bool full = (c8 + 7 < p.Cout);
-          if (XP || p.out_f32) {
+          if (XP != 0 || p.out_f32) {
             float* o = reinterpret_cast<float*>(p.out) + off;
             if (full) {
               *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
               *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-              if (XP && p.gnp) {  // fused GroupNorm statistics of the fp32 values stored (shifted sums, as below)
+              if (XP != 0 && p.gnp) {  // fused GroupNorm statistics of the fp32 values stored (shifted sums, as below)
                 if (!((gkm >> pr) & 1)) {
                   gk[pr][0] = v[0];  // per-lane shift (see the fast tail)
                   gk[pr][1] = v[4];
@@ -1196,7 +1323,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS, bool XP = false>
+          int PRO, int UPS, int XP = 0>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
   // (debug aid: CVVAE_NW4_SOLO=1 pads a 4-wave launch's LDS so that only ONE workgroup fits a CU)
   static const bool solo = getenv("CVVAE_NW4_SOLO") && atoi(getenv("CVVAE_NW4_SOLO"));

@@ -103,6 +103,20 @@
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
   X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
 
+// Fast-fp32 (XP = 2) instances: the multi-tap families of the list above (1x1x1 layers of such a model stay on the XP list)
+#define CVVAE_CONV_XQ_A(X) \
+  X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0) \
+  X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
+  X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0) \
+  X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 1, 0,2)
+#define CVVAE_CONV_XQ_B(X) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0) \
+  X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
+  X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
+#define CVVAE_CONV_XQ(X) CVVAE_CONV_XQ_A(X) CVVAE_CONV_XQ_B(X)
+
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \
   CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X)

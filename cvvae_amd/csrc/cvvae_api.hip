@@ -17,26 +17,32 @@ namespace cvvae {
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_ALL(CVVAE_EXTERN)
 #define CVVAE_EXTERN_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,true>(const ConvArgs&, int, hipStream_t);
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_XP(CVVAE_EXTERN_XP)
+#define CVVAE_EXTERN_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_XQ(CVVAE_EXTERN_XQ)
 
 typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 
 struct Instance {
   int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, kg, ksub, pro, ups;
-  launch_fn fn[3];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one)
+  launch_fn fn[4];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one), [CVVAE_F32Q] (fast fp32)
   char name[96];
 };
 
 #define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
-    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr}, ""},
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr, nullptr}, ""},
 #define CVVAE_ROW_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
-   {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,true>}, ""},
+   {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>, nullptr}, ""},
+#define CVVAE_ROW_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
+   {nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>}, ""},
 
-static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_XP(CVVAE_ROW_XP)};
+static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -152,14 +158,16 @@ static const Instance* odd_frame_sibling(const cvvae_conv_desc* d, const Instanc
 static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
     snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d%s", e->kt, e->kh, e->kw, e->st,
-             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups, e->fn[2] ? "_xp" : "");
+             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups, e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : ""));
   (void)dtype;
   return e->name;
 }
 
 static int check_desc(const cvvae_conv_desc* d) {
   if (!d) return CVVAE_EINVAL;
-  if (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16 && d->dtype != CVVAE_F32) return CVVAE_EINVAL;
+  if (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16 && d->dtype != CVVAE_F32 && d->dtype != CVVAE_F32Q) return CVVAE_EINVAL;
+  // fast fp32: multi-tap convolutions without a fused shortcut or per-item weights (those run as CVVAE_F32)
+  if (d->dtype == CVVAE_F32Q && (d->kH * d->kW == 1 || d->sc_Cin || d->w_batch_stride)) return CVVAE_EUNSUPPORTED;
   if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0)
     return CVVAE_EINVAL;
   const int ck = cvvae_conv_kchunk(d->kT, d->kH, d->kW);
@@ -311,7 +319,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
     a.in2_ps = d->sc_in_pix_stride;
     a.nchunks2 = d->sc_Cin / (16 * e->ksub);
   }
-  const int xpm = d->dtype == CVVAE_F32 ? 3 : 1;  // packed records per (k16, tap): the split-precision layout carries three
+  const int xpm = (d->dtype == CVVAE_F32 || d->dtype == CVVAE_F32Q) ? 3 : 1;  // packed records per (k16, tap): the fp32 layouts carry three
   a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT * (d->w_time_folds ? 2 : 1) * xpm) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;

@@ -81,10 +81,48 @@ __device__ __forceinline__ void xp_store(_Float16* dst, long long rec3, int lane
   *reinterpret_cast<f16x8*>(dst + (rec3 + 2) * 512 + lane * 8) = p2;
 }
 
+// Fast-fp32 records (dtype CVVAE_F32Q, conv_fwd_kernel<..., XP = 2>): the same three 1-KiB records per (k16, tap), holding
+//   [0]: Whi(c) at k = c (c = 0..15)                                        x B = hi(c)  on the fp16 MFMA
+//   [1], [2] (only at the FIRST tap of a pair; pairs = taps (0,1), (2,3), ... of every run of `run` taps): bytes 0-15 / 16-31 of
+//            a lane's operand of the K = 64 bf8 MFMA: lanes 0-31 bf8(Whi(c)), lanes 32-63 bf8(Wlo(c)), c = 0..15, of tap a in
+//            [1] and of tap b in [2] (zero when the run ends on tap a)     x B = [bf8(lo) | bf8(hi)] of taps a, b
+__device__ __forceinline__ uint4 xq_half(int kh, const float (&w)[16]) {
+  float v[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float hi = (float)(_Float16)w[j];
+    v[j] = kh ? w[j] - hi : hi;
+  }
+  float a[8], b[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    a[j] = v[j];
+    b[j] = v[8 + j];
+  }
+  const uint2 lo = pack8_bf8(a), hi = pack8_bf8(b);
+  return make_uint4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ void xq_store(_Float16* dst, long long rec3, int lane, const float (&wa)[16], const float (&wb)[16],
+                                         bool pair_start, bool has_b) {
+  const int kh = lane >> 5;
+  f16x8 p0;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) p0[j] = (_Float16)wa[kh * 8 + j];
+  uint4 q1 = make_uint4(0, 0, 0, 0), q2 = make_uint4(0, 0, 0, 0);
+  if (pair_start) {
+    q1 = xq_half(kh, wa);
+    if (has_b) q2 = xq_half(kh, wb);
+  }
+  *reinterpret_cast<f16x8*>(dst + (rec3 + 0) * 512 + lane * 8) = p0;
+  *reinterpret_cast<uint4*>(dst + (rec3 + 1) * 512 + lane * 8) = q1;
+  *reinterpret_cast<uint4*>(dst + (rec3 + 2) * 512 + lane * 8) = q2;
+}
+
+// qrun: 0 = split-precision (three fp16 MFMAs) records; > 0 = fast-fp32 records with tap pairs inside runs of qrun taps
 __global__ void pack_weights_xp_kernel(const float* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
                                        long long s_ci, long long s_tap, int nchunks, _Float16* __restrict__ dst,
                                        long long nfrag_lanes, int fold_n, long long s_fold, long long s_batch,
-                                       long long d_batch, int dst_taps, int dst_tap0) {
+                                       long long d_batch, int dst_taps, int dst_tap0, int qrun) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nfrag_lanes) return;
   src += (long long)blockIdx.y * s_batch;
@@ -96,19 +134,34 @@ __global__ void pack_weights_xp_kernel(const float* __restrict__ src, int Cout_s
   const int chunk = (int)(f % nchunks);  // k16 index
   const int nb = (int)(f / nchunks);
   const int co = nb * 32 + sigma_row(lane & 31);
-  float w[16];
+  auto load16 = [&](int tp, float (&w)[16]) {
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int ci = chunk * 16 + j;
-    float a = 0.f;
-    if (co < Cout_src && ci < Cin_src) {
-      const float* e = src + (long long)co * s_co + (long long)ci * s_ci + (long long)tap * s_tap;
-      for (int q = 0; q < (fold_n <= 1 ? 1 : fold_n); ++q) a += e[(long long)q * s_fold];
+    for (int j = 0; j < 16; ++j) {
+      const int ci = chunk * 16 + j;
+      float a = 0.f;
+      if (co < Cout_src && ci < Cin_src) {
+        const float* e = src + (long long)co * s_co + (long long)ci * s_ci + (long long)tp * s_tap;
+        for (int q = 0; q < (fold_n <= 1 ? 1 : fold_n); ++q) a += e[(long long)q * s_fold];
+      }
+      w[j] = a;
     }
-    w[j] = a;
-  }
+  };
+  float w[16];
+  load16(tap, w);
   const long long rec = ((long long)nb * nchunks + chunk) * dst_taps + dst_tap0 + tap;
-  xp_store(dst, rec * 3, lane, w);
+  if (qrun > 0) {
+    const int tr = tap % qrun;
+    const bool start = (tr & 1) == 0, has_b = start && tr + 1 < qrun;
+    float wb[16];
+    if (has_b) load16(tap + 1, wb);
+    else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wb[j] = 0.f;
+    }
+    xq_store(dst, rec * 3, lane, w, wb, start, has_b);
+  } else {
+    xp_store(dst, rec * 3, lane, w);
+  }
 }
 
 // Nearest-2x upsample folded into the conv weights (Upsample3D: F.interpolate(scale (1,2,2)) then a 3x3x3 conv,
@@ -162,7 +215,7 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
 
 __global__ void pack_upfold_xp_kernel(const float* __restrict__ src, int Cout, int Cin, int nchunks, _Float16* __restrict__ dst,
                                       long long per_phase_lanes, long long phase_stride_elems, int tfold, int dst_taps,
-                                      int dst_tap0) {
+                                      int dst_tap0, int qrun) {
   const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid0 >= 4 * per_phase_lanes) return;
   const int phase = (int)(gid0 / per_phase_lanes);
@@ -175,26 +228,40 @@ __global__ void pack_upfold_xp_kernel(const float* __restrict__ src, int Cout, i
   f /= ntap;
   const int chunk = (int)(f % nchunks);
   const int nb = (int)(f / nchunks);
-  const int kt = tap >> 2, a = (tap >> 1) & 1, b = tap & 1;
-  const int kt_lo = tfold == 0 ? kt : (tfold == 1 || tfold == 3 ? 0 : 1), kt_hi = tfold == 0 ? kt : (tfold == 2 || tfold == 3 ? 1 : 2);
-  const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
-  const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
   const int co = nb * 32 + sigma_row(lane & 31);
-  float w16[16];
+  auto load16 = [&](int tp, float (&w16)[16]) {
+    const int kt = tp >> 2, a = (tp >> 1) & 1, b = tp & 1;
+    const int kt_lo = tfold == 0 ? kt : (tfold == 1 || tfold == 3 ? 0 : 1), kt_hi = tfold == 0 ? kt : (tfold == 2 || tfold == 3 ? 1 : 2);
+    const int y_lo = a == 0 ? 0 : (py == 0 ? 1 : 2), y_hi = a == 0 ? (py == 0 ? 0 : 1) : 2;
+    const int x_lo = b == 0 ? 0 : (px == 0 ? 1 : 2), x_hi = b == 0 ? (px == 0 ? 0 : 1) : 2;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int ci = chunk * 16 + j;
-    float acc = 0.f;
-    if (co < Cout && ci < Cin) {
-      const float* w = src + ((long long)co * Cin + ci) * 27;
-      for (int k = kt_lo; k <= kt_hi; ++k)
-        for (int ky = y_lo; ky <= y_hi; ++ky)
-          for (int kx = x_lo; kx <= x_hi; ++kx) acc += w[k * 9 + ky * 3 + kx];
+    for (int j = 0; j < 16; ++j) {
+      const int ci = chunk * 16 + j;
+      float acc = 0.f;
+      if (co < Cout && ci < Cin) {
+        const float* w = src + ((long long)co * Cin + ci) * 27;
+        for (int k = kt_lo; k <= kt_hi; ++k)
+          for (int ky = y_lo; ky <= y_hi; ++ky)
+            for (int kx = x_lo; kx <= x_hi; ++kx) acc += w[k * 9 + ky * 3 + kx];
+      }
+      w16[j] = acc;
     }
-    w16[j] = acc;
-  }
+  };
+  float w16[16];
+  load16(tap, w16);
   const long long rec = ((long long)nb * nchunks + chunk) * dst_taps + dst_tap0 + tap;
-  xp_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16);
+  if (qrun > 0) {  // (runs of 4 taps = the 2x2 spatial taps of one time tap: pairs (0,1), (2,3))
+    const bool start = (tap & 1) == 0;
+    float wb[16];
+    if (start) load16(tap + 1, wb);
+    else {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) wb[j] = 0.f;
+    }
+    xq_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16, wb, start, start);
+  } else {
+    xp_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -978,6 +1045,7 @@ int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, in
 int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src,
                                int32_t Cin_src, int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad,
                                int32_t kchunk, void* dst, int64_t dst_batch_stride, void* stream) {
+  if (dtype == CVVAE_F32Q) return CVVAE_EUNSUPPORTED;  // per-item (attention) weights are 1x1: they stay in the three-MFMA form
   if (batch <= 0 || dst_batch_stride % 16 || (size_t)dst_batch_stride < cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps * (dtype == CVVAE_F32 ? 3 : 1)))
     return CVVAE_EINVAL;
   return pack_impl(dtype, src, batch, s_batch, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst,
@@ -1005,10 +1073,18 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
     hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid, batch), dim3(256), 0, s, (const _Float16*)src, Cout_src,
                        Cin_src, taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n,
                        fold_n, (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
-  else if (dtype == CVVAE_F32)  // fp32 source -> split-precision records (3 per (k16, tap); one thread per record TRIPLE)
+  else if (dtype == CVVAE_F32 || dtype == CVVAE_F32Q) {  // fp32 source -> split-precision records (3 per (k16, tap); one thread per record TRIPLE)
+    // fast-fp32 pairs stay inside a run of kH*kW taps (the kernel walks 3-tap time kernels as time groups of kH*kW steps):
+    // 27 / 54 (time-fold slots) / 9 -> runs of 9, 12 / 24 / 4 -> runs of 4 (the folded-upsample phases come through upfold_launch)
+    int qrun = 0;
+    if (dtype == CVVAE_F32Q) {
+      qrun = taps % 9 == 0 ? 9 : (taps % 4 == 0 ? 4 : 0);
+      if (!qrun || dst_taps % qrun || dst_tap0 % qrun) return CVVAE_EUNSUPPORTED;  // (1x1x1 weights: use CVVAE_F32)
+    }
     hipLaunchKernelGGL(pack_weights_xp_kernel, dim3(grid, batch), dim3(256), 0, s, (const float*)src, Cout_src, Cin_src, taps,
                        (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, (_Float16*)dst, n, fold_n, (long long)s_fold,
-                       (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
+                       (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0, qrun);
+  }
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();
@@ -1022,7 +1098,7 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
 int cvvae_pack_weights_tfolds(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t nsp, int64_t s_co,
                               int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream) {
   if (nsp <= 0) return CVVAE_EINVAL;
-  const int es = dtype == CVVAE_F32 ? 4 : 2;  // bytes per source element
+  const int es = (dtype == CVVAE_F32 || dtype == CVVAE_F32Q) ? 4 : 2;  // bytes per source element
   const char* sp = (const char*)src;
   int rc = pack_impl(dtype, src, 1, 0, Cout_src, Cin_src, 3 * nsp, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst, 0, stream, 6 * nsp, 0);
   if (rc) return rc;
@@ -1039,7 +1115,8 @@ static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t C
                          int32_t dst_taps, int32_t dst_tap0, void* stream) {
   const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16, ntap = tfold ? 4 : 12;
   const long long per_phase = (long long)nb * nchunks * ntap * 64;
-  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, dst_taps * (dtype == CVVAE_F32 ? 3 : 1)) / 2);
+  const bool f32 = dtype == CVVAE_F32 || dtype == CVVAE_F32Q;
+  const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, dst_taps * (f32 ? 3 : 1)) / 2);
   const int grid = (int)((4 * per_phase + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
@@ -1048,9 +1125,9 @@ static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t C
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL(pack_upfold_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)src, Cout, Cin, nchunks,
                        (_Float16*)dst, per_phase, stride, tfold, dst_taps, dst_tap0);
-  else if (dtype == CVVAE_F32)
+  else if (f32)
     hipLaunchKernelGGL(pack_upfold_xp_kernel, dim3(grid), dim3(256), 0, s, (const float*)src, Cout, Cin, nchunks, (_Float16*)dst,
-                       per_phase, stride, tfold, dst_taps, dst_tap0);
+                       per_phase, stride, tfold, dst_taps, dst_tap0, dtype == CVVAE_F32Q ? 4 : 0);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

@@ -26,6 +26,12 @@ class WeightCache:
     def __init__(self, module: torch.nn.Module):
         self.m = module
         self._c: Dict[str, tuple] = {}
+        # fp32 models: pack multi-tap conv weights in the fast layout (CVVAE_F32Q: fp16 MFMA + bf8 correction MFMA, DESIGN.md
+        # section 4) instead of the three-MFMA split-precision one; set through the model's `fp32_mode`
+        self.fast = False
+
+    def _q(self) -> str:
+        return "#q" if self.fast else ""
 
     def _key(self, *ps):
         return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps if p is not None)
@@ -37,7 +43,7 @@ class WeightCache:
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        tag = pre + "#tf" if time_folds else (pre if wscale is None else f"{pre}#ws{wscale}")
+        tag = (pre + "#tf" if time_folds else (pre if wscale is None else f"{pre}#ws{wscale}")) + self._q()
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -45,9 +51,12 @@ class WeightCache:
         co, ci = w.shape[0], w.shape[1]
         assert w.numel() == co * ci * taps, f"{pre}: weight {tuple(w.shape)} is not a {k} kernel"
         if time_folds:
-            pw = ops.pack_weight_tfolds(w.detach().reshape(co, ci, *k), b.detach(), cin_pad=cin_pad)
+            pw = ops.pack_weight_tfolds(w.detach().reshape(co, ci, *k), b.detach(), cin_pad=cin_pad, fast=self.fast)
         else:
-            pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad, wscale=wscale)
+            pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad, wscale=wscale, fast=self.fast)
+        if wscale is not None:  # one scaled form per prefix: older '#ws<scale>' variants (another conv2 scale) are dead weight
+            for t in [t for t in self._c if t.startswith(pre + "#ws") and t != tag]:
+                del self._c[t]
         self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
@@ -74,11 +83,11 @@ class WeightCache:
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        tag = f"{pre}#upfold{tfold}{'tf' if time_folds else ''}"
+        tag = f"{pre}#upfold{tfold}{'tf' if time_folds else ''}" + self._q()
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
-        pw = ops.pack_weight_upfold(w.detach(), b.detach(), tfold, time_folds=time_folds)
+        pw = ops.pack_weight_upfold(w.detach(), b.detach(), tfold, time_folds=time_folds, fast=self.fast)
         self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
@@ -88,7 +97,7 @@ class WeightCache:
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        tag = f"{pre}#upfold2d"
+        tag = f"{pre}#upfold2d" + self._q()
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
@@ -96,7 +105,7 @@ class WeightCache:
         assert (kh, kw) == (3, 3), f"{pre}: weight {tuple(w.shape)} is not a 3x3 kernel"
         w3 = torch.zeros((co, ci, 3, 3, 3), dtype=w.dtype, device=w.device)
         w3[:, :, 1] = w.detach()
-        pw = ops.pack_weight_upfold(w3, b.detach(), 2)
+        pw = ops.pack_weight_upfold(w3, b.detach(), 2, fast=self.fast)
         pw.alg_taps = 9
         self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
@@ -106,11 +115,11 @@ class WeightCache:
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        tag = f"{pre}#t1{mode}"
+        tag = f"{pre}#t1{mode}" + self._q()
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
-        pw = ops.pack_weight_t1(w.detach(), b.detach(), mode, cin_pad=cin_pad)
+        pw = ops.pack_weight_t1(w.detach(), b.detach(), mode, cin_pad=cin_pad, fast=self.fast)
         self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
@@ -131,6 +140,11 @@ class WeightCache:
             if len(ent) < 3 or not dataclasses.is_dataclass(ent[1]):
                 continue  # norm tables / summed biases: cheaper to rebuild than to read
             names = ent[2]
+            # entries are refreshed lazily, on access: one packed BEFORE a load_state_dict / in-place edit still holds the OLD
+            # weights, and exporting it under the fingerprint of the CURRENT parameters would hand a later process stale
+            # weights that pass the import check.  Only entries whose key still matches the live parameters are exported.
+            if ent[0] != self._key(*[self.m.get_parameter(n) for n in names]):
+                continue
             out[tag] = {"names": list(names), "fp": [self._fingerprint(self.m.get_parameter(n)) for n in names],
                         "pw": {f.name: getattr(ent[1], f.name) for f in dataclasses.fields(ent[1])}}
         return out
@@ -224,6 +238,20 @@ def _activated(x: torch.Tensor, kw: dict, k: Tuple[int, int, int], cout: int) ->
     return x, kw
 
 
+def _shortcut_scale_fits(wc: WeightCache, sc_name: str, pw2, dtype) -> bool:
+    """fp32 models: conv2's pack scale puts max |w_conv2| in [512, 1024); the fused 1x1 shortcut shares it.  Its fp16 hi part
+    must stay finite (max |w_sc| * scale < 2^15 leaves headroom for the rounding); otherwise the block runs unfused."""
+    if dtype != torch.float32:
+        return True
+    w = wc.m.get_parameter(sc_name + ".weight")
+    key = wc._key(w)
+    hit = wc._c.get(sc_name + "#absmax")
+    if hit is None or hit[0] != key:
+        hit = (key, float(w.detach().abs().max()))
+        wc._c[sc_name + "#absmax"] = hit
+    return hit[1] * pw2.wscale < 32768.0
+
+
 def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
     """conv2 (per-frame 3x3 over GN+SiLU(h), zero pad) + shortcut(x) + add -- vae_blocks3d_sd3.py:559-567, vae_models.py:404-410."""
     pw2 = wc.conv(pre + ".conv2", (1, 3, 3))
@@ -233,7 +261,10 @@ def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_
         kw.update(prologue=L.PRO_NONE, gn=None)
     if not wc.has(sc_name + ".weight"):
         y = ops.conv(h, pw2, residual=x, **kw)
-    elif fuse_shortcut():  # (fp32 models: the shortcut weights are packed with conv2's power-of-two scale -- one accumulator set)
+    elif fuse_shortcut() and pw2.dt != L.F32Q and _shortcut_scale_fits(wc, sc_name, pw2, x.dtype):
+        # (fp32 models: the shortcut weights are packed with conv2's power-of-two scale -- one accumulator set; the fast-fp32
+        # kernels have no fused shortcut, and a shortcut whose weights would overflow fp16 under conv2's scale is not fused
+        # either: the 1x1 then runs as its own three-MFMA launch with its own scale)
         pws = wc.conv(sc_name, (1, 1, 1), wscale=pw2.wscale if x.dtype == torch.float32 else None)
         y = ops.conv(h, pw2, shortcut=(x, pws), bias=wc.bias_sum(pre + ".conv2", sc_name), **kw)
     else:

@@ -131,7 +131,8 @@ class ConstraintDecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
         net, tape = ctx.net, ctx.tape
+        # the tape (block inputs, statistics records, attention operands) is kept until autograd frees the node, so a second
+        # backward through it (retain_graph=True, two losses) walks the same tape and gives the same bits
         with torch.cuda.device(gy.device):
             gz = constraint_decoder2d_backward(net._cache(), tape, gy)
-        ctx.tape = None
         return gz.to(ctx.zdtype), None

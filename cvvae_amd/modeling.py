@@ -68,10 +68,12 @@ class _Net(nn.Module):
         self._unsupported = None  # set by the wrapper when the configuration cannot run on the kernels (message)
         self._graphs = None  # enable_hip_graphs(): {(shape, dtype, device, switches): _GraphEntry}
         self._graph_cap = 0
+        self._fp32_fast = os.environ.get("CVVAE_F32_MODE", "exact") == "fast"  # see _CVVAEBase.fp32_mode
 
     def _cache(self) -> engine.WeightCache:
         if self._wc is None:
             object.__setattr__(self, "_wc", engine.WeightCache(self))
+        self._wc.fast = self._fp32_fast
         return self._wc
 
     def _check_input(self, x: torch.Tensor):
@@ -110,7 +112,7 @@ class _Net(nn.Module):
 
     def _forward_graphed(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        key = (tuple(x.shape), x.dtype, x.device.index, tuple(sorted(kwargs.items())), engine.fold_upsample(), engine.fold_t1(), engine.fuse_shortcut(), engine.fold_time())
+        key = (tuple(x.shape), x.dtype, x.device.index, tuple(sorted(kwargs.items())), engine.fold_upsample(), engine.fold_t1(), engine.fuse_shortcut(), engine.fold_time(), self._fp32_fast)
         ent = self._graphs.get(key)
         if ent is not None and ent[0] != sig:  # weights were replaced / moved / modified: the captured pointers are stale
             del self._graphs[key]
@@ -420,6 +422,23 @@ class _CVVAEBase(nn.Module):
         self.reshape_z_dim_to_4 = cfg["reshape_z_dim_to_4"]  # stored, never applied in encode (Appendix A.1)
         self.reshape_x_dim_to_4 = cfg["reshape_x_dim_to_4"]
 
+    # ---- arithmetic of fp32 models (torch_dtype=torch.float32, the reference's default).  gfx950 has no fp32-class MFMA, so an
+    #      fp32 model runs in split precision on the 16-bit matrix pipe:
+    #        "exact": three fp16 MFMAs per product -- ~1e-6 relative, latent max |delta| ~8e-6 against the reference's fp32 run
+    #        "fast" : one fp16 MFMA + the two correction terms on the bf8 K = 64 MFMA -- 2/3 of the time of "exact", latent max
+    #                 |delta| ~2e-4: the cheapest mode inside north_star's 1e-3 bound
+    #      16-bit models ignore it.  Default "exact"; CVVAE_F32_MODE=fast changes the default.
+    def _get_fp32_mode(self) -> str:
+        return "fast" if self.encoder._fp32_fast else "exact"
+
+    def _set_fp32_mode(self, mode: str):
+        if mode not in ("exact", "fast"):
+            raise ValueError(f"fp32_mode must be 'exact' or 'fast', got {mode!r}")
+        for net in (self.encoder, self.decoder):
+            object.__setattr__(net, "_fp32_fast", mode == "fast")
+
+    fp32_mode = property(_get_fp32_mode, _set_fp32_mode)
+
     def _flag_widths(self, widths):
         """widths the kernels cannot run: the model can still be built, loaded, converted and saved (parameter holder), but a
         forward pass raises NotImplementedError with this message instead of failing inside a launch."""
@@ -686,13 +705,16 @@ class _CVVAEBase(nn.Module):
 
     @torch.no_grad()
     def encode_latents(self, x: torch.Tensor, sample: bool = True, generator: Optional[torch.Generator] = None,
-                       scale_factor: Optional[float] = None, n_samples_a_time: Optional[int] = None) -> torch.Tensor:
+                       scale_factor: Optional[float] = None, n_samples_a_time: Optional[int] = None,
+                       flatten_frames: bool = False) -> torch.Tensor:
         """Frozen-encoder latent pre-compute for the diffusion training engines: the arithmetic of
         `DiffusionEngine.encode_first_stage` (/root/reference/lvdm/models/diffusion.py:159-171: rounds of
         `en_and_decode_n_samples_a_time` samples, `first_stage_model.encode`, cat, `scale_factor * z`) with the 4-D <-> 5-D
         adapters of `DiffusionEngineFor3DVAE.encode_first_stage` (:380-385: images [B,C,H,W] run as one-frame clips and the
         latents come back as [(B T),C,h,w]).  `sample=False` takes the posterior mode (deterministic latents for a cache).
-        x: [B,3,T,H,W] clips or [B,3,H,W] images -> latents [B,z,T',h,w] (clips) / [(B T'),z,h,w] (images)."""
+        x: [B,3,T,H,W] clips or [B,3,H,W] images -> latents [B,z,T',h,w] (clips) / [(B T'),z,h,w] (images).
+        DEVIATION, stated: the reference's :380-385 rearranges 'b c t h w -> (b t) c h w' for clips too; here clips come back 5-D
+        (what a latent cache stores) unless `flatten_frames=True`, which gives the reference's [(B T'),z,h,w] for every input."""
         images = x.dim() == 4
         if images:
             x = x.unsqueeze(2)
@@ -705,7 +727,7 @@ class _CVVAEBase(nn.Module):
         sf = scale_factor if scale_factor is not None else getattr(self.config, "scaling_factor", None)
         if sf is not None and sf != 1.0:
             z = sf * z
-        if images:
+        if images or flatten_frames:
             z = z.permute(0, 2, 1, 3, 4).reshape(-1, z.shape[1], *z.shape[3:])
         return z
 
@@ -716,7 +738,8 @@ class _CVVAEBase(nn.Module):
         x = self.decode(z, num_frames=num_frames).sample
         if x.dim() != 5 or x.shape[0] != 1:
             raise ValueError("decode_to_frames_u8 handles one clip [1,C,T,H,W] (reshape_x_dim_to_4 must be off)")
-        return ops.ncdhw_to_frames_u8(x.contiguous())
+        with torch.cuda.device(x.device):  # (the launch goes to x's device whatever the caller's current device is)
+            return ops.ncdhw_to_frames_u8(x.contiguous())
 
     def forward(self, sample: torch.Tensor, sample_posterior: bool = False, return_dict: bool = True,
                 generator: Optional[torch.Generator] = None, num_frames: Optional[int] = None

@@ -15,6 +15,16 @@ _DT = {torch.float16: L.F16, torch.bfloat16: L.BF16, torch.float32: L.F32}
 # fp32 models (the reference's default when from_pretrained gets no torch_dtype) run in SPLIT PRECISION: float tensors in HBM,
 # every product as three fp16 MFMAs (include/cvvae.h CVVAE_F32; csrc/conv_kernel.h XP): ~1e-6 relative error, 3x the MFMA work.
 SUPPORTS_FP32 = True
+# ... or, per model (`fp32_mode = "fast"`), with the two correction terms on the fp8 matrix pipe (CVVAE_F32Q; conv_kernel.h
+# XP == 2): ~6e-5 relative error at 2x the MFMA time of a 16-bit model -- the cheapest mode inside north_star's 1e-3 bound
+SUPPORTS_FP32_FAST = True
+
+
+def _pack_dt(w: torch.Tensor, taps_hw: int, fast: bool) -> int:
+    """dtype code a weight is packed with: fp32 weights of multi-tap convolutions take the fast layout when asked to"""
+    if fast and w.dtype == torch.float32 and taps_hw > 1:
+        return L.F32Q
+    return _dt(w.dtype)
 
 
 def _dt(t: torch.dtype) -> int:
@@ -78,17 +88,18 @@ class PackedConv:
     alg_taps: int = 0        # taps of the REFERENCE op when the packed weights are a folded form (0: kT*kH*kW)
     time_folds: bool = False  # packed with the time-fold slots (pack_weight_tfolds / pack_weight_upfold(time_folds=True))
     wscale: float = 1.0       # fp32 (split-precision) weights were packed as w * wscale (a power of two); conv() undoes it
+    dt: int = -1              # dtype code of the packed layout (L.F32 / L.F32Q for fp32 weights); -1: that of the input tensor
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
                 strides: Optional[Tuple[int, int, int]] = None, cout: Optional[int] = None, cin: Optional[int] = None,
                 out: Optional[torch.Tensor] = None, fold: Tuple[int, int] = (1, 0), offset: int = 0,
-                wscale: Optional[float] = None) -> PackedConv:
+                wscale: Optional[float] = None, fast: bool = False) -> PackedConv:
     """Pack a conv / linear weight ([Cout, Cin, *k] contiguous, or any strided view described by `strides` =
     (s_co, s_ci, s_tap) in elements) into MFMA fragment order for cvvae_conv_fwd."""
     lib = L.load()
     _need_gpu(w)
-    dt = _dt(w.dtype)
+    dt = _pack_dt(w, k[1] * k[2], fast)
     taps = k[0] * k[1] * k[2]
     if strides is None:
         w = w.contiguous()
@@ -114,7 +125,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     b = torch.zeros(round_up(cout_, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_, wscale=ws)
+    return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_, wscale=ws, dt=dt)
 
 
 @dataclass
@@ -146,12 +157,12 @@ def pack_weight_batched(w: torch.Tensor, k: Tuple[int, int, int], cin_pad: int, 
     return PackedConv(out, b, cout, cin_pad, tuple(k), cin, batch_stride=per)
 
 
-def pack_weight_tfolds(w: torch.Tensor, bias: Optional[torch.Tensor], cin_pad: Optional[int] = None) -> PackedConv:
+def pack_weight_tfolds(w: torch.Tensor, bias: Optional[torch.Tensor], cin_pad: Optional[int] = None, fast: bool = False) -> PackedConv:
     """[Cout, Cin, 3, kH, kW] weight -> packed weights with the three time-fold slots appended (cvvae_pack_weights_tfolds):
     for convs with REPLICATE time padding, where boundary frames read one stored frame through two or three time taps."""
     lib = L.load()
     _need_gpu(w)
-    dt = _dt(w.dtype)
+    dt = _pack_dt(w, w.shape[3] * w.shape[4], fast)
     assert w.dim() == 5 and w.shape[2] == 3
     w = w.contiguous()
     co, ci, _, kh, kw = w.shape
@@ -168,10 +179,11 @@ def pack_weight_tfolds(w: torch.Tensor, bias: Optional[torch.Tensor], cin_pad: O
     b = torch.zeros(round_up(co, 32), dtype=torch.float32, device=w.device)
     if bias is not None:
         b[:co] = bias.detach().to(torch.float32)
-    return PackedConv(out, b, co, cin_pad, k, ci, time_folds=True, wscale=ws)
+    return PackedConv(out, b, co, cin_pad, k, ci, time_folds=True, wscale=ws, dt=dt)
 
 
-def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin_pad: Optional[int] = None) -> PackedConv:
+def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin_pad: Optional[int] = None,
+                   fast: bool = False) -> PackedConv:
     """[Cout, Cin, 3, kH, kW] weight -> the 1 x kH x kW weight a single-frame input sees: mode 'sum' (replicate time padding:
     all three time taps read the one frame) or 'center' (zero time padding: only the centre tap reads data)."""
     assert w.dim() == 5 and w.shape[2] == 3 and mode in ("sum", "center")
@@ -179,17 +191,18 @@ def pack_weight_t1(w: torch.Tensor, bias: Optional[torch.Tensor], mode: str, cin
     co, ci, _, kh, kw = w.shape
     hw = kh * kw
     pw = pack_weight(w, bias, (1, kh, kw), cin_pad=cin_pad, strides=(ci * 3 * hw, 3 * hw, 1), cout=co, cin=ci,
-                     fold=(3, hw) if mode == "sum" else (1, 0), offset=0 if mode == "sum" else hw)
+                     fold=(3, hw) if mode == "sum" else (1, 0), offset=0 if mode == "sum" else hw, fast=fast)
     pw.alg_taps = 3 * hw
     return pw
 
 
-def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int = 0, time_folds: bool = False) -> PackedConv:
+def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int = 0, time_folds: bool = False,
+                       fast: bool = False) -> PackedConv:
     """Upsample3D's conv weight [Cout, Cin, 3, 3, 3] -> the four folded 3x2x2 phase weights (cvvae_pack_weights_upfold) for
     conv(..., upsample2x=2).  tfold 1 / 2 (single-frame input: time taps summed / centre tap only): 1x2x2 phases."""
     lib = L.load()
     _need_gpu(w)
-    dt = _dt(w.dtype)
+    dt = _pack_dt(w, 4, fast)
     w = w.contiguous()
     cout_, cin_ = w.shape[0], w.shape[1]
     assert w.numel() == cout_ * cin_ * 27
@@ -210,7 +223,7 @@ def pack_weight_upfold(w: torch.Tensor, bias: Optional[torch.Tensor], tfold: int
     if bias is not None:
         b[:cout_] = bias.detach().to(torch.float32)
     return PackedConv(out, b, cout_, cin_pad, (1, 3, 3) if tfold else (3, 3, 3), cin_, folded=True, alg_taps=27,
-                      time_folds=time_folds, wscale=ws)
+                      time_folds=time_folds, wscale=ws, dt=dt)
 
 
 def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO,
@@ -227,6 +240,10 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     _need_gpu(x)
     assert x.dim() == 5 and x.is_contiguous()
     dt = _dt(x.dtype)
+    if dt == L.F32 and pw.dt == L.F32Q:  # the layout the weights were packed in selects the fp32 arithmetic of this launch
+        if shortcut is not None:
+            raise ValueError("fast-fp32 weights (CVVAE_F32Q) have no fused-shortcut kernel: run the 1x1 shortcut as its own launch")
+        dt = L.F32Q
     B, Ti, Hi, Wi, Cs = x.shape
     assert Cs >= pw.cin, f"input has {Cs} channels, packed weights consume {pw.cin}"
     kT, kH, kW = pw.k

@@ -23,13 +23,18 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 7
+#define CVVAE_ABI_VERSION 8
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
  * fp16 hi + lo and run each product as three fp16 MFMAs into fp32 accumulators ("split precision": ~1e-6 relative error at 3x
- * the MFMA work) -- the parity mode that meets north_star's |delta| <= 1e-3 on latents as a maximum. */
-enum { CVVAE_F16 = 0, CVVAE_BF16 = 1, CVVAE_F32 = 2 };
+ * the MFMA work) -- the parity mode that meets north_star's |delta| <= 1e-3 on latents as a maximum.
+ * CVVAE_F32Q = the same float tensors with the two correction terms of every product on the fp8 matrix pipe
+ * (Whi.hi on the fp16 MFMA + bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi) on v_mfma_f32_32x32x64_f8f6f4, one per pair of taps): ~2^-14
+ * relative error per product at 2x the MFMA time of a 16-bit model -- the CHEAPEST mode that meets the 1e-3 bound.  It exists
+ * for convolutions with more than one tap (cvvae_pack_weights* and cvvae_conv_fwd* with kH*kW > 1, no fused shortcut); 1x1x1
+ * layers of such a model run as CVVAE_F32.  Every other entry point takes CVVAE_F32 for float tensors. */
+enum { CVVAE_F16 = 0, CVVAE_BF16 = 1, CVVAE_F32 = 2, CVVAE_F32Q = 3 };
 enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
 enum { CVVAE_PRO_NONE = 0, CVVAE_PRO_GN_SILU = 1, CVVAE_PRO_GN = 2 };   /* fused prologue on the input */
 enum { CVVAE_OUT_NDHWC = 0, CVVAE_OUT_NCDHW = 1, CVVAE_OUT_TIME_SHUFFLE = 2 };
@@ -61,8 +66,8 @@ static inline int cvvae_conv_kchunk(int kT, int kH, int kW) {
  *   nn.Linear / 1x1 Conv2d of the attention blocks (kT=kH=kW=1)
  */
 typedef struct cvvae_conv_desc {
-  int32_t dtype;              /* CVVAE_F16 | CVVAE_BF16: input, weights, residual, (non-f32) output; CVVAE_F32: float input /
-                               * residual / shortcut input / output, weights packed from float with dtype CVVAE_F32 */
+  int32_t dtype;              /* CVVAE_F16 | CVVAE_BF16: input, weights, residual, (non-f32) output; CVVAE_F32 / CVVAE_F32Q: float
+                               * input / residual / shortcut input / output, weights packed from float with the SAME dtype code */
   /* input, NDHWC, as stored */
   int32_t B, Ti, Hi, Wi;
   int32_t Cin;                /* channels consumed; multiple of cvvae_conv_kchunk(); extra channels must have zero weights */

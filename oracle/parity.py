@@ -20,6 +20,21 @@ REFERENCE_SELF_NOISE = {
 }
 
 
+def reference_self_noise(case: str, tag: str, golden_dir: str = GOLDEN_DIR):
+    """how far the reference's OWN fp16 / bf16 CPU run is from its fp32 run on fixture `case` (tests/golden/ref_self_noise.json,
+    written by oracle/make_noise.py with the metric of measure() below); the T=9 96x96 probe above when that shape was not run"""
+    import json
+    path = os.path.join(golden_dir, "ref_self_noise.json")
+    if os.path.isfile(path):
+        with open(path) as f:
+            e = json.load(f).get(case, {}).get(tag)
+        if e:
+            return {"latent_max": e["latent_max_abs"], "latent_mean": e["latent_mean_abs"], "recon_psnr_db": e["recon_psnr_db"],
+                    "recon_max": e["recon_max_abs"], "shape": e["shape"], "source": "tests/golden/ref_self_noise.json"}
+    e = REFERENCE_SELF_NOISE.get(tag)
+    return dict(e, source="BASELINE.md section 2 (T=9, 96x96 probe)") if e else None
+
+
 def load_seeded(model, wseed: int):
     sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
     model.load_state_dict(sd, strict=True)

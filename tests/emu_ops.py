@@ -28,6 +28,7 @@ class FakePacked:
     time_folds: bool = False
     wscale: float = 1.0
     alg_taps: int = 0
+    dt: int = -1
 
 
 @dataclass
@@ -45,16 +46,19 @@ def _bias(cout, bias, dev):
     return b
 
 
-def pack_weight(w, bias, k, cin_pad=None, strides=None, cout=None, cin=None, fold=(1, 0), offset=0, out=None, wscale=None):
+def pack_weight(w, bias, k, cin_pad=None, strides=None, cout=None, cin=None, fold=(1, 0), offset=0, out=None, wscale=None, fast=False):
     assert strides is None and fold == (1, 0) and offset == 0
     taps = k[0] * k[1] * k[2]
     co, ci = w.shape[0], w.shape[1]
     ck = ops.kchunk(k)
     cp = ops.round_up(ci, ck) if cin_pad is None else cin_pad
-    return FakePacked(w.detach().float().reshape(co, ci, taps), _bias(co, bias, w.device), co, cp, tuple(k), ci)
+    # (the power-of-two pack scale of fp32 weights is recorded as the real packer records it -- the host logic reads it, e.g. the
+    #  fused-shortcut range check -- but the emulated weights stay unscaled: conv() below never divides by it)
+    ws = (ops._wscale(w) if wscale is None else float(wscale)) if w.dtype == torch.float32 else 1.0
+    return FakePacked(w.detach().float().reshape(co, ci, taps), _bias(co, bias, w.device), co, cp, tuple(k), ci, wscale=ws)
 
 
-def pack_weight_tfolds(w, bias, cin_pad=None):
+def pack_weight_tfolds(w, bias, cin_pad=None, fast=False):
     """the summed time slots only change HOW boundary frames are multiplied, not the result: the plain weight"""
     co, ci, _, kh, kw = w.shape
     pw = pack_weight(w.reshape(co, ci, 3 * kh * kw), bias, (3, kh, kw), cin_pad=cin_pad)
@@ -62,7 +66,7 @@ def pack_weight_tfolds(w, bias, cin_pad=None):
     return pw
 
 
-def pack_weight_t1(w, bias, mode, cin_pad=None):
+def pack_weight_t1(w, bias, mode, cin_pad=None, fast=False):
     """a single-frame input under replicate ('sum': all three time taps read the frame) / zero ('center') time padding"""
     co, ci, _, kh, kw = w.shape
     w2 = w.detach().float().sum(2) if mode == "sum" else w.detach().float()[:, :, 1]
@@ -71,7 +75,7 @@ def pack_weight_t1(w, bias, mode, cin_pad=None):
     return pw
 
 
-def pack_weight_upfold(w, bias, tfold=0, time_folds=False):
+def pack_weight_upfold(w, bias, tfold=0, time_folds=False, fast=False):
     """nearest-2x + conv with the phase-folded weights == the conv of the upsampled tensor with the plain weight"""
     co, ci = w.shape[0], w.shape[1]
     wf = w.detach().float().reshape(co, ci, 3, 3, 3)

@@ -123,3 +123,68 @@ def test_packed_weight_cache_roundtrip(tmp_path, monkeypatch):
         import cvvae_amd
         with pytest.warns(UserWarning):  # another model class: ignored before anything is read
             assert cvvae_amd.CVVAEModel().load_packed_weights(path) == 0
+
+
+def test_packed_weight_cache_skips_stale_entries(tmp_path):
+    """a warm-up pass, THEN new weights (load_state_dict / in-place edit), THEN save_packed_weights must not store the
+    old packed forms under the new parameters' fingerprints: stale cache entries are left out of the export, and a fresh model
+    that imports the file computes with the NEW weights."""
+    m = build("sd3", {}, 4)
+    x = seeded_input((1, 3, 5, 32, 32), 2)
+    path = str(tmp_path / "packed.pt")
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        z_old = m.encode(x).latent_dist.mode()                   # packs everything the encoder uses
+        n_all = len(m.encoder._cache().export_packed())
+        m.encoder.conv_in.weight.mul_(1.5)                       # in-place edit after the warm-up (what load_state_dict does)
+        sd = {k: v.clone() for k, v in m.state_dict().items()}
+        exp = m.encoder._cache().export_packed()
+        assert len(exp) == n_all - 1 and not any(t.startswith("conv_in") for t in exp)
+        m.save_packed_weights(path)
+        z_new = m.encode(x).latent_dist.mode()
+        assert not torch.equal(z_new, z_old)
+        m2 = build("sd3", {}, 4)
+        m2.load_state_dict(sd)
+        m2.load_packed_weights(path)
+        assert torch.equal(m2.encode(x).latent_dist.mode(), z_new)
+
+
+def test_encode_latents_flatten_frames_matches_reference_layout():
+    """DiffusionEngineFor3DVAE.encode_first_stage returns '(b t) c h w' for clips as well (diffusion.py:380-385)"""
+    m = build("sd3", {}, 4)
+    x = seeded_input((2, 3, 5, 32, 32), 3)
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        z5 = m.encode_latents(x, sample=False)
+        z4 = m.encode_latents(x, sample=False, flatten_frames=True)
+    assert z5.dim() == 5 and z4.dim() == 4 and z4.shape[0] == z5.shape[0] * z5.shape[2]
+    assert torch.equal(z4, z5.permute(0, 2, 1, 3, 4).reshape(z4.shape))
+
+
+def test_fp32_fused_shortcut_falls_back_when_scale_would_overflow():
+    """the fused 1x1 shortcut of an fp32 model shares conv2's power-of-two pack scale; with shortcut weights 64x
+    larger than conv2's the fp16 hi part would overflow -- the block must then run unfused, with the same result"""
+    from cvvae_amd import engine
+    m = build("sd3", {}, 4).float()
+    x = seeded_input((1, 3, 5, 32, 32), 2)
+    blk = m.encoder.down_blocks[1].resnets[0]
+    with torch.no_grad():
+        blk.conv_shortcut.weight.mul_(4096.0 / float(blk.conv_shortcut.weight.abs().max()) * float(blk.conv2.weight.abs().max()))
+    wc = m.encoder._cache()
+    calls = []
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        real = emu_ops.conv
+
+        def spy(xx, pw, **kw):
+            calls.append(kw.get("shortcut") is not None)
+            return real(xx, pw, **kw)
+        import cvvae_amd.ops as ops_mod
+        old = ops_mod.conv
+        ops_mod.conv = spy
+        try:
+            m.encode(x)
+        finally:
+            ops_mod.conv = old
+        pw2 = wc.conv("down_blocks.1.resnets.0.conv2", (1, 3, 3))
+        assert not engine._shortcut_scale_fits(wc, "down_blocks.1.resnets.0.conv_shortcut", pw2, torch.float32)
+        assert engine._shortcut_scale_fits(wc, "down_blocks.2.resnets.0.conv_shortcut",
+                                           wc.conv("down_blocks.2.resnets.0.conv2", (1, 3, 3)), torch.float32)
+    assert sum(calls) == 1, "only the other channel-changing block keeps its fused shortcut"

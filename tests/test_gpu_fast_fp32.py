@@ -1,0 +1,137 @@
+"""Fast fp32 (`fp32_mode = "fast"`, C-ABI dtype CVVAE_F32Q): every kernel family of the mode against a plain PyTorch fp32
+evaluation of the same op on the same inputs, and the model-level parity that is the point of the mode -- north_star's
+|delta| <= 1e-3 on the latent AS A MAXIMUM at twice (not three times) the MFMA time of a 16-bit model.
+
+The arithmetic: x = hi + lo, w = Whi + Wlo (fp16 pairs);  w.x ~ Whi.hi (fp16 MFMA) + bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi), the
+two correction terms of two taps in one v_mfma_f32_32x32x64_f8f6f4 (conv_kernel.h XP == 2).  CPU prediction of the error:
+oracle/precision_ladder.py."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.test_gpu_ops import DEV, FAST_ULP, REP, ZERO, _ops, rnd, run_conv_case, to_ncdhw, to_ndhwc
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+
+
+@pytest.mark.parametrize("Cout", [128, 256, 32, 3])
+def test_fast_conv333_sd3_causal(Cout):
+    L = _ops()[1]
+    run_conv_case(F32, 128, Cout, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 24, 40),
+                  out_mode=L.OUT_NCDHW if Cout <= 32 else L.OUT_NDHWC, fast=True)
+
+
+@pytest.mark.parametrize("mode", [(REP, REP), (ZERO, ZERO), (REP, ZERO)])
+def test_fast_conv333_prologue(mode):
+    run_conv_case(F32, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), mode[0], mode[1], (2, 4, 20, 36), prologue=1,
+                  fast=True)
+
+
+@pytest.mark.parametrize("stride", [(2, 2, 2), (1, 2, 2)])
+def test_fast_conv333_downsample(stride):
+    run_conv_case(F32, 128, 128, (3, 3, 3), stride, ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 24, 40), fast=True)
+    run_conv_case(F32, 128, 128, (3, 3, 3), stride, ((2, 0), (0, 1), (0, 1)), REP, ZERO, (1, 5, 24, 40), fast=True)
+
+
+@pytest.mark.parametrize("tpad", [(2, 0), (1, 1)])
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_fast_conv333_time_folds(tpad, T):
+    run_conv_case(F32, 128, 256, (3, 3, 3), (1, 1, 1), (tpad, (1, 1), (1, 1)), REP, REP, (1, T, 16, 40), prologue=1,
+                  time_folds=True, tol=2 * 3 * FAST_ULP, fast=True)
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+@pytest.mark.parametrize("time_folds", [False, True])
+def test_fast_upsample_folded(shuffle, time_folds):
+    L = _ops()[1]
+    run_conv_case(F32, 256, 512 if shuffle else 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (1, 3, 12, 20),
+                  ups=2, out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC, time_folds=time_folds, tol=2 * FAST_ULP,
+                  fast=True)
+
+
+@pytest.mark.parametrize("Cout", [128, 256])
+def test_fast_conv133_prologue_residual(Cout):
+    run_conv_case(F32, Cout, Cout, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, (2, 3, 24, 40), prologue=1,
+                  residual=True, fast=True)
+
+
+@pytest.mark.parametrize("case", ["sum", "center", "sum_down", "sum_up", "center_up_shuffle"])
+def test_fast_single_frame_temporal_fold(case):
+    """image mode: the folded 1x3x3 / strided 1x3x3 / 1x2x2-phase instances of the fast mode"""
+    ops, L = _ops()
+    Cin, Cout = 256, 256
+    mode_t = ZERO if case.startswith("center") else REP
+    stride = (2, 2, 2) if case == "sum_down" else (1, 1, 1)
+    ups = case.endswith("up") or case.endswith("up_shuffle")
+    shuffle = case.endswith("shuffle")
+    padt = (2, 0) if case == "sum_down" else (1, 1)
+    B, H, W = 2, 12, 20
+    x = rnd((B, Cin, 1, H, W), F32, 1, 1.0)
+    w = rnd((Cout, Cin, 3, 3, 3), F32, 2, 1.0 / (Cin * 27) ** 0.5)
+    bias = rnd((Cout,), F32, 3, 0.1)
+    xr = x
+    if ups:
+        xr = F.interpolate(xr, scale_factor=(1.0, 2.0, 2.0), mode="nearest")
+    (hf, hb), (wf, wb) = (1, 1), (1, 1)
+    xr = F.pad(xr, (wf, wb, hf, hb, 0, 0), mode="replicate")
+    xr = F.pad(xr, (0, 0, 0, 0) + padt, mode="replicate") if mode_t == REP else F.pad(xr, (0, 0, 0, 0) + padt)
+    ref = F.conv3d(xr, w, bias, stride=stride)
+    if shuffle:
+        b_, nc, t_, h_, w_ = ref.shape
+        ref = ref.reshape(b_, 2, nc // 2, t_, h_, w_).permute(0, 2, 3, 1, 4, 5).reshape(b_, nc // 2, 2 * t_, h_, w_)[:, :, 1:]
+    xd = to_ndhwc(x).to(DEV)
+    if ups:
+        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), 2 if mode_t == ZERO else 1, fast=True)
+        out = ops.conv(xd, pw, pad=((0, 0), (1, 1), (1, 1)), pad_mode_hw=REP, upsample2x=2,
+                       out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC)
+    else:
+        pw = ops.pack_weight_t1(w.to(DEV), bias.to(DEV), "center" if mode_t == ZERO else "sum", fast=True)
+        out = ops.conv(xd, pw, stride=(1, stride[1], stride[2]), pad=((0, 0), (1, 1), (1, 1)), pad_mode_hw=REP)
+    assert pw.dt == L.F32Q
+    torch.cuda.synchronize()
+    got = to_ncdhw(out.float().cpu())
+    assert got.shape == ref.shape
+    err = (got - ref).abs().max().item()
+    assert err <= 2 * FAST_ULP * ref.abs().max().item() + 1e-6, err
+
+
+def test_fast_is_between_fp16_and_exact():
+    """the rung's place on the ladder, on one conv: error(exact) < error(fast) < error(fp16 model) by clear factors"""
+    errs = {}
+    for tag, dtype, fast in (("f16", torch.float16, False), ("fast", F32, True), ("exact", F32, False)):
+        errs[tag] = run_conv_case(dtype, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (1, 4, 20, 36),
+                                  prologue=1, fast=fast, tol=1.0)
+    print("relative max error of one 256->256 3x3x3 conv with fused GN+SiLU:", errs)
+    assert errs["exact"] * 4 < errs["fast"] < errs["f16"] / 4, errs
+
+
+def test_fast_rejects_what_it_has_no_kernel_for():
+    ops, L = _ops()
+    w = rnd((128, 128, 1, 1, 1), F32, 1, 0.1).to(DEV)
+    assert ops.pack_weight(w, None, (1, 1, 1), fast=True).dt == L.F32  # 1x1x1 weights stay in the three-MFMA layout
+    lib = L.load()
+    out = torch.zeros(1 << 20, dtype=torch.uint8, device=DEV)
+    rc = lib.cvvae_pack_weights(L.F32Q, w.data_ptr(), 128, 128, 1, 128, 1, 1, 128, 128, out.data_ptr(), None)
+    assert rc == -2
+
+
+@pytest.mark.parametrize("family", ["sd3", "vae3d"])
+def test_fast_model_meets_the_latent_bound_on_small_golden(family, golden_dir):
+    """whole model, small fixtures of the reference's own modules: latent max |delta| <= 1e-3 (north_star) in fast mode, and the
+    exact mode stays an order of magnitude below it"""
+    import cvvae_amd
+    from oracle import parity as P
+    name = f"{family}_t5_64"
+    cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
+    m = cls()
+    P.load_seeded(m, P.case_of(name)[3])
+    m = m.to(F32).cuda().eval()
+    m.fp32_mode = "fast"
+    rf = P.measure(m, name, golden_dir)
+    m.fp32_mode = "exact"
+    re_ = P.measure(m, name, golden_dir)
+    print("\n" + P.fmt("f32q", rf) + "\n" + P.fmt("f32", re_))
+    assert rf["latent_max_abs"] <= 1.0e-3 and rf["recon_psnr_db"] >= 80.0, rf
+    assert re_["latent_max_abs"] <= 1.0e-4, re_
+    assert re_["latent_max_abs"] < rf["latent_max_abs"]

@@ -11,6 +11,9 @@ DEV = "cuda"
 
 # one-rounding error of the storage dtype relative to the data range; fp32: split-precision products + summation order
 ULP = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11, torch.float32: 4e-6}
+# fast fp32 (one fp16 MFMA + bf8 correction terms): each product is right to ~2^-14; over a dot product the errors add like a
+# random walk, so relative to the largest output ~2^-15 is typical -- the band leaves a factor of ~4
+FAST_ULP = 1.2e-4
 
 
 def _ops():
@@ -42,7 +45,8 @@ def ref_pad(x, pad, mode_t, mode_hw):
 
 
 def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prologue=0, ups=False, out_mode=0,
-                  residual=False, seed=0, tol=None, time_folds=False):
+                  residual=False, seed=0, tol=None, time_folds=False, fast=False):
+    """fast (fp32 only): weights packed for the fast-fp32 kernels (CVVAE_F32Q: fp16 MFMA + bf8 correction MFMA)"""
     ops, L = _ops()
     if dtype == torch.float32 and ups is True:
         pytest.skip("the 27-tap gather form of the upsample conv (CVVAE_FOLD_UPSAMPLE=0 tuning path) has no split-precision instance")
@@ -79,9 +83,9 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         xp[..., :Cin] = xd
         xd = xp
     if time_folds:  # packed with the summed time slots for boundary frames (cvvae_pack_weights_tfolds)
-        pw = ops.pack_weight_tfolds(w.to(DEV), bias.to(DEV), cin_pad=cin_pad)
+        pw = ops.pack_weight_tfolds(w.to(DEV), bias.to(DEV), cin_pad=cin_pad, fast=fast)
     else:
-        pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k, cin_pad=cin_pad)
+        pw = ops.pack_weight(w.to(DEV), bias.to(DEV), k, cin_pad=cin_pad, fast=fast)
     gn = None
     if prologue:
         g = torch.zeros(cin_pad); g[:Cin] = gamma
@@ -89,7 +93,7 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         assert cin_pad == Cin, "prologue cases use channel counts that need no padding"
         gn = ops.gn_stats(xd, g.to(DEV), bb.to(DEV), 1e-6)
     if ups == 2:
-        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), time_folds=time_folds)
+        pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), time_folds=time_folds, fast=fast)
     out = ops.conv(xd, pw, stride=stride, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=prologue, gn=gn,
                    residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode)
     torch.cuda.synchronize()
@@ -102,7 +106,7 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
     if tol is None:
         # inputs are exact in 16 bit; remaining error = fp32 accumulation order + one output rounding
         # (+ one rounding of the GN/SiLU operand when the prologue is fused)
-        base = ULP[dtype]
+        base = FAST_ULP if fast else ULP[dtype]
         tol = base * (3.0 if prologue else 1.0)
     assert err <= tol * scale + 1e-6, f"max err {err:.4g} vs scale {scale:.4g} (tol {tol * scale:.4g})"
     return err / scale
