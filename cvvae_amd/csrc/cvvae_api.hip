@@ -334,11 +334,14 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.out_mode = d->out_mode;
   a.out_f32 = d->out_f32;
   a.gn_rpb = d->gn_rows_per_batch;
-  a.order = 1;
-  if (const char* f = getenv("CVVAE_CONV_ORDER")) a.order = atoi(f) ? 1 : 0;  // tuning aid
+  // tuning / debug aids, read ONCE per process (a launch never calls getenv)
+  static const int env_order = getenv("CVVAE_CONV_ORDER") ? (atoi(getenv("CVVAE_CONV_ORDER")) ? 1 : 0) : 1;
+  static const int env_noshift = getenv("CVVAE_STATS_NOSHIFT") ? atoi(getenv("CVVAE_STATS_NOSHIFT")) : 0;
+  a.order = env_order;
   a.alpha = d->alpha;
-  if (const char* f = getenv("CVVAE_STATS_NOSHIFT")) a.stats_noshift = atoi(f);  // debug aid
-  if (const char* f = getenv("CVVAE_CONV_PHASE_SYNC")) a.phase_sync = atoi(f) ? 1 : 0;  // tuning aid (conv_kernel.h phase_sync)
+  a.stats_noshift = env_noshift;
+  // (two knobs stay per launch because the GPU tests flip them inside one process: CVVAE_CONV_FORCE in select_instance and this one)
+  if (const char* f = getenv("CVVAE_CONV_PHASE_SYNC")) a.phase_sync = atoi(f) ? 1 : 0;  // conv_kernel.h phase_sync
   a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1) * xpm;
   static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid
   a.res_pre = (residual && d->alpha == 1.0f && !d->out_f32 && !res_pre_off) ? 1 : 0;

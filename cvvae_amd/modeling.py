@@ -551,20 +551,26 @@ class _CVVAEBase(nn.Module):
             return b
 
     # ---- spatial tiles (modeling_vae.py:144-191, 230-277) ---------------------------------------------
-    def _spatial_tiled(self, x, net, tile, stride, overlap_out, stride_out, hdim=3, wdim=4, **kwargs):
-        """hdim / wdim: the H and W axes of the INPUT (3, 4 for NCDHW; 2, 3 for the NDHWC clips of encode_frames_u8); the
-        network outputs are always NCDHW."""
+    @staticmethod
+    def _tile_grid(H: int, W: int, tile: int, stride: int):
+        """the reference's tile loop (modeling_vae.py:150-160): rows of (i, j, h, w) input windows, start step `stride`, a row /
+        column loop ends at the first tile that reaches the edge"""
         rows = []
-        H, W = x.shape[hdim], x.shape[wdim]
         for i in range(0, H, stride):
             cols = []
             for j in range(0, W, stride):
-                cols.append(net(x.narrow(hdim, i, min(tile, H - i)).narrow(wdim, j, min(tile, W - j))))
+                cols.append((i, j, min(tile, H - i), min(tile, W - j)))
                 if j + tile >= W:
                     break
             rows.append(cols)
             if i + tile >= H:
                 break
+        return rows
+
+    def _assemble_tiles(self, rows, overlap_out, stride_out):
+        """blend (in place, in the reference's order: every tile with its already blended upper, then left neighbour), crop
+        all but the last tile of a row / column to `stride_out`, concatenate (modeling_vae.py:161-191).  rows: network outputs
+        (NCDHW) in the order of _tile_grid."""
         res = []
         for i, cols in enumerate(rows):
             rc = []
@@ -585,6 +591,23 @@ class _CVVAEBase(nn.Module):
                 cols[j] = t
             out_rows.append(torch.cat(cols, dim=4))
         return torch.cat(out_rows, dim=3)
+
+    def _spatial_tiled(self, x, net, tile, stride, overlap_out, stride_out, hdim=3, wdim=4, **kwargs):
+        """hdim / wdim: the H and W axes of the INPUT (3, 4 for NCDHW; 2, 3 for the NDHWC clips of encode_frames_u8); the
+        network outputs are always NCDHW."""
+        grid = self._tile_grid(x.shape[hdim], x.shape[wdim], tile, stride)
+        rows = [[net(x.narrow(hdim, i, h).narrow(wdim, j, w)) for (i, j, h, w) in cols] for cols in grid]
+        return self._assemble_tiles(rows, overlap_out, stride_out)
+
+    def _tile_params(self, encode: bool):
+        """(input tile, input stride, output overlap, output stride) of the spatial tiling, or None when tiling is off"""
+        if self.pixel_tile_size is None:
+            return None
+        if encode:
+            ov = round(self.latent_tile_size * self.tile_overlap_ratio)
+            return (self.pixel_tile_size, round(self.pixel_tile_size * (1 - self.tile_overlap_ratio)), ov, self.latent_tile_size - ov)
+        ov = round(self.pixel_tile_size * self.tile_overlap_ratio)
+        return (self.latent_tile_size, round(self.latent_tile_size * (1 - self.tile_overlap_ratio)), ov, self.pixel_tile_size - ov)
 
     def spatial_tiled_encode(self, x, _ndhwc=False):
         # _ndhwc (private): x is a channel-padded NDHWC clip [B,T,H,W,Cpad] straight from the device-side pre-processing
