@@ -268,9 +268,12 @@ def main():
         from cvvae_amd import dist as D
 
         def step():
-            mom = D.encode_windows_sharded(vae, x)                     # all_gather of the latents (15 MB)
+            # (window x spatial tile) network calls split over the ranks (8 x 6 = 48 units at cfg 4: one window per rank on 8 GPUs,
+            # no tile traffic; fewer windows than ranks -> the tiles of a window spread out, raw tiles go point-to-point to the
+            # rank that blends the window)
+            mom = D.encode_units_sharded(vae, x)                       # all_gather of the latents (15 MB)
             z = mom[:, :mom.shape[1] // 2]
-            return D.decode_windows_sharded(vae, z, gather=False)      # pixels stay sharded (713 MB if gathered)
+            return D.decode_units_sharded(vae, z, gather=False)        # pixels stay sharded (713 MB if gathered)
     elif cfg5:
         def step():
             return vae.encode_latents(x, sample=False)                 # the latent pre-compute API
@@ -294,8 +297,12 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert cfg5 or (cfg4 and dist is not None) or y.shape == x.shape
+    rank_times = None
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        ts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(ts, t)                      # per-rank clocks (diagnostic); the reported time is their MAX
+        rank_times = [round(float(v.item()) / args.steps * 1e3, 3) for v in ts]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -319,8 +326,16 @@ def main():
         "config": {"workload": f"{args.workload}: {family} " + ("encode(x).mode()" if cfg5 else "encode(x).mode() + decode(z)") +
                                f", x=[{B},3,{T},{H},{W}] per GPU",
                    "clips_per_gpu": B, "hip_graphs": bool(args.hip_graphs),
-                   "parallelism": (f"temporal windows sharded x{world}, latents all-gathered" if strong else
+                   "parallelism": (f"(temporal window x spatial tile) network calls sharded x{world}, latents all-gathered" if strong else
                                    f"independent clips x{world} (no collective)")},
+        "multi_gpu": None if dist is None else {
+            "n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
+            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+            "ms_per_step_by_rank": rank_times, "devices": torch.cuda.device_count(),
+            "device_name": torch.cuda.get_device_name(local_rank),
+            "data_path_collectives": ("all_gather of the latents (15 MB) once per step; tile results point-to-point only when a "
+                                      "window's tiles span ranks") if strong else "none (independent clips)",
+            "note": "value = work of all ranks / MAX over ranks of the barrier-bracketed time"},
         "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * units / elapsed, 1),
         "hbm": {"algorithmic_gbps": round(ALG_GB[args.workload] * units / elapsed, 1), "peak_gbps": HBM_PEAK_GBPS,
                 "note": "algorithmic bytes (BASELINE.md section 3) / step time; the path is MFMA-bound (AI ~1900 FLOP/B)"},
@@ -329,7 +344,7 @@ def main():
     if cfg4 and dist is not None and not args.no_check:
         # the sharded run must reproduce the single-process wrapper bit for bit (windows are independent network calls)
         from cvvae_amd import dist as D
-        mom = D.encode_windows_sharded(vae, x)
+        mom = D.encode_units_sharded(vae, x)
         ok = True
         if rank == 0:
             ref = vae.encode(x).latent_dist.parameters

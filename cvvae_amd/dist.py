@@ -10,6 +10,12 @@ window, so sharding windows across ranks is reference-exact.  Two
     left neighbour travels by point-to-point send/recv ("causal halo exchange": 5.5 MB of pixels for encode at
     720x1280, 0.46 MB of latents for decode) -- no ring, no all-reduce.
 
+  * window x tile units (`encode_units_sharded` / `decode_units_sharded`, replicated input) -- the finer partition SURVEY 8(e)
+    names: every (window, spatial tile) network call is one unit (cfg 4: 8 x 6 = 48), split over the ranks in contiguous,
+    area-balanced runs; raw tile results travel point-to-point to the rank that owns the window, which blends and crops them
+    in the reference's order (modeling_vae.py:161-191).  A 17-frame 720p clip (ONE window) then keeps 6 GPUs busy, a 65-frame
+    one all 8.
+
 There is no collective inside the network itself.
 """
 from typing import List, Optional, Tuple
@@ -136,3 +142,144 @@ def encode_windows_sharded(model, x: torch.Tensor, T_total: Optional[int] = None
 def decode_windows_sharded(model, z: torch.Tensor, T_total: Optional[int] = None, time_sharded: bool = False,
                            gather: bool = True, group=None):
     return _sharded(model, z, z.shape[2] if T_total is None else T_total, False, time_sharded, gather, group)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# window x tile units
+# ------------------------------------------------------------------------------------------------------------------------
+def balanced_runs(cost: List[int], world: int) -> List[Tuple[int, int]]:
+    """contiguous runs [a, b) of the units, one per rank, with the smallest possible maximum run cost (linear partition: binary
+    search on the bound, greedy fill); ranks left over are given work by splitting the costliest multi-unit runs, so that as
+    many ranks as there are units are busy.  A rank may get nothing when there are fewer units than ranks."""
+    n = len(cost)
+
+    def fill(limit):
+        runs, a, acc = [], 0, 0
+        for i, c in enumerate(cost):
+            if acc and acc + c > limit:
+                runs.append((a, i))
+                a, acc = i, 0
+            acc += c
+        runs.append((a, n))
+        return runs
+
+    lo, hi = max(cost), sum(cost)
+    while lo < hi:
+        mid = (lo + hi) // 2
+        if len(fill(mid)) <= world:
+            hi = mid
+        else:
+            lo = mid + 1
+    runs = fill(lo)
+    run_cost = lambda r: sum(cost[r[0]:r[1]])  # noqa: E731
+    while len(runs) < world:
+        multi = [r for r in runs if r[1] - r[0] > 1]
+        if not multi:
+            break
+        a, b = max(multi, key=run_cost)
+        # split where the two halves are closest
+        best = min(range(a + 1, b), key=lambda k: abs(sum(cost[a:k]) - sum(cost[k:b])))
+        i = runs.index((a, b))
+        runs[i:i + 1] = [(a, best), (best, b)]
+    runs += [(n, n)] * (world - len(runs))
+    return runs
+
+
+def unit_plan(model, shape, encode: bool, world: int):
+    """-> (windows [(a, b)], tile grid rows [(i, j, h, w)], units [(n, r, c)], owner of every unit, owner of every window)"""
+    T, H, W = shape[2], shape[3], shape[4]
+    tstride = model.encode_n_frames_a_time if encode else model.decode_n_frames_a_time
+    wins = [(a, min(b, T)) for a, b in model._windows(T, tstride)] if tstride is not None else [(0, T)]
+    tp = model._tile_params(encode)
+    grid = model._tile_grid(H, W, tp[0], tp[1]) if tp is not None else [[(0, 0, H, W)]]
+    units = [(n, r, c) for n in range(len(wins)) for r, row in enumerate(grid) for c in range(len(row))]
+    cost = [(wins[n][1] - wins[n][0]) * grid[r][c][2] * grid[r][c][3] for n, r, c in units]
+    runs = balanced_runs(cost, world)
+    owner = [next(rk for rk, (a, b) in enumerate(runs) if a <= u < b) for u in range(len(units))]
+    per_win = len(units) // len(wins)
+    wowner = [owner[n * per_win] for n in range(len(wins))]  # the rank that holds the window's first tile assembles it
+    return wins, grid, units, owner, wowner
+
+
+def _units_sharded(model, x: torch.Tensor, encode: bool, gather: bool, group=None):
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    wins, grid, units, owner, wowner = unit_plan(model, x.shape, encode, world)
+    net = model.encoder if encode else model.decoder
+    tp = model._tile_params(encode)
+    tnc, snc = model.config.time_n_compress, model.config.spatial_n_compress
+    cout = [net.conv_out.weight.shape[0] if hasattr(net, "conv_out") else 0]
+
+    def out_shape(u):  # what the network returns for unit u (receivers allocate from geometry alone)
+        n, r, c = units[u]
+        f = wins[n][1] - wins[n][0]
+        _, _, h, w = grid[r][c]
+        if encode:
+            return (x.shape[0], cout[0], 1 + (f - 1) // tnc, h // snc, w // snc)
+        return (x.shape[0], cout[0], 1 + (f - 1) * tnc, h * snc, w * snc)
+
+    outs = {}
+    for u, (n, r, c) in enumerate(units):
+        if owner[u] != rank:
+            continue
+        i, j, h, w = grid[r][c]
+        o = net(x[:, :, wins[n][0]:wins[n][1], i:i + h, j:j + w])
+        cout[0] = cout[0] or o.shape[1]
+        assert tuple(o.shape) == out_shape(u), (tuple(o.shape), out_shape(u))
+        outs[u] = o
+    if not hasattr(net, "conv_out"):  # (a network without the shipped layout: the ranks agree on its channel count)
+        c = torch.tensor([cout[0]], device=x.device)
+        dist.all_reduce(c, op=dist.ReduceOp.MAX, group=group)
+        cout[0] = int(c.item())
+    # raw tiles to the owner of their window (both sides walk the units in the same order: FIFO per pair, tags for gloo)
+    ops_p2p = []
+    for u, (n, r, c) in enumerate(units):
+        src, dst = owner[u], wowner[n]
+        if src == dst:
+            continue
+        if rank == src:
+            ops_p2p.append(dist.P2POp(dist.isend, outs[u].contiguous(), dst, group, tag=u))
+        elif rank == dst:
+            outs[u] = torch.empty(out_shape(u), dtype=x.dtype, device=x.device)
+            ops_p2p.append(dist.P2POp(dist.irecv, outs[u], src, group, tag=u))
+    if ops_p2p:
+        for q in dist.batch_isend_irecv(ops_p2p):
+            q.wait()
+    # assemble my windows (blend in place in the reference's order, crop, concatenate), drop frame 0 of every window but the first
+    mine = []
+    per_win = len(units) // len(wins)
+    for n in range(len(wins)):
+        if wowner[n] != rank:
+            continue
+        rows, u = [], n * per_win
+        for row in grid:
+            rows.append([outs[u + k] for k in range(len(row))])
+            u += len(row)
+        o = model._assemble_tiles(rows, tp[2], tp[3]) if tp is not None else rows[0][0]
+        mine.append(o if n == 0 else o[:, :, 1:])
+    out = torch.cat(mine, dim=2) if mine else None
+    if not gather:
+        return out
+    counts = []
+    for rk in range(world):
+        cnt = 0
+        for n in range(len(wins)):
+            if wowner[n] == rk:
+                f = wins[n][1] - wins[n][0]
+                cnt += (1 + (f - 1) // tnc if encode else 1 + (f - 1) * tnc) - (0 if n == 0 else 1)
+        counts.append(cnt)
+    if out is None:
+        ref = out_shape(0)
+        full_h = x.shape[3] // snc if encode else x.shape[3] * snc
+        full_w = x.shape[4] // snc if encode else x.shape[4] * snc
+        out = x.new_zeros((ref[0], ref[1], 0, full_h, full_w))
+    return _gather_time(out, counts, group)
+
+
+def encode_units_sharded(model, x: torch.Tensor, gather: bool = True, group=None):
+    """moments of the whole clip with the (window x spatial tile) network calls split over the ranks; x: the full clip on
+    every rank.  Equal to model.encode(x).latent_dist.parameters bit for bit."""
+    return _units_sharded(model, x, True, gather, group)
+
+
+def decode_units_sharded(model, z: torch.Tensor, gather: bool = True, group=None):
+    return _units_sharded(model, z, False, gather, group)

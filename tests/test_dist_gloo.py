@@ -115,3 +115,68 @@ def test_real_model_window_sharding_on_emulated_kernels():
         assert p.exitcode == 0
     for rank, ok_e, ok_d, se, sy in res:
         assert ok_e and ok_d, (rank, se, sy)
+
+
+def _worker_units(rank, world, port, T, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.test_host_logic import make
+        from cvvae_amd import dist as D
+        m = make("sd3", tile_spatial_size=144)
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand((1, 3, T, 160, 200), generator=g) * 2 - 1
+        full = m.encode(x).latent_dist.parameters
+        wins, grid, units, owner, wowner = D.unit_plan(m, x.shape, True, world)
+        got = D.encode_units_sharded(m, x)
+        z = full[:, :4]
+        ref_y = m.decode(z).sample
+        y = D.decode_units_sharded(m, z)
+        mine = D.encode_units_sharded(m, x, gather=False)
+        q.put((rank, torch.equal(got, full), torch.equal(y, ref_y), len(units), sorted(set(owner)), None if mine is None else mine.shape[2]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,T", [(4, 33), (4, 17), (3, 49), (2, 5)])
+def test_window_x_tile_units_match_single_process(world, T):
+    """SURVEY 8(e) "windows x tiles": a 160x200 clip with 144-pixel tiles is a 2x2 tile grid per window; the (window, tile) network
+    calls are split over the ranks in contiguous area-balanced runs, raw tiles go point-to-point to the rank that assembles the
+    window, results are all-gathered: equal to the single-process wrapper bit for bit -- including a ONE-window clip (T = 17, 5)
+    whose four tiles keep four ranks busy, which the window partition cannot do."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_units, args=(r, world, port, T, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_e, ok_d, n_units, owners, _ in res:
+        assert ok_e and ok_d, rank
+        nwin = max(1, -(-(T - 1) // 16))
+        assert n_units == 4 * nwin
+        assert len(owners) == min(world, n_units), owners  # every rank that can have work has some
+
+
+def test_unit_plan_cfg4_and_short_clips():
+    """cfg 4 (129 frames, 720x1280): 8 windows x 6 tiles = 48 units, 6 per rank on 8 ranks, every window assembled by the rank that
+    computes it (no tile traffic).  A 17-frame 720p clip: 6 units on 6 of 8 ranks; a 65-frame one: all 8 ranks busy."""
+    import cvvae_amd
+    from cvvae_amd import dist as D
+    m = cvvae_amd.CVVAESD3Model.__new__(cvvae_amd.CVVAESD3Model)
+    torch.nn.Module.__init__(m)
+    m._init_common({})
+    wins, grid, units, owner, wowner = D.unit_plan(m, (1, 3, 129, 720, 1280), True, 8)
+    assert len(wins) == 8 and [len(r) for r in grid] == [3, 3] and len(units) == 48
+    assert [owner.count(r) for r in range(8)] == [6] * 8 and wowner == list(range(8))
+    assert all(owner[u] == wowner[units[u][0]] for u in range(48))
+    _, _, units, owner, wowner = D.unit_plan(m, (1, 3, 17, 720, 1280), True, 8)
+    assert len(units) == 6 and len(set(owner)) == 6 and len(set(wowner)) == 1
+    _, _, units, owner, _ = D.unit_plan(m, (1, 3, 65, 720, 1280), True, 8)
+    assert len(units) == 24 and len(set(owner)) == 8
+    # decode side: latent tiles of 72 with stride 56
+    wins, grid, units, owner, _ = D.unit_plan(m, (1, 16, 33, 90, 160), False, 8)
+    assert len(wins) == 8 and [len(r) for r in grid] == [3, 3] and [owner.count(r) for r in range(8)] == [6] * 8

@@ -246,6 +246,11 @@ def _nccl_worker(rank, world, port, q):
         a, b = D.owned_frames(Tz, 4, world, rank)
         y = D.decode_windows_sharded(m, z[:, :, a:b].contiguous(), T_total=Tz, time_sharded=True)
         ok_d = torch.equal(y, m.decode(z).sample)
+        # (window x tile) units: a ONE-window clip whose 2x2 tiles are split over the two ranks (raw tiles by batched send/recv)
+        x1 = x[:, :, :17].contiguous()
+        ok_e = ok_e and torch.equal(D.encode_units_sharded(m, x1), m.encode(x1).latent_dist.parameters)
+        z1 = z[:, :, :5].contiguous()
+        ok_d = ok_d and torch.equal(D.decode_units_sharded(m, z1), m.decode(z1).sample)
         q.put((rank, ok_e, ok_d))
     finally:
         dist.destroy_process_group()
