@@ -38,6 +38,7 @@ class ConvDesc(ctypes.Structure):
         ("w_batch_stride", ctypes.c_int64),
         ("sc_Cin", ctypes.c_int32), ("w_time_folds", ctypes.c_int32),
         ("sc_in_pix_stride", ctypes.c_int64),
+        ("in_overlap", ctypes.c_int32), ("reserved0", ctypes.c_int32),
     ]
 
 
@@ -71,6 +72,9 @@ PROTOTYPES = {
     "cvvae_transpose": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp]),
     "cvvae_temporal_attention": (_i32, [_i32, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp]),
     "cvvae_ncdhw_to_ndhwc": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_ncdhw_to_rowpack": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_conv_out_gather": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "cvvae_ndhwc_to_rowpack": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp, _vp]),
     "cvvae_ndhwc_to_ncdhw": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp]),
     "cvvae_frames_u8_to_ndhwc": (_i32, [_i32, _vp, _i64, _i32, _vp, _vp]),
     "cvvae_ncdhw_to_frames_u8": (_i32, [_i32, _vp, _i64, _vp, _vp]),

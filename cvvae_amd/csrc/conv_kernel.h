@@ -123,7 +123,7 @@ struct ConvArgs {
   int gn_rpb;
   float alpha;
   // fused GroupNorm statistics of the OUTPUT (NDHWC / time-shuffle modes): partial (n, mean, M2) records
-  float* gnp;        // [B][gn_slabs][gn_G][3], or null
+  float* gnp;        // [B][gn_G][gn_slabs][3], or null
   int gn_slabs;      // records per batch row and group = pixel tiles * WM * KG * (4-channel slots per group)
   int gn_G;          // groups of the stored tensor
   int gn_sh;         // log2(channels per group), >= 2
@@ -158,11 +158,14 @@ constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
 
 // XP: 0 = 16-bit model; 1 = fp32 model, three fp16 MFMAs per product ("exact"); 2 = fp32 model, one fp16 MFMA + bf8 correction
 // terms on the K = 64 fp8 MFMA ("fast", see conv_fwd_kernel)
-template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int XP = 0>
+// NB: 32-channel N-blocks per wave.  NB = 2: a wave multiplies every activation fragment it reads from LDS with TWO weight
+// fragments (a 2 x MREP register block): half the LDS operand reads per MFMA -- the LDS pipe (128 B/clk/CU = one 1-KiB fragment
+// per 8 clocks) is otherwise exactly saturated at the full MFMA rate of four SIMDs -- for twice the (L2-resident) weight stream.
+template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int XP = 0, int NB = 1>
 struct Geo {
   static constexpr int NTAPS = KT * KH * KW;
   static constexpr int BM = TT * TH * TW;
-  static constexpr int BN = 32 * WN;
+  static constexpr int BN = 32 * WN * NB;
   static constexpr int MREP = BM / 32 / WM;
   static constexpr int FT = (TT - 1) * ST + KT, FH = (TH - 1) * SH + KH, FW = (TW - 1) * SW + KW;
   static constexpr int NPIX = FT * FH * FW;
@@ -187,11 +190,13 @@ struct Geo {
   static constexpr int STEPS = NTAPS * KSUB * XPM;   // k16 steps per chunk, ordered ks-major: st = (ks * NTAPS + tap) * XPM + part
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
   // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
-  static constexpr int PF = XP ? 3 : (STEPS_W % 9 == 0) ? (MREP >= 8 ? 3 : 9) : (STEPS_W % 8 == 0 ? (MREP >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
+  static constexpr int MPS = NB * MREP;  // MFMAs per k16 step of a wave
+  static constexpr int PF = XP ? 3 : (KT == 3 && KH * KW == 1) ? KSUB : (STEPS_W % 9 == 0) ? ((MPS >= 8 || KH * KW < 9) ? 3 : 9) : (STEPS_W % 8 == 0 ? (MPS >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
   // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
   static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
   static constexpr int SMEMB = cmax(LDSB, REDB);
   static_assert(XP == 0 || KG == 1, "split-precision instances: no K-group split");
+  static_assert(NB == 1 || (NB == 2 && KG == 1 && XP == 0), "two N-blocks per wave: 16-bit instances without K-group split");
   static_assert(NWV == 8 || (NWV == 4 && KG == 1), "8 waves per workgroup, or 4 (two workgroups per CU; no K-group split)");
   static_assert(NWV == 8 || LDSB <= 80 * 1024, "two resident workgroups share the CU's 160 KiB of LDS");
   static_assert(KG == 1 || (KG == 2 && KSUB % 2 == 0 && MREP % 2 == 0 && WM * WN == 4), "K-group split");
@@ -307,9 +312,9 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
 // and the three-MFMA form 1.9e-5).  The packed weights keep three 1-KiB records per (k16, tap): [0] Whi (fp16), [1], [2] the
 // two halves of the pair's bf8 record (at the pair's FIRST tap; pairs never cross a run of KH*KW taps).
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS, int XP = 0>
+          int PRO, int UPS, int XP = 0, int NB = 1>
 __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) void conv_fwd_kernel(const ConvArgs p) {
-  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, XP>;
+  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, XP, NB>;
   using TIO = std::conditional_t<XP != 0, float, T>;  // element type of the activation tensors in HBM
   static_assert(XP == 0 || std::is_same<T, _Float16>::value, "split precision runs on fp16 MFMA");
   constexpr int XPM = G::XPM;
@@ -502,7 +507,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         if (k < NPASS && ((passmask >> k) & 1)) {
           // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
           const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
-          raw[kk] = ldraw8<TIO>(src + (size_t)sp * src_ps + c0);
+          if constexpr (KT == 3 && KH == 3 && KW == 1 && !std::is_same<TIO, float>::value) {
+            // row-packed first layer (cvvae_conv_desc.in_overlap): the 16 virtual channels of a pixel start at an 8-byte boundary
+            const uint2* q2 = reinterpret_cast<const uint2*>(src + (size_t)sp * src_ps + c0);
+            const uint2 lo2 = q2[0], hi2 = q2[1];
+            raw[kk].a = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
+          } else {
+            raw[kk] = ldraw8<TIO>(src + (size_t)sp * src_ps + c0);
+          }
         }
       }
 #ifdef CVVAE_CONV_PROBE
@@ -574,8 +586,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   };
 
   // ---- MFMA plan
-  const int nb = ntile * WN + wave_n;  // my 32-output-channel block
-  const bool active = nb < p.nblk32;
+  const int nb0 = (ntile * WN + wave_n) * NB;  // my first 32-output-channel block (NB consecutive ones; the host admits NB = 2
+  const int nb = nb0;                          // instances only for Cout % 64 == 0, so the blocks of a wave are all real or none)
+  const bool active = nb0 < p.nblk32;
   unsigned aoff[MREP];
 #pragma unroll
   for (int r = 0; r < MREP; ++r) {
@@ -604,17 +617,21 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   const T* wqx = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
                  (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
                  (size_t)(active ? nb : 0) * (size_t)p.nchunks * (size_t)wq_cs + lane * 8;
-  v8 wf[NWF];
+  // elements between the packed weights of consecutive 32-channel blocks (NB = 2: the wave's second block)
+  const long long wq_nbs = (long long)p.nchunks * (TFOLD ? w_cs : (long long)(STEPS * 512));
+  v8 wf[NB][NWF];
   if constexpr (XP == 2) {
     const T* e = wqx + (TFOLD ? tf_w0 : 0);  // chunk 0, time group 0, pair 0 (taps 0 and 1 of k16 sub-chunk 0)
-    wf[0] = *reinterpret_cast<const v8*>(e);
-    wf[1] = *reinterpret_cast<const v8*>(e + 512);
-    wf[2] = *reinterpret_cast<const v8*>(e + 1024);
-    wf[3] = *reinterpret_cast<const v8*>(e + (KH * KW > 1 ? 3 * 512 : 0));
+    wf[0][0] = *reinterpret_cast<const v8*>(e);
+    wf[0][1] = *reinterpret_cast<const v8*>(e + 512);
+    wf[0][2] = *reinterpret_cast<const v8*>(e + 1024);
+    wf[0][3] = *reinterpret_cast<const v8*>(e + (KH * KW > 1 ? 3 * 512 : 0));
   } else {
 #pragma unroll
-    for (int i = 0; i < PF; ++i)
-      wf[i] = *reinterpret_cast<const v8*>(TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512);
+    for (int n = 0; n < NB; ++n)
+#pragma unroll
+      for (int i = 0; i < PF; ++i)
+        wf[n][i] = *reinterpret_cast<const v8*>((TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512) + n * wq_nbs);
   }
 
   // The accumulators start from the BIAS (alpha == 1, i.e. every layer but the attention score product): 128 v_add per lane
@@ -624,20 +641,21 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   // sigma(i) into MFMA row i (sigma swaps bits 2 and 3 of the index inside the 32-channel block), so quads 2p and 2p+1 of a
   // lane are 8 CONSECUTIVE channels and the store tail writes 16-byte runs without any cross-lane exchange.
   const bool bias_pre = p.alpha == 1.0f;
-  f32x16 acc[MREP];
-  {
+  f32x16 acc[NB * MREP];  // fragment r of N-block n: acc[n * MREP + r]
+#pragma unroll
+  for (int n = 0; n < NB; ++n) {
     float bq[16];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
       if (bias_pre && active && kgrp == 0)
-        bv = *reinterpret_cast<const float4*>(p.bias + nb * 32 + (g >> 1) * 16 + (lane >> 5) * 8 + (g & 1) * 4);
+        bv = *reinterpret_cast<const float4*>(p.bias + (nb0 + n) * 32 + (g >> 1) * 16 + (lane >> 5) * 8 + (g & 1) * 4);
       bq[g * 4] = bv.x; bq[g * 4 + 1] = bv.y; bq[g * 4 + 2] = bv.z; bq[g * 4 + 3] = bv.w;
     }
 #pragma unroll
     for (int r = 0; r < MREP; ++r)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[r][i] = bq[i];
+      for (int i = 0; i < 16; ++i) acc[n * MREP + r][i] = bq[i];
   }
 
   // ---- residual pre-accumulation (per-frame convs = the ResnetBlock tails).  The residual add in the store tail is a chain
@@ -646,7 +664,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   //      fly under ~150 MFMAs (a 16-byte run = quads 2pr, 2pr+1 of the lane).  Measured: +1.3 % (128 ch) ... +2.7 %
   //      (512 ch) on the conv2 layers.
   constexpr bool RES_PRE = (KT == 1 && KG == 1 && UPS == 0 && MREP % 2 == 0 && XP == 0);
-  const bool res_pre = RES_PRE && p.res != nullptr && p.res_pre != 0 && p.nchunks >= MREP / 2;
+  constexpr int NFR = NB * MREP;  // accumulator fragments of a wave; unit u = n * MREP + r
+  const bool res_pre = RES_PRE && p.res != nullptr && p.res_pre != 0 && p.nchunks >= NFR / 2;
   uint4 rpre[2][2];
 
   // ---- pipeline
@@ -694,31 +713,31 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             // Whi.hi of tap a
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
-              acc[r] = Tr<T>::mfma(wf[0], fa[r], acc[r]);
+              acc[r] = Tr<T>::mfma(wf[0][0], fa[r], acc[r]);
               if (hasb) fb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob]);
               else qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
             }
-            wf[0] = *reinterpret_cast<const v8*>(ne);
+            wf[0][0] = *reinterpret_cast<const v8*>(ne);
             __builtin_amdgcn_sched_barrier(0);
             if (hasb) {  // Whi.hi of tap b
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
-                acc[r] = Tr<T>::mfma(wf[3], fb[r], acc[r]);
+                acc[r] = Tr<T>::mfma(wf[0][3], fb[r], acc[r]);
                 qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
                 qb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob + 32]);
               }
             }
-            wf[3] = *reinterpret_cast<const v8*>(ne + (nhasb ? 3 * 512 : 0));
+            wf[0][3] = *reinterpret_cast<const v8*>(ne + (nhasb ? 3 * 512 : 0));
             __builtin_amdgcn_sched_barrier(0);
             // bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi) of both taps
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
-              acc[r] = mfma_bf8_k64(wf[1], wf[2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
+              acc[r] = mfma_bf8_k64(wf[0][1], wf[0][2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
               if (!lastq) fa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ona]);
               else if (!lastg) fa[r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
-            wf[1] = *reinterpret_cast<const v8*>(ne + 512);
-            wf[2] = *reinterpret_cast<const v8*>(ne + 1024);
+            wf[0][1] = *reinterpret_cast<const v8*>(ne + 512);
+            wf[0][2] = *reinterpret_cast<const v8*>(ne + 1024);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -740,13 +759,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           const unsigned lbn = lb + (g == 0 ? tf_l1 : tf_l2);                   // LDS frame of the next group
 #pragma unroll
           for (int i = 0; i < GS; ++i) {
-            const v8 wv = wf[i % PF];
             const int nj = (i + 1) / XPM, npart = (i + 1) % XPM;
             const int nsp = nj % NSP, nks = nj / NSP;
             const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
-              acc[r] = Tr<T>::mfma(wv, ab[i & (NAB - 1)][r], acc[r]);
+#pragma unroll
+              for (int n = 0; n < NB; ++n) acc[n * MREP + r] = Tr<T>::mfma(wf[n][i % PF], ab[i & (NAB - 1)][r], acc[n * MREP + r]);
               if (i + 1 < GS)
                 ab[(i + 1) & (NAB - 1)][r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
               else if (NAB == 1 && !lastg)  // (in place) first fragments of the next time group
@@ -756,7 +775,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
               for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
-            wf[i % PF] = *reinterpret_cast<const v8*>(i + PF < GS ? wg + tf_rec(i + PF) : wn + tf_rec(i + PF - GS));
+#pragma unroll
+            for (int n = 0; n < NB; ++n)
+              wf[n][i % PF] = *reinterpret_cast<const v8*>((i + PF < GS ? wg + tf_rec(i + PF) : wn + tf_rec(i + PF - GS)) + n * wq_nbs);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -771,12 +792,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
       for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r]]);
       if constexpr (RES_PRE) {
-        if (res_pre && c < MREP / 2) {
+        if (res_pre && c < NFR / 2) {
           int lane_p = lane;  // opaque copy: keeps the address math inside this branch (not hoisted into loop-long VGPRs)
           asm volatile("" : "+v"(lane_p));
+          const int nbr = nb0 + (2 * c) / MREP;  // (MREP is even: both fragments of chunk c lie in one N-block)
 #pragma unroll
           for (int ri = 0; ri < 2; ++ri) {
-            const int m = (wave_m * MREP + 2 * c + ri) * 32 + (lane_p & 31);
+            const int m = (wave_m * MREP + (2 * c) % MREP + ri) * 32 + (lane_p & 31);
             const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
             const int to = t0 + tt, yo = y0 + ty, xo = x0 + tx;
             const bool in = to < p.To && yo < p.Ho && xo < p.Wo;  // lanes outside read pixel 0; their sums are never stored
@@ -784,25 +806,27 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr)
               rpre[ri][pr] = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.res) + pix * (long long)p.out_ps +
-                                                             (nb * 32 + pr * 16 + (lane_p >> 5) * 8));
+                                                             (nbr * 32 + pr * 16 + (lane_p >> 5) * 8));
           }
         }
       }
 #pragma unroll
       for (int st = 0; st < STEPS_W; ++st) {
-        const v8 wv = wf[st % PF];
         const int nq = (st + 1) / XPM, npart = (st + 1) % XPM;
         const int nks = nq / NTAPS, nt = nq % NTAPS;  // next step's k-sub-chunk (within my K-group) / tap
         const int ndt = nt / (KH * KW), ndy = (nt / KW) % KH, ndx = nt % KW;
         const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
 #pragma unroll
         for (int r = 0; r < MREP; ++r) {
-          acc[r] = Tr<T>::mfma(wv, ab[st & (NAB - 1)][r], acc[r]);
+#pragma unroll
+          for (int n = 0; n < NB; ++n) acc[n * MREP + r] = Tr<T>::mfma(wf[n][st % PF], ab[st & (NAB - 1)][r], acc[n * MREP + r]);
           if (st + 1 < STEPS_W)
             ab[(st + 1) & (NAB - 1)][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
         }
         // ring refill: my record st+PF of this chunk, or (wrapping) record st+PF-STEPS_W of the next chunk
-        wf[st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512);
+#pragma unroll
+        for (int n = 0; n < NB; ++n)
+          wf[n][st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512 + n * wq_nbs);
         // Fence per step: keeps the next step's ds_reads and the weight prefetch inside THIS step.  hipcc otherwise
         // sinks every load to just before its first use, which exposes the LDS / L2 latency once per MFMA
         // (measured on MI355X: 1158 -> 1240 TFLOP/s on 256->256 @9x256^2; pinning a strict MFMA/ds_read
@@ -810,9 +834,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (RES_PRE) {
-        if (res_pre && c < MREP / 2) {
+        if (res_pre && c < NFR / 2) {
 #pragma unroll
-          for (int cc = 0; cc < MREP / 2; ++cc) {  // static accumulator indices (a runtime-indexed array would go to scratch)
+          for (int cc = 0; cc < NFR / 2; ++cc) {  // static accumulator indices (a runtime-indexed array would go to scratch)
             if (c != cc) continue;
 #pragma unroll
             for (int ri = 0; ri < 2; ++ri)
@@ -854,19 +878,24 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         if (stage_first && more) stage2(c + 1, cur ^ 1);
         if (active) {
           const unsigned lb = (unsigned)(cur * G::BUFB);
-          v8 wv[KSUB * XPM];
+          v8 wv[NB][KSUB * XPM];
 #pragma unroll
-          for (int ks = 0; ks < KSUB * XPM; ++ks) wv[ks] = *reinterpret_cast<const v8*>(w2q + ((size_t)c * KSUB * XPM + ks) * 512);
+          for (int n = 0; n < NB; ++n)
+#pragma unroll
+            for (int ks = 0; ks < KSUB * XPM; ++ks)
+              wv[n][ks] = *reinterpret_cast<const v8*>(w2q + (size_t)n * (size_t)p.nchunks2 * (KSUB * XPM * 512) +
+                                                       ((size_t)c * KSUB * XPM + ks) * 512);
 #pragma unroll
           for (int ks = 0; ks < KSUB; ++ks)
 #pragma unroll
             for (int part = 0; part < XPM; ++part)
 #pragma unroll
-              for (int r = 0; r < MREP; ++r)
-                acc[r] = Tr<T>::mfma(wv[ks * XPM + part],
-                                     *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (part ? lhi16 : 0u) + ctr +
-                                                                        ks * (XP ? 64 : 32) + (part == 2 ? 16 : 0)]),
-                                     acc[r]);
+              for (int r = 0; r < MREP; ++r) {
+                const v8 bf = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (part ? lhi16 : 0u) + ctr +
+                                                                 ks * (XP ? 64 : 32) + (part == 2 ? 16 : 0)]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n * MREP + r] = Tr<T>::mfma(wv[n][ks * XPM + part], bf, acc[n * MREP + r]);
+              }
         }
         if (!stage_first && more) stage2(c + 1, cur ^ 1);
         __syncthreads();
@@ -920,6 +949,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     }
   }
   if (!active) return;
+  // The epilogue runs once per N-block of the wave (NB = 2: the second pass re-derives the channel terms; the pixel terms fold)
+  auto epilogue = [&](auto ni_tag) {
+    constexpr int NI = decltype(ni_tag)::value;
+    const int nb = nb0 + NI;
 
   // ---- epilogue.  Accumulator layout: lane = one pixel, register quad g = 4 consecutive output channels
   //      (lanes 0-31: channels 8g..8g+3, lanes 32-63: channels 8g+4..8g+7 of the wave's 32-channel block).
@@ -947,7 +980,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         for (int j = 0; j < 4; ++j)
           if (cb + j < p.Cout)
             o[((((size_t)b * p.Cout + (cb + j)) * p.To + to) * p.Ho + yo) * (size_t)p.Wo + xo] =
-                (TIO)(bias_pre ? acc[r][g * 4 + j] : acc[r][g * 4 + j] * p.alpha + bb[j]);
+                (TIO)(bias_pre ? acc[NI * MREP + r][g * 4 + j] : acc[NI * MREP + r][g * 4 + j] * p.alpha + bb[j]);
       }
     }
     CVVAE_PROBE_MARK();
@@ -1066,7 +1099,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           float v[8];
 #pragma unroll
           for (int j = 0; j < 4; ++j) {  // quads 2pr, 2pr+1 = my 8 consecutive channels
-            float lo = acc[r][(2 * pr) * 4 + j], hi = acc[r][(2 * pr + 1) * 4 + j];
+            float lo = acc[NI * MREP + r][(2 * pr) * 4 + j], hi = acc[NI * MREP + r][(2 * pr + 1) * 4 + j];
             asm volatile("" : "+v"(lo), "+v"(hi));  // (pins the reads to this point: see the general tail)
             v[j] = lo;
             v[4 + j] = hi;
@@ -1123,7 +1156,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       }
     }
   };
-  constexpr bool F32TAIL = XP != 0 || (KT * KH * KW == 1);  // instances that can store float from the fast tail
+  constexpr bool F32TAIL = XP != 0 || (KH * KW == 1);  // instances that can store float from the fast tail
   const bool f32out = XP != 0 || p.out_f32;
   if (tile_full && !f32out) {
     fast_tail((T)0.f);
@@ -1162,7 +1195,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           for (int j = 0; j < 4; ++j) {
             // (the empty asm pins the accumulator reads to this point of the tail: with plain reads hipcc keeps 128 more
             // values alive across the tails and spills 500+ VGPRs on most instances; an input-only constraint is not enough)
-            float lo = acc[r][(2 * pr) * 4 + j], hi = acc[r][(2 * pr + 1) * 4 + j];
+            float lo = acc[NI * MREP + r][(2 * pr) * 4 + j], hi = acc[NI * MREP + r][(2 * pr + 1) * 4 + j];
             asm volatile("" : "+v"(lo), "+v"(hi));
             v[j] = lo;
             v[4 + j] = hi;
@@ -1311,23 +1344,27 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           const float mean = n > 0.f ? gk[pr][q] + dmean : 0.f;
           float m2 = gq[pr][q] - gs[pr][q] * dmean;
           m2 = m2 > 0.f ? m2 : 0.f;
-          float* o = p.gnp + (((size_t)b * p.gn_slabs + (size_t)(slab * E + sub)) * p.gn_G + g) * 3;
+          // [row][group][record]: the records of one (row, group) are contiguous, so the merge pass reads whole lines
+          float* o = p.gnp + (((size_t)b * p.gn_G + g) * p.gn_slabs + (size_t)(slab * E + sub)) * 3;
           o[0] = n;
           o[1] = mean;
           o[2] = p.stats_noshift == 2 ? gk[pr][q] : (p.stats_noshift == 3 ? gdev[pr][q] : m2);  // (debug aid: expose the shift)
         }
     }
   }
+  };
+  epilogue(std::integral_constant<int, 0>{});
+  if constexpr (NB == 2) epilogue(std::integral_constant<int, 1>{});
   CVVAE_PROBE_MARK();
 }
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS, int XP = 0>
+          int PRO, int UPS, int XP = 0, int NB = 1>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
   // (debug aid: CVVAE_NW4_SOLO=1 pads a 4-wave launch's LDS so that only ONE workgroup fits a CU)
   static const bool solo = getenv("CVVAE_NW4_SOLO") && atoi(getenv("CVVAE_NW4_SOLO"));
-  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XP>), dim3(grid),
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XP, NB>), dim3(grid),
                      dim3(WM * WN * KG * 64), (WM * WN * KG == 4 && solo) ? 48 * 1024 : 0, s, a);
   return (int)hipGetLastError();
 }

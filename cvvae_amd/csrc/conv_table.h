@@ -25,6 +25,13 @@
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 0,0)
+// the row-packed first layer (cvvae_conv_desc.in_overlap: kW taps live in the 16 virtual channels), Cout = 128
+#define CVVAE_CONV_G12(X) \
+  X(3,3,1, 1,1,1, 2,8,32, 2,4,1, 1, 0,0) \
+  X(3,3,1, 1,1,1, 1,8,32, 2,4,1, 1, 0,0)
+// the taps-in-N last layer (include/cvvae.h cvvae_conv_out_gather): (3,1,1) over four-frame tiles, 27 of 32 columns useful
+#define CVVAE_CONV_G13(X) \
+  X(3,1,1, 1,1,1, 4,4,32, 8,1,1, 2, 1,0)
 // BN = 32 (conv_out: Cout = 3 / 8 / 32) and the fused nearest-2x upsample conv
 #define CVVAE_CONV_G4(X) \
   X(3,3,3, 1,1,1, 1,8,32, 8,1,1, 1, 0,0) \
@@ -120,6 +127,30 @@
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
   X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
 
+// TWO N-blocks per wave (NB = 2, conv_kernel.h): every activation fragment read from LDS feeds two MFMAs.  WM x WN waves cover
+// BM pixels x 64*WN channels.  16-bit models only.
+//   X(KT,KH,KW, ST,SH,SW, TT,TH,TW, WM,WN,KG, KSUB, PRO, UPS)
+// NOT BUILT BY DEFAULT (make NB2=1 / -DCVVAE_BUILD_NB2).  Measured in round 3 (profiles/r3_ab_nb2.log, interleaved A/B on one box):
+// bit-identical results, and NO gain -- 128 -> 128 @17x512^2 3.49 vs 3.47 ms, 256 -> 256 @9x256^2 1.64 vs 1.62 ms, folded upsample
+// +-0 %, per-frame convs 4-50 % slower.  The K loop is not bound by LDS operand bandwidth.
+#ifdef CVVAE_BUILD_NB2
+#define CVVAE_CONV_NB2_A(X) \
+  X(3,3,3, 1,1,1, 2,8,32, 4,2,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 2,8,32, 4,2,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 4,2,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,0)
+#define CVVAE_CONV_NB2_B(X) \
+  X(3,2,2, 1,1,1, 1,8,32, 2,4,1, 1, 0,2) \
+  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
+  X(1,3,3, 1,1,1, 1,16,32, 4,2,1, 2, 1,0)
+#else
+#define CVVAE_CONV_NB2_A(X)
+#define CVVAE_CONV_NB2_B(X)
+#endif
+#define CVVAE_CONV_NB2(X) CVVAE_CONV_NB2_A(X) CVVAE_CONV_NB2_B(X)
+
 // Fast-fp32 (XP = 2) instances: the multi-tap families of the list above (1x1x1 layers of such a model stay on the XP list)
 #define CVVAE_CONV_XQ_A(X) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 0,0) \
@@ -140,4 +171,4 @@
 
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \
-  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X)
+  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X) CVVAE_CONV_G12(X) CVVAE_CONV_G13(X)

@@ -22,27 +22,36 @@ CVVAE_CONV_XP(CVVAE_EXTERN_XP)
 #define CVVAE_EXTERN_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_XQ(CVVAE_EXTERN_XQ)
+#define CVVAE_EXTERN_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t); \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_NB2(CVVAE_EXTERN_NB2)
 
 typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 
 struct Instance {
   int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, kg, ksub, pro, ups;
+  int nbw;  // 32-channel N-blocks per wave (1; 2 = the register-blocked instances: a wave's tile is 64 channels wide)
   launch_fn fn[4];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one), [CVVAE_F32Q] (fast fp32)
   char name[96];
 };
 
 #define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
     &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr, nullptr}, ""},
+#define CVVAE_ROW_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 2, \
+   {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, \
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, nullptr, nullptr}, ""},
 #define CVVAE_ROW_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
    {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>, nullptr}, ""},
 #define CVVAE_ROW_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
    {nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>}, ""},
 
-static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ)};
+static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -66,7 +75,7 @@ static int cu_count() {
 // "a batch of B clips == B single-clip calls, bit for bit" (tests/test_gpu_model.py::test_batch_of_clips_matches_single_clips).
 static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
   const int fold = d->upsample2x == 2;
-  const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn;
+  const long long bm = (long long)e.tt * e.th * e.tw, bn = 32LL * e.wn * e.nbw;
   // per-phase output grid for the folded upsample (4 phases of Ho/2 x Wo/2), the output grid otherwise
   const long long tiles = fold ? cdiv(d->To, e.tt) * cdiv(d->Ho / 2, e.th) * cdiv(d->Wo / 2, e.tw) * d->B * 4
                                : cdiv(d->To, e.tt) * cdiv(d->Ho, e.th) * cdiv(d->Wo, e.tw) * d->B;
@@ -79,6 +88,12 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
   // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
   cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
   if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)
+  // two N-blocks per wave: half the LDS operand reads per MFMA (the weight-traffic term above already charges its doubled weight
+  // stream); CVVAE_CONV_NB2=<factor> scales its cost (tuning aid)
+  if (e.nbw == 2) {
+    static const double nb2 = getenv("CVVAE_CONV_NB2") ? atof(getenv("CVVAE_CONV_NB2")) : 1.0;
+    cost *= nb2;
+  }
   // four-wave instances (two workgroups per CU): NOT selected by default.  Measured (profiles/r2_ab_4wave_*.log): per-frame 3x3 at
   // 128 channels with residual + statistics 1.71 -> 1.62 ms (+6 %), 3x3x3 at 128 channels 3.38 -> 3.55 ms (-4 %) -- but with two
   // workgroups resident on a CU a few of the fused GroupNorm records came out wrong and differed from run to run (DESIGN.md
@@ -106,11 +121,14 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
 
 static const Instance* select_instance(const cvvae_conv_desc* d) {
   // tuning aid: CVVAE_CONV_FORCE="TTxTHxTW:WMxWNxKG:KSUB" restricts the choice (ignored when nothing matches)
-  int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0, fg = 0, fk = 0;
-  if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%dx%d:%d", &ft, &fh, &fw, &fm, &fn, &fg, &fk);
+  // (optional ":NB" suffix: 32-channel N-blocks per wave)
+  int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0, fg = 0, fk = 0, fnb = 0;
+  if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%dx%d:%d:%d", &ft, &fh, &fw, &fm, &fn, &fg, &fk, &fnb);
   auto eligible = [&](const Instance& e, bool forced) {
     if (!e.fn[d->dtype]) return false;  // fp32 models run the split-precision instances, fp16 / bf16 models the others
     if (forced && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) return false;
+    if (forced && ft && fnb && e.nbw != fnb) return false;
+    if (e.nbw == 2 && (d->Cout % 64)) return false;  // both N-blocks of every wave must be real
     // the folded upsample (upsample2x == 2) runs 3x2x2 phase kernels; everything else matches the descriptor's taps
     const int fold = d->upsample2x == 2;
     if (e.kt != d->kT || e.kh != (fold ? 2 : d->kH) || e.kw != (fold ? 2 : d->kW)) return false;
@@ -147,7 +165,7 @@ static const Instance* odd_frame_sibling(const cvvae_conv_desc* d, const Instanc
   for (int i = 0; i < g_ntable; ++i) {
     const Instance& s = g_table[i];
     if (!s.fn[d->dtype]) continue;
-    if (s.tt == 1 && s.th == e->th && s.tw == e->tw && s.wm == e->wm && s.wn == e->wn && s.kg == e->kg && s.ksub == e->ksub &&
+    if (s.tt == 1 && s.th == e->th && s.tw == e->tw && s.wm == e->wm && s.wn == e->wn && s.nbw == e->nbw && s.kg == e->kg && s.ksub == e->ksub &&
         s.pro == e->pro && s.ups == e->ups && s.kt == e->kt && s.kh == e->kh && s.kw == e->kw && s.st == e->st && s.sh == e->sh &&
         s.sw == e->sw)
       return &s;
@@ -158,7 +176,8 @@ static const Instance* odd_frame_sibling(const cvvae_conv_desc* d, const Instanc
 static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
     snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d%s", e->kt, e->kh, e->kw, e->st,
-             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups, e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : ""));
+             e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups,
+             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->nbw == 2 ? "_nb2" : "")));
   (void)dtype;
   return e->name;
 }
@@ -173,7 +192,14 @@ static int check_desc(const cvvae_conv_desc* d) {
   const int ck = cvvae_conv_kchunk(d->kT, d->kH, d->kW);
   if (!ck) return CVVAE_EUNSUPPORTED;
   if (d->Cin <= 0 || d->Cin % ck) return CVVAE_EINVAL;
-  if (d->in_pix_stride < d->Cin || d->in_pix_stride % 8) return CVVAE_EINVAL;
+  if (d->in_overlap) {  // row-packed first layer: 16 virtual channels = 4 stored pixels of 4 channels, kW folded into them
+    if (d->in_overlap != 1 || d->kT != 3 || d->kH != 3 || d->kW != 1 || d->Cin != 16 || d->in_pix_stride != 4 || d->pad_w != 0 ||
+        d->sW != 1 || d->prologue != CVVAE_PRO_NONE || d->upsample2x || d->sc_Cin || d->Wo > d->Wi - 3 ||
+        (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16))
+      return CVVAE_EINVAL;
+  } else if (d->kW == 1 && d->kH == 3) {
+    return CVVAE_EINVAL;  // (3,3,1) exists as the row-packed form only
+  } else if (d->in_pix_stride < d->Cin || d->in_pix_stride % 8) return CVVAE_EINVAL;
   if (d->out_mode < 0 || d->out_mode > 2) return CVVAE_EINVAL;
   if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride < (d->out_mode == 2 ? d->Cout / 2 : d->Cout))) return CVVAE_EINVAL;
   if (d->out_mode != CVVAE_OUT_NCDHW && (d->out_pix_stride % 8)) return CVVAE_EINVAL;  // 16-byte stores
@@ -328,7 +354,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.tiles_t = e2 ? (d->To - 1) / 2 : (int)cdiv(d->To, e->tt);
   a.tiles_h = (int)cdiv(a.Ho, e->th);
   a.tiles_w = (int)cdiv(a.Wo, e->tw);
-  a.ntiles_n = (int)cdiv(d->Cout, 32LL * e->wn);
+  a.ntiles_n = (int)cdiv(d->Cout, 32LL * e->wn * e->nbw);
   a.nchunks = d->Cin / (16 * e->ksub);
   a.nblk32 = (d->Cout + 31) / 32;
   a.out_mode = d->out_mode;

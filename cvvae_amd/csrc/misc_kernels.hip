@@ -397,7 +397,7 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 }
 
 // Finalize for the statistics fused into the conv epilogue: grid (G, rows); the block merges the `slabs` records of
-// its (row, group) -- ws[(row*slabs + s)*G + g] = (n, mean, M2) -- in a fixed order (thread-strided, then a Chan tree)
+// its (row, group) -- ws[(row*G + g)*slabs + s] = (n, mean, M2), contiguous -- in a fixed order (thread-strided, then a Chan tree)
 // and writes the affine table of the group's channels.
 __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __restrict__ ws, long long slabs, int G, int C,
                                                                 float eps, const float* __restrict__ gamma,
@@ -405,15 +405,15 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
                                                                 float* __restrict__ shift) {
   const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
   WStat acc = {0.f, 0.f, 0.f};
-  // records are 12 bytes at a stride of G*12: latency-bound, so keep 8 independent loads in flight per thread and
-  // merge them in index order afterwards (the merge order, hence the result, does not depend on the batching)
+  // keep 8 independent loads in flight per thread and merge them in index order afterwards (the merge order, hence the
+  // result, does not depend on the batching); a wave's loads cover 768 contiguous bytes
   constexpr int U = 8;
   long long s = tid;
   for (; s + (long long)(U - 1) * 256 < slabs; s += (long long)U * 256) {
     WStat q[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
-      const float* o = ws + (((long long)row * slabs + s + (long long)i * 256) * G + g) * 3;
+      const float* o = ws + (((long long)row * G + g) * slabs + s + (long long)i * 256) * 3;
       q[i].n = o[0];
       q[i].mean = o[1];
       q[i].m2 = o[2];
@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
     for (int i = 0; i < U; ++i) chan_merge(acc, q[i]);
   }
   for (; s < slabs; s += 256) {
-    const float* o = ws + (((long long)row * slabs + s) * G + g) * 3;
+    const float* o = ws + (((long long)row * G + g) * slabs + s) * 3;
     WStat q = {o[0], o[1], o[2]};
     chan_merge(acc, q);
   }
@@ -940,6 +940,49 @@ __global__ __launch_bounds__(256) void ncdhw_to_ndhwc_kernel(const TS* __restric
   }
 }
 
+// [B,C,T,H,W] -> row-packed [B,T,H,W+3,4] (include/cvvae.h, in_overlap): one thread per stored pixel (8 / 16 bytes)
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void ncdhw_to_rowpack_kernel(const TS* __restrict__ in, int C, long long THW, int W, int replicate,
+                                                               long long npix_out, TD* __restrict__ out) {
+  const long long op = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*T*H*(W+3)
+  if (op >= npix_out) return;
+  const int Wp = W + 3;
+  const long long row = op / Wp;            // over B*T*H
+  const int xp = (int)(op - row * Wp);
+  int xs = xp - 1;
+  bool zero = xp == W + 2;
+  if (xs < 0 || xs >= W) {
+    if (replicate) xs = xs < 0 ? 0 : W - 1;
+    else zero = true;
+  }
+  const long long TH = THW / W;             // rows per batch item
+  const long long b = row / TH, r = row - b * TH;
+  TD v[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) v[c] = (TD)((c < C && !zero) ? (float)in[(b * C + c) * THW + r * W + xs] : 0.f);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[op * 4 + c] = v[c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ndhwc_to_rowpack_kernel(const T* __restrict__ in, int C, long long ps, int W, int replicate,
+                                                               long long npix_out, T* __restrict__ out) {
+  const long long op = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*T*H*(W+3)
+  if (op >= npix_out) return;
+  const int Wp = W + 3;
+  const long long row = op / Wp;
+  const int xp = (int)(op - row * Wp);
+  int xs = xp - 1;
+  bool zero = xp == W + 2;
+  if (xs < 0 || xs >= W) {
+    if (replicate) xs = xs < 0 ? 0 : W - 1;
+    else zero = true;
+  }
+  const T* src = in + (row * W + xs) * ps;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) out[op * 4 + c] = (c < C && !zero) ? src[c] : (T)0.f;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void ndhwc_to_ncdhw_kernel(const T* __restrict__ in, int C, long long THW, long long ps,
                                                              long long npix, T* __restrict__ out) {
@@ -983,6 +1026,55 @@ __global__ __launch_bounds__(256) void ncdhw_to_frames_u8_kernel(const T* __rest
     const T a = (T)(x + 1.0f);                         // + 1.0
     const T m = (T)((float)a * 127.5f);                // * 127.5
     f[pix * 3 + c] = (uint8_t)(float)m;                // .to(torch.uint8): truncation
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// the last layer's spatial taps, gathered from the (3,1,1) conv's per-input-pixel columns (include/cvvae.h cvvae_conv_out_gather)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, int CO>
+__global__ __launch_bounds__(256) void conv_out_gather_kernel(const float* __restrict__ V, int T_, int H, int W, long long ldv,
+                                                              const float* __restrict__ bias, int replicate, long long npix,
+                                                              T* __restrict__ out, uint8_t* __restrict__ u8) {
+  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*T*H*W
+  if (pix >= npix) return;
+  const int x = (int)(pix % W);
+  const long long r1 = pix / W;
+  const int y = (int)(r1 % H);
+  const long long bt = r1 / H;  // b*T + t
+  float acc[CO];
+#pragma unroll
+  for (int c = 0; c < CO; ++c) acc[c] = bias[c];
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy) {
+    int ys = y + dy - 1;
+    const bool oy = ys < 0 || ys >= H;
+    ys = ys < 0 ? 0 : (ys >= H ? H - 1 : ys);
+#pragma unroll
+    for (int dx = 0; dx < 3; ++dx) {
+      int xs = x + dx - 1;
+      const bool ox = xs < 0 || xs >= W;
+      xs = xs < 0 ? 0 : (xs >= W ? W - 1 : xs);
+      if (!replicate && (oy || ox)) continue;  // zero padding: the neighbour is outside the frame
+      const float* v = V + ((bt * H + ys) * W + xs) * ldv + (dy * 3 + dx) * CO;
+#pragma unroll
+      for (int c = 0; c < CO; ++c) acc[c] += v[c];
+    }
+  }
+  const long long thw = (long long)T_ * H * W;
+  const long long b = bt / T_, s = pix - b * thw;
+#pragma unroll
+  for (int c = 0; c < CO; ++c) {
+    const T q = (T)acc[c];  // the layer's output, rounded to the model dtype as the stored tensor would be
+    if (u8) {
+      float xf = (float)q;
+      xf = xf < -1.0f ? -1.0f : (xf > 1.0f ? 1.0f : xf);   // torch.clamp(results, -1.0, 1.0)
+      const T a = (T)(xf + 1.0f);                            // + 1.0
+      const T m = (T)((float)a * 127.5f);                    // * 127.5
+      u8[pix * CO + c] = (uint8_t)(float)m;                  // .to(torch.uint8): truncation   ('t h w c', B = 1)
+    } else {
+      out[(b * CO + c) * thw + s] = q;
+    }
   }
 }
 
@@ -1393,6 +1485,53 @@ int cvvae_ncdhw_to_ndhwc(int32_t src_dtype, int32_t dst_dtype, const void* in, i
   CHECK_LAUNCH();
 }
 
+int cvvae_ncdhw_to_rowpack(int32_t src_dtype, int32_t dst_dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H,
+                           int32_t W, int32_t pad_mode_w, void* out, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || C > 4 || T <= 0 || H <= 0 || W <= 0 || (pad_mode_w != 0 && pad_mode_w != 1)) return CVVAE_EINVAL;
+  const long long THW = (long long)T * H * W, npo = (long long)B * T * H * (W + 3);
+  const int grid = (int)((npo + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  // the 16 read-ahead elements behind the last pixel are zeroed (they are only ever multiplied by zero weights)
+  const size_t es = dst_dtype == CVVAE_F32 ? 4 : 2;
+  hipError_t me = hipMemsetAsync((char*)out + (size_t)npo * 4 * es, 0, 16 * es, s);
+  if (me != hipSuccess) return (int)me;
+#define L(TS, TD) \
+  hipLaunchKernelGGL((ncdhw_to_rowpack_kernel<TS, TD>), dim3(grid), dim3(256), 0, s, (const TS*)in, C, THW, W, pad_mode_w, npo, (TD*)out)
+  if (dst_dtype == CVVAE_BF16) {
+    if (src_dtype == CVVAE_BF16) L(__bf16, __bf16);
+    else if (src_dtype == CVVAE_F16) L(_Float16, __bf16);
+    else if (src_dtype == CVVAE_F32) L(float, __bf16);
+    else return CVVAE_EINVAL;
+  } else if (dst_dtype == CVVAE_F16) {
+    if (src_dtype == CVVAE_BF16) L(__bf16, _Float16);
+    else if (src_dtype == CVVAE_F16) L(_Float16, _Float16);
+    else if (src_dtype == CVVAE_F32) L(float, _Float16);
+    else return CVVAE_EINVAL;
+  } else
+    return CVVAE_EUNSUPPORTED;  // (fp32 models keep the channel-padded first layer: no split-precision (3,3,1) instance)
+#undef L
+  CHECK_LAUNCH();
+}
+
+int cvvae_ndhwc_to_rowpack(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W, int64_t pix_stride,
+                           int32_t pad_mode_w, void* out, void* stream) {
+  if (!in || !out || B <= 0 || C <= 0 || C > 4 || T <= 0 || H <= 0 || W <= 0 || pix_stride < C || (pad_mode_w != 0 && pad_mode_w != 1))
+    return CVVAE_EINVAL;
+  if (dtype != CVVAE_F16 && dtype != CVVAE_BF16) return CVVAE_EUNSUPPORTED;
+  const long long npo = (long long)B * T * H * (W + 3);
+  const int grid = (int)((npo + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t me = hipMemsetAsync((char*)out + (size_t)npo * 4 * 2, 0, 16 * 2, s);
+  if (me != hipSuccess) return (int)me;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL(ndhwc_to_rowpack_kernel<__bf16>, dim3(grid), dim3(256), 0, s, (const __bf16*)in, C, (long long)pix_stride, W,
+                       pad_mode_w, npo, (__bf16*)out);
+  else
+    hipLaunchKernelGGL(ndhwc_to_rowpack_kernel<_Float16>, dim3(grid), dim3(256), 0, s, (const _Float16*)in, C, (long long)pix_stride, W,
+                       pad_mode_w, npo, (_Float16*)out);
+  CHECK_LAUNCH();
+}
+
 int cvvae_ndhwc_to_ncdhw(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W,
                          int64_t pix_stride, void* out, void* stream) {
   if (!in || !out || B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || pix_stride < C) return CVVAE_EINVAL;
@@ -1444,6 +1583,26 @@ int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t
                        frames);
   else
     return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_conv_out_gather(int32_t dtype, const float* V, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Cout, int64_t ldv,
+                          const float* bias, int32_t pad_mode_hw, void* out_ncdhw, uint8_t* out_u8, void* stream) {
+  if (!V || !bias || B <= 0 || T <= 0 || H <= 0 || W <= 0 || ldv < 9LL * Cout || (pad_mode_hw != 0 && pad_mode_hw != 1)) return CVVAE_EINVAL;
+  if ((out_ncdhw != nullptr) == (out_u8 != nullptr)) return CVVAE_EINVAL;
+  if (Cout != 3) return CVVAE_EUNSUPPORTED;  // the shipped decoders: RGB
+  if (out_u8 && B != 1) return CVVAE_EINVAL;
+  const long long npix = (long long)B * T * H * W;
+  const int grid = (int)((npix + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    hipLaunchKernelGGL((conv_out_gather_kernel<__bf16, 3>), dim3(grid), dim3(256), 0, s, V, T, H, W, (long long)ldv, bias, pad_mode_hw,
+                       npix, (__bf16*)out_ncdhw, out_u8);
+  else if (dtype == CVVAE_F16)
+    hipLaunchKernelGGL((conv_out_gather_kernel<_Float16, 3>), dim3(grid), dim3(256), 0, s, V, T, H, W, (long long)ldv, bias, pad_mode_hw,
+                       npix, (_Float16*)out_ncdhw, out_u8);
+  else
+    return CVVAE_EUNSUPPORTED;
   CHECK_LAUNCH();
 }
 

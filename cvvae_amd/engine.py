@@ -110,6 +110,33 @@ class WeightCache:
         self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
+    def conv_rowpack(self, pre: str, time_folds: bool = False) -> ops.PackedConv:
+        """the networks' first layer ([Cout, 3, 3, 3, 3]) as the (3,3,1) conv over the row-packed input (ops.pack_weight_rowpack)"""
+        w = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(w, b)
+        tag = f"{pre}#rowpack{'tf' if time_folds else ''}"
+        hit = self._c.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1]
+        pw = ops.pack_weight_rowpack(w.detach(), b.detach(), time_folds=time_folds)
+        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
+        return pw
+
+    def conv_tapsn(self, pre: str, time_folds: bool = False):
+        """the decoders' last layer as the taps-in-N (3,1,1) conv (ops.pack_weight_tapsn) + its fp32 bias"""
+        w = self.m.get_parameter(pre + ".weight")
+        b = self.m.get_parameter(pre + ".bias")
+        key = self._key(w, b)
+        tag = f"{pre}#tapsn{'tf' if time_folds else ''}"
+        hit = self._c.get(tag)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[3]
+        pw = ops.pack_weight_tapsn(w.detach(), time_folds=time_folds)
+        bias = b.detach().float().contiguous()
+        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"), bias)
+        return pw, bias
+
     def conv_t1(self, pre: str, mode: str, cin_pad: Optional[int] = None) -> ops.PackedConv:
         """3 x kH x kW weights as the single-frame (T = 1) input sees them: time taps summed ('sum') or centre tap ('center')."""
         w = self.m.get_parameter(pre + ".weight")
@@ -376,6 +403,49 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
     return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 
+def rowpack_conv_in() -> bool:
+    """conv_in of the encoders (3 -> 128 channels, 3x3x3) on clips: run as a (3,3,1) convolution over a row-packed, W-padded copy of
+    the input whose 16 virtual channels are the three kW taps x 4 channel slots (include/cvvae.h in_overlap): K = 144 per output
+    instead of 432 with the channels padded 3 -> 16, and a 4x smaller converted input.  Same products, another summation order
+    inside the fp32 accumulator.  CVVAE_ROWPACK_IN=0 keeps the channel-padded form."""
+    return os.environ.get("CVVAE_ROWPACK_IN", "1") != "0"
+
+
+def encoder_conv_in(wc: WeightCache, x: torch.Tensor, cfg: dict, dtype: torch.dtype, pad, mode_t, mode_hw):
+    """conv_in of both encoders: x NCDHW (or the padded NDHWC clip of encode_frames_u8) -> (h NDHWC, GroupNorm partials)"""
+    nd = bool(cfg.get("ndhwc_in"))
+    cin = wc.m.get_parameter("conv_in.weight").shape[1]
+    if (rowpack_conv_in() and x.shape[1 if nd else 2] > 1 and dtype in (torch.float16, torch.bfloat16) and cin <= 4
+            and pad[2] == (1, 1) and (x.dtype == dtype or not nd)):
+        # (the device-side pixel path hands over its padded NDHWC clip: same values, hence the same bits as the NCDHW entry)
+        xr = ops.ndhwc_to_rowpack(x, cin, mode_hw) if nd else ops.ncdhw_to_rowpack(x, dtype, mode_hw)
+        pw = wc.conv_rowpack("conv_in", time_folds=mode_t == REP and fold_time())
+        return ops.conv(xr, pw, pad=(pad[0], pad[1], (0, 0)), pad_mode_t=mode_t, pad_mode_hw=mode_hw, gn_out=G32, row_packed=True)
+    h, cpad = _encoder_input(x, cfg, dtype)
+    return conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, gn_out=G32)
+
+
+def tapsn_conv_out() -> bool:
+    """conv_out of the decoders (128 -> 3 channels, 3x3x3): the nine spatial taps moved into the GEMM's N axis -- a (3,1,1) conv
+    with 27 of 32 MFMA columns useful, no spatial halo (GroupNorm + SiLU applied 1.5x per element instead of 2.7x) and a ninth of the
+    MFMAs, then a gather pass that sums the nine neighbours' columns in fp32 (include/cvvae.h cvvae_conv_out_gather).  Same
+    products, another summation order.  CVVAE_TAPSN_OUT=0 keeps the 32-column form."""
+    return os.environ.get("CVVAE_TAPSN_OUT", "1") != "0"
+
+
+def decoder_conv_out(wc: WeightCache, h: torch.Tensor, g, pad, mode_t, mode_hw, u8: bool = False):
+    """norm_out + SiLU + conv_out of both decoders -> pixels NCDHW (or, u8: the scripts' uint8 frames [T,H,W,3], one clip)"""
+    w = wc.m.get_parameter("conv_out.weight")
+    if (tapsn_conv_out() and h.dtype in (torch.float16, torch.bfloat16) and 9 * w.shape[0] <= 32 and w.shape[0] == 3
+            and pad[1] == (1, 1) and pad[2] == (1, 1) and h.shape[-1] % 32 == 0):
+        pw, bias = wc.conv_tapsn("conv_out", time_folds=mode_t == REP and fold_time())
+        v = ops.conv(h, pw, pad=(pad[0], (0, 0), (0, 0)), pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=L.PRO_GN_SILU, gn=g,
+                     out_f32=True)                                                   # [B,T,H,W,32] fp32
+        return ops.conv_out_gather(v, w.shape[0], bias, mode_hw, h.dtype, u8=u8)
+    y = conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
+    return ops.ncdhw_to_frames_u8(y) if u8 else y
+
+
 def _encoder_input(x: torch.Tensor, cfg: dict, dtype: torch.dtype):
     """the encoder's NDHWC input, channel-padded for conv_in's K chunk: converted from the caller's NCDHW clip, or -- cfg
     "ndhwc_in" (the device-side pixel pre-processing, modeling.encode_frames_u8) -- the padded NDHWC clip as it arrives."""
@@ -418,9 +488,7 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
-    h, cpad = _encoder_input(x, cfg, dtype)
-    h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
-                     gn_out=G32)
+    h, hp = encoder_conv_in(wc, x, cfg, dtype, PC if causal else P1, REP, REP)
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"]):
             h, hp = sd3_resnet(wc, h, hp, f"down_blocks.{i}.resnets.{j}", causal)
@@ -453,8 +521,7 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
             up_time = i % 2 == 0
             h, hp = upsample_conv(wc, h, f"up_blocks.{i}.upsamplers.0.conv", pad, REP, REP, up_time)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
-    return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=g,
-                    out_mode=L.OUT_NCDHW)
+    return decoder_conv_out(wc, h, g, pad, REP, REP, u8=bool(cfg.get("u8_out")))
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -532,8 +599,7 @@ def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
-    h, cpad = _encoder_input(x, cfg, dtype)
-    h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, gn_out=G32)
+    h, hp = encoder_conv_in(wc, x, cfg, dtype, pad, mt, mhw)
     for lvl in range(nlev):
         for j in range(cfg["num_res_blocks"]):
             h, hp = v3_resnet(wc, h, hp, f"down.{lvl}.block.{j}", causal)
@@ -584,5 +650,4 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
             up_time = lvl % 2 == 1
             h, hp = upsample_conv(wc, h, f"up.{lvl}.upsample.conv", P1, REP, ZERO, up_time)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
-    return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
-                    out_mode=L.OUT_NCDHW)
+    return decoder_conv_out(wc, h, g, pad, mt, mhw, u8=bool(cfg.get("u8_out")))

@@ -276,7 +276,8 @@ class Decoder(_Net):
 
     def forward(self, z, **kwargs):
         self.last_z_shape = z.shape  # vae_models.py:962
-        return super().forward(z)
+        # (the reference ignores its kwargs; `u8_out` is this implementation's private switch of decode_to_frames_u8)
+        return super().forward(z, **{k: v for k, v in kwargs.items() if k == "u8_out"})
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -758,7 +759,17 @@ class _CVVAEBase(nn.Module):
     def decode_to_frames_u8(self, z: torch.Tensor, num_frames: Optional[int] = None) -> torch.Tensor:
         """`decode(z).sample` followed by the scripts' `(clamp(x,-1,1)+1)*127.5 -> uint8` ('t h w c',
         cvvae_inference_video.py:47-50) on the device.  One clip (B = 1)."""
-        x = self.decode(z, num_frames=num_frames).sample
+        # one window, one tile (clips up to 17 frames and 576 x 576 pixels): the uint8 conversion is the store of the decoder's last
+        # pass (engine.decoder_conv_out, u8) -- the float clip is never written
+        if (z.dim() == 5 and z.shape[0] == 1 and not self.reshape_x_dim_to_4 and
+                (self.decode_n_frames_a_time is None or len(self._windows(z.shape[2], self.decode_n_frames_a_time)) == 1) and
+                (self.latent_tile_size is None or (z.shape[3] <= self.latent_tile_size and z.shape[4] <= self.latent_tile_size))):
+            out = self.decoder(z, u8_out=True)
+            if out.dtype == torch.uint8:
+                return out
+            x = out
+        else:
+            x = self.decode(z, num_frames=num_frames).sample
         if x.dim() != 5 or x.shape[0] != 1:
             raise ValueError("decode_to_frames_u8 handles one clip [1,C,T,H,W] (reshape_x_dim_to_4 must be off)")
         with torch.cuda.device(x.device):  # (the launch goes to x's device whatever the caller's current device is)

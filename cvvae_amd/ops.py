@@ -68,7 +68,7 @@ def _need_gpu(t: torch.Tensor):
 
 
 def kchunk(k: Tuple[int, int, int]) -> int:
-    return {(3, 3, 3): 16, (1, 3, 3): 32, (1, 1, 1): 128}[tuple(k)]
+    return {(3, 3, 3): 16, (1, 3, 3): 32, (1, 1, 1): 128, (3, 3, 1): 16, (3, 1, 1): 32}[tuple(k)]
 
 
 def round_up(x: int, m: int) -> int:
@@ -128,10 +128,83 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int
     return PackedConv(out, b, cout_, cin_pad, tuple(k), cin_, wscale=ws, dt=dt)
 
 
+def ncdhw_to_rowpack(x: torch.Tensor, dtype: torch.dtype, pad_mode_w: int) -> torch.Tensor:
+    """x: [B,C<=4,T,H,W] -> the row-packed first-layer input [B,T,H,W+3,4] `dtype` (include/cvvae.h, cvvae_conv_desc.in_overlap):
+    stored pixel xp holds input pixel xp - 1, columns 0 and W+1 the W padding (replicate / zero), 4 channel slots.  The returned
+    tensor is a view of a buffer that stays readable 32 bytes past its end (conv(..., row_packed=True) reads 4 pixels per pixel)."""
+    lib = L.load()
+    _need_gpu(x)
+    x = x.contiguous()
+    B, C, T, H, W = x.shape
+    if x.dtype not in _DT:
+        raise TypeError(f"unsupported input dtype {x.dtype}")
+    n = B * T * H * (W + 3) * 4
+    buf = torch.empty(n + 16, dtype=dtype, device=x.device)
+    L.check(lib.cvvae_ncdhw_to_rowpack(_DT[x.dtype], _dt(dtype), x.data_ptr(), B, C, T, H, W, pad_mode_w, buf.data_ptr(), _stream(x)),
+            "cvvae_ncdhw_to_rowpack")
+    return buf[:n].view(B, T, H, W + 3, 4)
+
+
+def ndhwc_to_rowpack(x: torch.Tensor, c: int, pad_mode_w: int) -> torch.Tensor:
+    """x: NDHWC [B,T,H,W,Cs] (fp16 / bf16, contiguous), its first c <= 4 channels -> the row-packed first-layer input (see
+    ncdhw_to_rowpack): the entry of the device-side pixel pre-processing (modeling.encode_frames_u8) into the same conv_in."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous() and x.shape[-1] >= c
+    B, T, H, W, Cs = x.shape
+    n = B * T * H * (W + 3) * 4
+    buf = torch.empty(n + 16, dtype=x.dtype, device=x.device)
+    L.check(lib.cvvae_ndhwc_to_rowpack(_dt(x.dtype), x.data_ptr(), B, c, T, H, W, Cs, pad_mode_w, buf.data_ptr(), _stream(x)),
+            "cvvae_ndhwc_to_rowpack")
+    return buf[:n].view(B, T, H, W + 3, 4)
+
+
+def pack_weight_rowpack(w: torch.Tensor, bias: Optional[torch.Tensor], time_folds: bool = False) -> PackedConv:
+    """[Cout, C<=4, 3, 3, 3] first-layer weight -> packed (3,3,1) weights over the 16 virtual channels (dx, c) of the row-packed
+    input: virtual channel dx*4 + c of tap (kt, kh) is w[:, c, kt, kh, dx] (dx = 3 and channel slots >= C are zero)."""
+    co, ci = w.shape[0], w.shape[1]
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and ci <= 4 and w.dtype in (torch.float16, torch.bfloat16)
+    wv = torch.zeros((co, 4, 4, 3, 3), dtype=w.dtype, device=w.device)      # [co, dx, c, kt, kh]
+    wv[:, :3, :ci] = w.detach().permute(0, 4, 1, 2, 3)                      # [co, dx(kw), c, kt, kh]
+    wv = wv.reshape(co, 16, 3, 3, 1).contiguous()
+    pw = pack_weight_tfolds(wv, bias, cin_pad=16) if time_folds else pack_weight(wv.reshape(co, 16, 9), bias, (3, 3, 1), cin_pad=16)
+    pw.cin_real, pw.alg_taps = ci, 27   # algorithmic FLOP accounting: the 3x3x3 conv over C channels it replaces
+    return pw
+
+
+def pack_weight_tapsn(w: torch.Tensor, time_folds: bool = False) -> PackedConv:
+    """[Cout, Cin, 3, 3, 3] last-layer weight (9 * Cout <= 32) -> packed (3,1,1) weights whose output column (dy*3+dx)*Cout + co is
+    w[co, :, dt, dy, dx]: the nine spatial taps in the GEMM's N axis (include/cvvae.h cvvae_conv_out_gather).  No bias: the gather
+    pass adds it."""
+    co, ci = w.shape[0], w.shape[1]
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and 9 * co <= 32 and w.dtype in (torch.float16, torch.bfloat16)
+    wv = torch.zeros((32, ci, 3, 1, 1), dtype=w.dtype, device=w.device)                 # (columns 9*co .. 31: zero weights)
+    wv[:9 * co] = w.detach().permute(3, 4, 0, 1, 2).reshape(9 * co, ci, 3, 1, 1)          # [(dy, dx, co), ci, dt, 1, 1]
+    pw = pack_weight_tfolds(wv, None) if time_folds else pack_weight(wv.reshape(32, ci, 3), None, (3, 1, 1))
+    return pw
+
+
+def conv_out_gather(v: torch.Tensor, cout: int, bias: torch.Tensor, pad_mode_hw: int, dtype: torch.dtype, u8: bool = False) -> torch.Tensor:
+    """v: fp32 [B,T,H,W,ldv] columns of the taps-in-N last layer (conv(..., pack_weight_tapsn, out_f32=True)) -> the layer's output
+    [B,cout,T,H,W] `dtype`, or (u8, B = 1) the scripts' uint8 frames [T,H,W,3] of it; bias: fp32 [>= cout]."""
+    lib = L.load()
+    _need_gpu(v)
+    assert v.dim() == 5 and v.is_contiguous() and v.dtype == torch.float32 and bias.dtype == torch.float32 and bias.numel() >= cout
+    B, T, H, W, ldv = v.shape
+    if u8:
+        out = torch.empty((T, H, W, cout), dtype=torch.uint8, device=v.device)
+    else:
+        out = torch.empty((B, cout, T, H, W), dtype=dtype, device=v.device)
+    L.check(lib.cvvae_conv_out_gather(_dt(dtype), v.data_ptr(), B, T, H, W, cout, ldv, bias.data_ptr(), pad_mode_hw,
+                                      None if u8 else out.data_ptr(), out.data_ptr() if u8 else None, _stream(v)),
+            "cvvae_conv_out_gather")
+    return out
+
+
 @dataclass
 class GNPartials:
     """per-tile (n, mean, M2) records of a conv output, written by the conv's epilogue (cvvae_conv_fwd_gn)"""
-    buf: torch.Tensor   # fp32 [rows, slabs, groups, 3]
+    buf: torch.Tensor   # fp32, rows * groups * slabs records of 3 floats (layout private to the library: [row][group][slab])
     rows: int
     slabs: int
     C: int
@@ -230,32 +303,43 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
          pad_mode_hw=L.PAD_ZERO, prologue=L.PRO_NONE, gn: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
          gn_per_frame=False, residual: Optional[torch.Tensor] = None, upsample2x=False, out_mode=L.OUT_NDHWC,
          shortcut: Optional[Tuple[torch.Tensor, "PackedConv"]] = None, bias: Optional[torch.Tensor] = None,
-         out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None, gn_out: int = 0):
+         out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None, gn_out: int = 0,
+         row_packed: bool = False):
     """x: [B,T,H,W,Cs] with Cs >= pw.cin.  pad = ((t_front,t_back),(h_front,h_back),(w_front,w_back)).
     Returns [B,To,Ho,Wo,Cout(_pad)] (NDHWC), [B,2To-1,Ho,Wo,Cout/2] (TIME_SHUFFLE) or [B,Cout,To,Ho,Wo] (NCDHW).
     gn_out = G > 0: also returns the GNPartials of the stored tensor for a following G-group GroupNorm (gn_finalize).
+    row_packed: x is ncdhw_to_rowpack()'s [B,T,H,W+3,4] tensor and pw pack_weight_rowpack()'s (3,3,1) weights: the networks' first
+    layer with its kW taps folded into 16 virtual channels; pad = (time pad, H pad, (0, 0)); the output has W columns.
     shortcut = (x2, pw2): fused 1x1 shortcut -- out = conv(x) + pw2 . x2 + bias, x2 [B,T,H,W,C2] (same pixels as x), pw2 a
     packed (1,1,1) weight; `bias` then overrides pw.bias (the caller passes b_conv + b_shortcut, fp32, padded to 32)."""
     lib = L.load()
     _need_gpu(x)
     assert x.dim() == 5 and x.is_contiguous()
     dt = _dt(x.dtype)
+    if row_packed:
+        assert pw.k == (3, 3, 1) and x.shape[-1] == 4 and pw.cin == 16 and pad[2] == (0, 0) and prologue == L.PRO_NONE
+        assert residual is None and shortcut is None and not upsample2x and stride[2] == 1
+    else:
+        assert pw.k != (3, 3, 1), "(3,3,1) weights are the row-packed first layer: conv(..., row_packed=True)"
     if dt == L.F32 and pw.dt == L.F32Q:  # the layout the weights were packed in selects the fp32 arithmetic of this launch
         if shortcut is not None:
             raise ValueError("fast-fp32 weights (CVVAE_F32Q) have no fused-shortcut kernel: run the 1x1 shortcut as its own launch")
         dt = L.F32Q
     B, Ti, Hi, Wi, Cs = x.shape
-    assert Cs >= pw.cin, f"input has {Cs} channels, packed weights consume {pw.cin}"
+    assert row_packed or Cs >= pw.cin, f"input has {Cs} channels, packed weights consume {pw.cin}"
     kT, kH, kW = pw.k
     Hl, Wl = (2 * Hi, 2 * Wi) if upsample2x else (Hi, Wi)
     To = (Ti + pad[0][0] + pad[0][1] - kT) // stride[0] + 1
     Ho = (Hl + pad[1][0] + pad[1][1] - kH) // stride[1] + 1
     Wo = (Wl + pad[2][0] + pad[2][1] - kW) // stride[2] + 1
+    if row_packed:
+        Wo = Wi - 3  # the stored rows carry the W padding (+ one read-ahead pixel)
     cout = pw.cout
     d = L.ConvDesc()
     d.dtype = dt
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, pw.cin
     d.in_pix_stride = Cs
+    d.in_overlap = 1 if row_packed else 0
     if pw.folded != (upsample2x == 2):
         raise ValueError("folded upsample weights (pack_weight_upfold) go with upsample2x=2 and only with it")
     d.upsample2x = int(upsample2x)
@@ -312,7 +396,7 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
         cst = cout // 2 if out_mode == L.OUT_TIME_SHUFFLE else cout
         # time-shuffle outputs: workgroups whose whole tile is the dropped frame exit without writing their records
         alloc = torch.zeros if out_mode == L.OUT_TIME_SHUFFLE else torch.empty
-        part = GNPartials(alloc((B, slabs, gn_out, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
+        part = GNPartials(alloc((B, gn_out, slabs, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
 
     def launch():
         if shortcut is not None:

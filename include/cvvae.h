@@ -49,7 +49,9 @@ enum {
  * must be a multiple of -- 16 for 3x3x3, 32 for 1x3x3, 128 for 1x1x1.  The packed-weight LAYOUT is the same for every
  * family: [Cout/32][Cin_pad/16][tap][64 lanes][8]. */
 static inline int cvvae_conv_kchunk(int kT, int kH, int kW) {
-  return (kT == 3 && kH == 3 && kW == 3) ? 16 : (kT == 1 && kH == 3 && kW == 3) ? 32 : (kT == 1 && kH == 1 && kW == 1) ? 128 : 0;
+  return (kT == 3 && kH == 3 && kW == 3) ? 16 : (kT == 1 && kH == 3 && kW == 3) ? 32 : (kT == 1 && kH == 1 && kW == 1) ? 128 :
+         (kT == 3 && kH == 3 && kW == 1) ? 16 /* the row-packed first layer, see in_overlap */ :
+         (kT == 3 && kH == 1 && kW == 1) ? 32 /* the taps-in-N last layer, see cvvae_conv_out_gather */ : 0;
 }
 
 /*
@@ -98,6 +100,15 @@ typedef struct cvvae_conv_desc {
   int32_t sc_Cin;             /* multiple of the instance's K-chunk (32) */
   int32_t w_time_folds;       /* 1: w_packed carries the time-fold slots (cvvae_pack_weights_tfolds / _upfold_tfolds; kT == 3 only) */
   int64_t sc_in_pix_stride;
+  /* Row-packed input (the networks' first layer, conv_in: 3 -> 128 channels, models/vae_models3d_sd3.py:97-104, vae_models.py:706-716).
+   * With in_overlap = 1 the "channel" vectors of consecutive pixels OVERLAP in memory: in_pix_stride (>= 4, multiple of 4) is
+   * smaller than Cin, so pixel x's Cin = 16 channels are the 4 stored pixels x .. x+3 of 4 channels each.  A 3x3x3 convolution
+   * over [B,T,H,W,3] then runs as a (kT,kH,kW) = (3,3,1) convolution over a W-padded copy [B,T,H,W+3,4] (cvvae_ncdhw_to_rowpack;
+   * padding along W is in the copy, Wi = W + 3 is the STORED row length, Wo = W, pad_w = 0) whose 16 virtual channels are
+   * (dx, c) = the three kW taps x 4 channel slots: K = 9 x 16 = 144 per output instead of 27 x 16 = 432 with the channels
+   * padded 3 -> 16, and a 36 MB instead of a 142 MB input at 17 x 512^2.  The buffer must stay readable 32 bytes past its end. */
+  int32_t in_overlap;
+  int32_t reserved0;
 } cvvae_conv_desc;
 
 /* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */
@@ -158,7 +169,7 @@ int cvvae_conv_fwd(const cvvae_conv_desc* d, const void* in, const void* w_packe
  * dtype, Cout % 8 == 0), so that the GroupNorm of the NEXT layer never re-reads the activation: norm2 after conv1, norm1
  * of the next ResnetBlock3D after conv2 (+residual), conv_norm_out -- models/vae_blocks3d_sd3.py:523,547,
  * models/vae_models3d_sd3.py:204,382, models/vae_models.py:395,402,820,999 (5-D GroupNorm: statistics per sample).
- * out_partials: [B][slabs][out_groups][3] fp32 records (n, mean, M2) of the ROUNDED stored values, one per pixel tile /
+ * out_partials: [B][out_groups][slabs][3] fp32 records (n, mean, M2) of the ROUNDED stored values, one per pixel tile /
  * wave slab / 4-channel slot, slabs = cvvae_conv_gn_slabs(d, out_groups); every record is written exactly once (no
  * atomics: results are bit-reproducible).  cvvae_gn_finalize merges them (Chan, fixed order) into the affine table.
  * With out_mode = TIME_SHUFFLE the caller ZERO-FILLS out_partials first: workgroups whose whole tile is the dropped frame
@@ -179,6 +190,28 @@ int cvvae_conv_fwd_gn(const cvvae_conv_desc* d, const void* in, const void* w_pa
 int cvvae_conv_fwd_gn_sc(const cvvae_conv_desc* d, const void* in, const void* w_packed, const float* bias,
                          const float* gn_scale, const float* gn_shift, const void* sc_in, const void* sc_w_packed, void* out,
                          int32_t out_groups, float* out_partials, void* stream);
+/* [B,C,T,H,W] (C <= 4, any cvvae dtype) -> the row-packed first-layer input [B,T,H,W+3,4] of dtype dst_dtype: stored pixel xp of
+ * a row holds input pixel xp - 1; xp = 0 and xp = W + 1 hold the W padding (pad_mode_w: replicate = the edge pixel, zero), xp = W + 2
+ * and channel slots >= C are zero.  `out` must be (B*T*H*(W+3)*4 + 16) elements long (read-ahead of the last pixels). */
+int cvvae_ncdhw_to_rowpack(int32_t src_dtype, int32_t dst_dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H,
+                           int32_t W, int32_t pad_mode_w, void* out, void* stream);
+/*
+ * The networks' LAST layer (conv_out: 128 -> 3 channels, 3x3x3; models/vae_models3d_sd3.py:319-321,384-386, vae_models.py:952-955,
+ * 1000) with its nine SPATIAL taps moved into the GEMM's N axis.  A 32-column MFMA block would carry 3 useful output channels;
+ * instead a (3,1,1) convolution (cvvae_conv_fwd, weights re-ordered by the caller, fp32 NDHWC output, out_f32 = 1) computes, for every
+ * INPUT pixel, V[pixel][(dy*3+dx)*Cout + co] = sum over (dt, ci) of w[co][ci][dt][dy][dx] * act[t+dt-pad_t][pixel][ci] -- 9*Cout <= 32
+ * columns, no spatial halo, every activation staged 1.5x (time halo) instead of 2.7x, a ninth of the MFMAs -- and this pass
+ * finishes the convolution:   out[co][t][y][x] = bias[co] + sum over (dy, dx) of V[t][y+dy-1][x+dx-1][(dy*3+dx)*Cout + co]
+ * with the spatial padding of the layer (replicate: clamped neighbour coordinates; zero: neighbours outside the frame add nothing),
+ * summed in fp32 in the fixed order dy, dx.  V: fp32 [B,T,H,W,ldv] (ldv >= 9*Cout).  Exactly one of out_ncdhw ([B,Cout,T,H,W] of
+ * `dtype`) and out_u8 (B = 1, Cout = 3: uint8 frames [T,H,W,3] = the scripts' (clamp(x,-1,1)+1)*127.5 -> uint8 on the value
+ * rounded to `dtype`, cvvae_inference_video.py:47-50) is non-NULL.
+ */
+int cvvae_conv_out_gather(int32_t dtype, const float* V, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Cout, int64_t ldv,
+                          const float* bias, int32_t pad_mode_hw, void* out_ncdhw, uint8_t* out_u8, void* stream);
+/* the same from an NDHWC tensor [B,T,H,W] of `dtype` with pixel stride pix_stride (>= C) elements: its first C (<= 4) channels */
+int cvvae_ndhwc_to_rowpack(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W, int64_t pix_stride,
+                           int32_t pad_mode_w, void* out, void* stream);
 int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_t C, int32_t groups, float eps,
                       const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 

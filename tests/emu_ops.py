@@ -58,6 +58,51 @@ def pack_weight(w, bias, k, cin_pad=None, strides=None, cout=None, cin=None, fol
     return FakePacked(w.detach().float().reshape(co, ci, taps), _bias(co, bias, w.device), co, cp, tuple(k), ci, wscale=ws)
 
 
+def ncdhw_to_rowpack(x, dtype, pad_mode_w):
+    """[B,C,T,H,W] -> [B,T,H,W+3,4]: stored pixel xp = input pixel xp - 1, columns 0 / W+1 = the W padding, column W+2 and channel
+    slots >= C zero (include/cvvae.h, cvvae_ncdhw_to_rowpack)"""
+    B, C, T, H, W = x.shape
+    f = x.to(dtype)
+    f = F.pad(f.float(), (1, 1, 0, 0, 0, 0), mode="replicate").to(dtype) if pad_mode_w == L.PAD_REPLICATE else F.pad(f, (1, 1))
+    out = torch.zeros(B, T, H, W + 3, 4, dtype=dtype)
+    out[:, :, :, :W + 2, :C] = f.permute(0, 2, 3, 4, 1)
+    return out
+
+
+def pack_weight_tapsn(w, time_folds=False):
+    co, ci = w.shape[0], w.shape[1]
+    wv = torch.zeros((32, ci, 3, 1, 1), dtype=w.dtype)
+    wv[:9 * co] = w.detach().permute(3, 4, 0, 1, 2).reshape(9 * co, ci, 3, 1, 1)
+    pw = pack_weight(wv.reshape(32, ci, 3), None, (3, 1, 1))
+    pw.time_folds = time_folds
+    return pw
+
+
+def conv_out_gather(v, cout, bias, pad_mode_hw, dtype, u8=False):
+    """out[co] = bias[co] + sum over (dy, dx) of V[y+dy-1, x+dx-1][(dy*3+dx)*cout + co] with the layer's spatial padding"""
+    B, T, H, W, _ = v.shape
+    f = v.permute(0, 4, 1, 2, 3)                                                    # [B,32,T,H,W]
+    f = F.pad(f, (1, 1, 1, 1, 0, 0), mode="replicate") if pad_mode_hw == L.PAD_REPLICATE else F.pad(f, (1, 1, 1, 1, 0, 0))
+    out = bias[:cout].float().view(1, cout, 1, 1, 1).expand(B, cout, T, H, W).clone()
+    for dy in range(3):
+        for dx in range(3):
+            out = out + f[:, (dy * 3 + dx) * cout:(dy * 3 + dx + 1) * cout, :, dy:dy + H, dx:dx + W]
+    out = out.to(dtype)
+    return ncdhw_to_frames_u8(out) if u8 else out
+
+
+def ndhwc_to_rowpack(x, c, pad_mode_w):
+    return ncdhw_to_rowpack(x[..., :c].permute(0, 4, 1, 2, 3), x.dtype, pad_mode_w)
+
+
+def pack_weight_rowpack(w, bias, time_folds=False):
+    """the (3,3,1) weights over the 16 virtual channels compute the original 3x3x3 conv: keep the original weight"""
+    co, ci = w.shape[0], w.shape[1]
+    pw = FakePacked(w.detach().float().reshape(co, ci, 27), _bias(co, bias, w.device), co, 16, (3, 3, 1), ci, time_folds=time_folds,
+                    alg_taps=27)
+    return pw
+
+
 def pack_weight_tfolds(w, bias, cin_pad=None, fast=False):
     """the summed time slots only change HOW boundary frames are multiplied, not the result: the plain weight"""
     co, ci, _, kh, kw = w.shape
@@ -135,9 +180,17 @@ def _pad3(f, pad, mode_t, mode_hw):
 
 def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO,
          prologue=L.PRO_NONE, gn=None, gn_per_frame=False, residual=None, upsample2x=False, out_mode=L.OUT_NDHWC, shortcut=None,
-         bias=None, out_f32=False, alpha=1.0, out=None, cout_pad=None, gn_out=0):
+         bias=None, out_f32=False, alpha=1.0, out=None, cout_pad=None, gn_out=0, row_packed=False):
     assert pw.folded == (upsample2x == 2)
     B, T, H, W, Cs = x.shape
+    if row_packed:  # x already carries the W padding: columns 0 .. W+1 of the stored row are the padded input row
+        assert pw.k == (3, 3, 1) and Cs == 4 and pad[2] == (0, 0) and prologue == L.PRO_NONE and residual is None and shortcut is None
+        f = x.float()[:, :, :, :W - 1, :pw.cin_real].permute(0, 4, 1, 2, 3)
+        f = _pad3(f, (pad[0], pad[1], (0, 0)), pad_mode_t, pad_mode_hw)
+        y = F.conv3d(f, pw.w.reshape(pw.cout, pw.cin_real, 3, 3, 3), None, stride=stride).permute(0, 2, 3, 4, 1)
+        y = y * alpha + (pw.bias if bias is None else bias)[:pw.cout]
+        res = y.to(x.dtype)
+        return (res, FakePart(res, B, pw.cout, gn_out)) if gn_out else res
     assert Cs >= pw.cin, (Cs, pw.cin)
     a = x.float()[..., :pw.cin_real]
     if prologue != L.PRO_NONE:
@@ -281,7 +334,7 @@ def upsample2x_sum(g):
     return g.float().reshape(N, 1, H2 // 2, 2, W2 // 2, 2, C).sum((3, 5)).to(g.dtype)
 
 
-_NAMES = ["pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
+_NAMES = ["ncdhw_to_rowpack", "ndhwc_to_rowpack", "pack_weight_rowpack", "pack_weight_tapsn", "conv_out_gather", "pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
           "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "temporal_attention", "ncdhw_to_ndhwc",
           "ndhwc_to_ncdhw", "blend_", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
 

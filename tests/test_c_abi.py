@@ -29,8 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from cvvae_amd import _lib
-    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64 = 152 bytes
-    assert ctypes.sizeof(_lib.ConvDesc) == 152 and _lib.ConvDesc.w_batch_stride.offset == 128
+    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, 2 x i32 = 160 bytes (ABI 8)
+    assert ctypes.sizeof(_lib.ConvDesc) == 160 and _lib.ConvDesc.w_batch_stride.offset == 128
+    assert _lib.ConvDesc.in_overlap.offset == 152
     assert _lib.ConvDesc.sc_Cin.offset == 136 and _lib.ConvDesc.sc_in_pix_stride.offset == 144
     assert _lib.ConvDesc.in_pix_stride.offset == 24 and _lib.ConvDesc.out_pix_stride.offset == 112
     assert _lib.ConvDesc.alpha.offset == 120

@@ -17,17 +17,37 @@ pytestmark = pytest.mark.gpu
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# max / mean |delta| of the LATENT (posterior mean) and recon PSNR against the reference's fp32 outputs.  The bands are the
-# reference's own low-precision noise with the same head-room as tests/test_gpu_model.py; the fp32
-# model (3xfp16 split MFMA) must meet north_star's |delta| <= 1e-3 as a MAX.
-# (the maximum over N latent values of a noise of fixed sigma grows like sqrt(2 ln N): the fp16 band of the small fixtures, 4e-3 at
-# N ~ 1e4-1e5, becomes 5e-3 at the 1.15e6 latent values of the 720x1280 window; the mean band does not move)
-TOL = {
-    torch.float16: dict(latent_max=5.0e-3, latent_mean=8.0e-4, psnr=62.0),
-    torch.bfloat16: dict(latent_max=3.5e-2, latent_mean=6.0e-3, psnr=45.0),
-    torch.float32: dict(latent_max=1.0e-3, latent_mean=1.0e-4, psnr=80.0),
+# The 16-bit bands are DERIVED from the reference's own low-precision noise at the SAME shape (tests/golden/ref_self_noise.json:
+# the reference's modules run on the CPU in fp16 / bf16 against their own fp32 run, oracle/make_noise.py, with the metric of
+# oracle/parity.py::measure): the HIP model must be no further from the reference's fp32 result than K x the reference's own
+# 16-bit model is -- K_MAX on the maximum (the maximum of ~1e6 noise samples itself wanders by ~10 % between two roundings of the
+# same computation), K_MEAN on the mean, PSNR within PSNR_SLACK dB.  Measured: the HIP path sits BELOW the reference's own noise
+# on every shape (fp32 accumulation and GroupNorm statistics, one rounding per layer output).  A shape without its own entry
+# (the 720x1280 window: its fp16 CPU run takes hours) borrows cfg 3's with the sqrt(2 ln N) growth of a maximum over more values.
+# fp32 models must meet north_star's |delta| <= 1e-3 as a MAXIMUM in both arithmetic modes.
+K_MAX, K_MEAN, PSNR_SLACK = 1.25, 1.10, 1.0
+TOL_F32 = {
+    "exact": dict(latent_max=1.0e-4, latent_mean=1.0e-5, psnr=100.0),   # three fp16 MFMAs per product
+    "fast": dict(latent_max=1.0e-3, latent_mean=1.0e-4, psnr=80.0),     # fp16 MFMA + bf8 correction MFMA (measured 1.7e-4)
 }
+BORROW = {"cfg4win_sd3_t17_720x1280": ("cfg3_sd3_t17_512", 1.08)}
+
+
+def band(name, tag, golden_dir):
+    src, grow = name, 1.0
+    e = P.reference_self_noise(name, tag, golden_dir)
+    if (e is None or "shape" not in e) and name in BORROW:
+        src, grow = BORROW[name]
+        e = P.reference_self_noise(src, tag, golden_dir)
+    if e is None or "shape" not in e:
+        e = dict(P.REFERENCE_SELF_NOISE[tag])  # the T=9 96x96 probe of BASELINE.md section 2 (last resort)
+        grow = 1.35                              # sqrt(2 ln N) from 7e3 to 1e6 latent values
+    return dict(latent_max=K_MAX * grow * e["latent_max"], latent_mean=K_MEAN * e["latent_mean"],
+                psnr=e["recon_psnr_db"] - PSNR_SLACK, source=f"{src}/{tag}")
+
+
 TAG = {torch.float16: "f16", torch.bfloat16: "bf16", torch.float32: "f32"}
+MODES = [(torch.float16, None), (torch.bfloat16, None), (torch.float32, "exact"), (torch.float32, "fast")]
 
 
 def _log(line: str):
@@ -45,9 +65,9 @@ def _model(family, over, dtype, wseed):
     return m.to(dtype).cuda().eval()
 
 
-@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("dtype,mode", MODES, ids=["float16", "bfloat16", "float32", "float32-fast"])
 @pytest.mark.parametrize("name", sorted(BIG_CASES))
-def test_baseline_shape_golden(name, dtype, golden_dir):
+def test_baseline_shape_golden(name, dtype, mode, golden_dir):
     if not os.path.isfile(os.path.join(golden_dir, name + ".npz")):
         pytest.skip(f"fixture {name}.npz not generated")
     family, over, shape, wseed, xseed, s = BIG_CASES[name]
@@ -55,13 +75,19 @@ def test_baseline_shape_golden(name, dtype, golden_dir):
     if dtype == torch.float32 and not getattr(ops, "SUPPORTS_FP32", False):
         pytest.skip("fp32 models (3xfp16 split MFMA) not built in this revision")
     m = _model(family, over, dtype, wseed)
+    if mode is not None:
+        m.fp32_mode = mode
     r = P.measure(m, name, golden_dir)
-    line = P.fmt(TAG[dtype], r)
+    tag = TAG[dtype] + ("q" if mode == "fast" else "")
+    t = TOL_F32[mode] if mode is not None else band(name, TAG[dtype], golden_dir)
+    line = P.fmt(tag, r) + (f"   [band: max {t['latent_max']:.3e} mean {t['latent_mean']:.3e} PSNR {t['psnr']:.1f} dB"
+                           f"{' = K x reference own ' + t['source'] if 'source' in t else ''}]")
     print("\n" + line)
     _log(line)
-    t = TOL[dtype]
     assert r["latent_max_abs"] <= t["latent_max"], line
     assert r["latent_mean_abs"] <= t["latent_mean"], line
     assert r["recon_psnr_db"] >= t["psnr"], line
     if dtype == torch.float16:
         assert r["latent_mean_abs"] <= 1.0e-3  # north_star's bound, met in the mean by the fp16 path
+    if dtype == torch.float32:
+        assert r["latent_max_abs"] <= 1.0e-3   # ... and as a maximum by both fp32 modes

@@ -1,0 +1,147 @@
+"""Round-3 kernel variants on a real MI355X: the two-N-blocks-per-wave conv instances (NB = 2: every activation fragment read
+from LDS feeds two MFMAs) must reproduce the one-N-block instances -- the K order and the fp32 accumulators of every output
+are the same, so results are BIT-identical (except where the residual is pre-accumulated at another K chunk: last-bit rounding)."""
+import pytest
+import torch
+
+from tests.test_gpu_ops import DEV, REP, ZERO, _ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_nb2(monkeypatch, ops):
+    from tests.test_gpu_round2 import L_desc_name
+    monkeypatch.setenv("CVVAE_CONV_FORCE", "1x16x32:4x2x1:2:2")
+    name = L_desc_name(ops, torch.bfloat16)
+    monkeypatch.delenv("CVVAE_CONV_FORCE")
+    if name is None or not name.endswith("_nb2"):
+        pytest.skip("the NB = 2 instances are not in this build (make -C cvvae_amd/csrc NB2=1; measured: no gain)")
+
+
+def _name_under(monkeypatch, ops, force, fn):
+    names = []
+    ops.PROFILE = lambda d, pw_, launch: (names.append(ops.conv_kernel_name(d)), launch())
+    try:
+        if force:
+            monkeypatch.setenv("CVVAE_CONV_FORCE", force)
+        out = fn()
+    finally:
+        ops.PROFILE = None
+        if force:
+            monkeypatch.delenv("CVVAE_CONV_FORCE")
+    return out, names
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_nb2_instances_reproduce_nb1_bit_for_bit(dtype, monkeypatch):
+    ops, L = _ops()
+    _need_nb2(monkeypatch, ops)
+    g = torch.Generator().manual_seed(5)
+
+    def rnd(shape, scale=1.0):
+        return (torch.randn(shape, generator=g) * scale).to(dtype).to(DEV)
+
+    ones = lambda c: torch.ones(c, device=DEV)    # noqa: E731
+    zeros = lambda c: torch.zeros(c, device=DEV)  # noqa: E731
+    cases = []
+    # (label, NB2 force, Cin, Cout, k, T, H, W, pad, mode_t, mode_hw, ups, out_mode, residual, tfolds)
+    cases.append(("k333 128ch odd T", "2x8x32:4x2x1:1:2", 128, 128, (3, 3, 3), 5, 40, 72, ((2, 0), (1, 1), (1, 1)), REP, REP, 0, 0, False, True))
+    cases.append(("k333 256ch", "1x8x32:2x4x1:1:2", 256, 256, (3, 3, 3), 4, 24, 40, ((1, 1), (1, 1), (1, 1)), REP, REP, 0, 0, False, True))
+    cases.append(("k333 256->512 zero pad", "1x8x32:2x4x1:1:2", 256, 512, (3, 3, 3), 3, 16, 32, ((1, 1), (1, 1), (1, 1)), ZERO, ZERO, 0, 0, False, False))
+    cases.append(("upfold shuffle", "1x8x32:2x4x1:1:2", 256, 512, (3, 3, 3), 3, 12, 20, ((1, 1), (1, 1), (1, 1)), REP, REP, 2, 2, False, True))
+    cases.append(("k133 256 residual", "1x8x32:2x4x1:2:2", 256, 256, (1, 3, 3), 3, 24, 40, ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, 0, 0, True, False))
+    cases.append(("k133 128 residual", "1x16x32:4x2x1:2:2", 128, 128, (1, 3, 3), 3, 40, 72, ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, 0, 0, True, False))
+    cases.append(("k133 128 plain", "1x16x32:4x2x1:2:2", 128, 128, (1, 3, 3), 3, 40, 72, ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, 0, 0, False, False))
+    for label, force, cin, cout, k, T, H, W, pad, mt, mhw, ups, om, with_res, tf in cases:
+        x = rnd((2, T, H, W, cin))
+        w = rnd((cout, cin) + k, 1.0 / (cin * k[0] * k[1] * k[2]) ** 0.5)
+        b = rnd((cout,), 0.1).float()
+        if ups == 2:
+            pw = ops.pack_weight_upfold(w, b, time_folds=tf)
+        elif tf:
+            pw = ops.pack_weight_tfolds(w, b)
+        else:
+            pw = ops.pack_weight(w.reshape(cout, cin, -1), b, k)
+        gn = ops.gn_stats(x, 1.0 + 0.1 * torch.randn(cin, generator=g).to(DEV), 0.1 * torch.randn(cin, generator=g).to(DEV), 1e-6) if not ups else None
+        kw = dict(pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=1 if gn is not None else 0, gn=gn, upsample2x=ups,
+                  out_mode=L.OUT_TIME_SHUFFLE if om == 2 else L.OUT_NDHWC, gn_out=32)
+        (y1, p1), n1 = _name_under(monkeypatch, ops, None, lambda: ops.conv(x, pw, **kw))
+        if with_res:
+            kw["residual"] = rnd(tuple(y1.shape))
+            (y1, p1), n1 = _name_under(monkeypatch, ops, None, lambda: ops.conv(x, pw, **kw))
+        (y2, p2), n2 = _name_under(monkeypatch, ops, force, lambda: ops.conv(x, pw, **kw))
+        assert n2[-1].endswith("_nb2") and not n1[-1].endswith("_nb2"), (label, n1, n2)
+        if with_res:
+            ulp = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+            assert (y1.float() - y2.float()).abs().max().item() <= ulp * 8, label
+        else:
+            assert torch.equal(y1, y2), f"{label}: {n1[-1]} vs {n2[-1]}"
+        cst = y1.shape[-1]
+        a = ops.gn_finalize(p1, ones(cst), zeros(cst), 1e-6)
+        c = ops.gn_finalize(p2, ones(cst), zeros(cst), 1e-6)
+        assert torch.allclose(a[0], c[0], rtol=2e-5) and torch.allclose(a[1], c[1], rtol=2e-5, atol=2e-6), label
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_nb2_fused_shortcut(dtype, monkeypatch):
+    """ResnetBlock tail with a channel change on the NB = 2 per-frame instance: conv2 + fused 1x1 shortcut in one accumulator set"""
+    ops, L = _ops()
+    _need_nb2(monkeypatch, ops)
+    g = torch.Generator().manual_seed(6)
+    rnd = lambda shape, s=1.0: (torch.randn(shape, generator=g) * s).to(dtype).to(DEV)  # noqa: E731
+    h, x = rnd((2, 3, 24, 40, 256)), rnd((2, 3, 24, 40, 128))
+    w2, ws = rnd((256, 256, 9), 1 / 48.0), rnd((256, 128, 1), 1 / 11.3)
+    pw2 = ops.pack_weight(w2, rnd((256,), 0.1).float(), (1, 3, 3))
+    pws = ops.pack_weight(ws, None, (1, 1, 1))
+    gn = ops.gn_stats(h, torch.ones(256, device=DEV), torch.zeros(256, device=DEV), 1e-6)
+    kw = dict(pad=((0, 0), (1, 1), (1, 1)), prologue=1, gn=gn, shortcut=(x, pws), gn_out=32)
+    (y1, _), n1 = _name_under(monkeypatch, ops, None, lambda: ops.conv(h, pw2, **kw))
+    (y2, _), n2 = _name_under(monkeypatch, ops, "1x8x32:2x4x1:2:2", lambda: ops.conv(h, pw2, **kw))
+    assert n2[-1].endswith("_nb2") and not n1[-1].endswith("_nb2"), (n1, n2)
+    assert torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["sd3_causal", "sd3_sym", "vae3d_causal", "vae3d_zero", "narrow"])
+def test_rowpacked_conv_in_vs_fp32_conv3d(dtype, case):
+    """conv_in (3 -> 128, 3x3x3) as the (3,3,1) convolution over the row-packed input (cvvae_conv_desc.in_overlap; kW taps in 16
+    virtual channels): against F.conv3d in fp32 on the same 16-bit inputs, every padding flavour of the two encoders, odd frame
+    counts (two-frame tiles + the one-frame sibling), widths that are no multiple of the tile, batch 2; and against the
+    channel-padded form (same products, another summation order)."""
+    import torch.nn.functional as F
+    ops, L = _ops()
+    tpad, mode_t, mode_hw, shape = {
+        "sd3_causal": ((2, 0), REP, REP, (2, 5, 40, 72)),
+        "sd3_sym": ((1, 1), REP, REP, (1, 4, 24, 64)),
+        "vae3d_causal": ((2, 0), REP, ZERO, (1, 5, 40, 72)),
+        "vae3d_zero": ((1, 1), ZERO, ZERO, (1, 3, 16, 96)),
+        "narrow": ((2, 0), REP, REP, (1, 3, 20, 50)),
+    }[case]
+    B, T, H, W = shape
+    g = torch.Generator().manual_seed(7)
+    x = (torch.rand((B, 3, T, H, W), generator=g) * 2 - 1).to(dtype)
+    w = (torch.randn((128, 3, 3, 3, 3), generator=g) / 9.0).to(dtype)
+    b = torch.randn(128, generator=g) * 0.1
+    xr = x.float()
+    xr = F.pad(xr, (1, 1, 1, 1, 0, 0), mode="replicate") if mode_hw == REP else F.pad(xr, (1, 1, 1, 1, 0, 0))
+    xr = F.pad(xr, (0, 0, 0, 0) + tpad, mode="replicate") if mode_t == REP else F.pad(xr, (0, 0, 0, 0) + tpad)
+    ref = F.conv3d(xr, w.float(), b)
+    for tf in ((False, True) if mode_t == REP else (False,)):
+        xp = ops.ncdhw_to_rowpack(x.to(DEV), dtype, mode_hw)
+        assert tuple(xp.shape) == (B, T, H, W + 3, 4)
+        pw = ops.pack_weight_rowpack(w.to(DEV), b.to(DEV), time_folds=tf)
+        y, part = ops.conv(xp, pw, pad=(tpad, (1, 1), (0, 0)), pad_mode_t=mode_t, pad_mode_hw=mode_hw, gn_out=32, row_packed=True)
+        got = y.float().cpu().permute(0, 4, 1, 2, 3)
+        assert got.shape == ref.shape
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        err = (got - ref).abs().max().item()
+        assert err <= (2 if tf else 1) * ulp * ref.abs().max().item() + 1e-6, (case, tf, err)
+        # fused statistics of what was stored
+        sc, sh = ops.gn_finalize(part, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), 1e-6)
+        sc2, sh2 = ops.gn_stats(y, torch.ones(128, device=DEV), torch.zeros(128, device=DEV), 1e-6)
+        assert torch.allclose(sc, sc2, rtol=2e-4) and torch.allclose(sh, sh2, rtol=2e-4, atol=2e-4)
+    # the channel-padded form of the same layer
+    xd = ops.ncdhw_to_ndhwc(x.to(DEV), 16, dtype)
+    pwc = ops.pack_weight(w.to(DEV).reshape(128, 3, 27), b.to(DEV), (3, 3, 3), cin_pad=16)
+    yc = ops.conv(xd, pwc, pad=(tpad, (1, 1), (1, 1)), pad_mode_t=mode_t, pad_mode_hw=mode_hw)
+    assert (yc.float() - y.float()).abs().max().item() <= 4 * ulp * ref.abs().max().item()

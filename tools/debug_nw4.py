@@ -36,7 +36,7 @@ for rp in ("0", "1"):
 
 print("---- which records differ (4-wave, pro=1, stats=1)")
 outs = [run("1x8x32:1x4x1:2", 1, 0, 1) for _ in range(3)]
-a, b = outs[0][1].buf, outs[1][1].buf          # [rows, slabs, G, 3]
+a, b = outs[0][1].buf.permute(0, 2, 1, 3), outs[1][1].buf.permute(0, 2, 1, 3)          # library layout [rows, G, slabs, 3] -> [rows, slabs, G, 3]
 d = (a != b)
 print("shape", tuple(a.shape), "differing entries", int(d.sum()), "by field", [int(d[..., i].sum()) for i in range(3)])
 idx = d.any(-1).nonzero()[:12]
