@@ -30,8 +30,10 @@
   X(3,3,1, 1,1,1, 2,8,32, 2,4,1, 1, 0,0) \
   X(3,3,1, 1,1,1, 1,8,32, 2,4,1, 1, 0,0)
 // the taps-in-N last layer (include/cvvae.h cvvae_conv_out_gather): (3,1,1) over four-frame tiles, 27 of 32 columns useful
+// (the 256-pixel tile -- 61 KB of LDS -- leaves room for TWO workgroups per CU: one's staging / store runs under the other's K
+//  loop.  Measured at 128 -> 27 columns @17x512^2: 0.71 ms; the 512-pixel tile 0.89 ms, 64-channel chunks 1.09 ms)
 #define CVVAE_CONV_G13(X) \
-  X(3,1,1, 1,1,1, 4,4,32, 8,1,1, 2, 1,0)
+  X(3,1,1, 1,1,1, 4,4,16, 8,1,1, 2, 1,0)
 // BN = 32 (conv_out: Cout = 3 / 8 / 32) and the fused nearest-2x upsample conv
 #define CVVAE_CONV_G4(X) \
   X(3,3,3, 1,1,1, 1,8,32, 8,1,1, 1, 0,0) \

@@ -1036,7 +1036,12 @@ template <typename T, int CO>
 __global__ __launch_bounds__(256) void conv_out_gather_kernel(const float* __restrict__ V, int T_, int H, int W, long long ldv,
                                                               const float* __restrict__ bias, int replicate, long long npix,
                                                               T* __restrict__ out, uint8_t* __restrict__ u8) {
-  const long long pix = (long long)blockIdx.x * 256 + threadIdx.x;  // over B*T*H*W
+  // XCD-aware block order: consecutive blocks run on different XCDs (8, round-robin), each with its own L2; every V row is read
+  // by the three output rows around it, so each XCD gets a CONTIGUOUS band of blocks (rows) -- the neighbours' reads hit its L2
+  // instead of fetching the row into eight L2s
+  const long long nblk = gridDim.x, q8 = nblk / 8, bid = blockIdx.x;
+  const long long lb = bid < q8 * 8 ? (bid % 8) * q8 + bid / 8 : bid;
+  const long long pix = lb * 256 + threadIdx.x;  // over B*T*H*W
   if (pix >= npix) return;
   const int x = (int)(pix % W);
   const long long r1 = pix / W;

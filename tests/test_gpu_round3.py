@@ -145,3 +145,66 @@ def test_rowpacked_conv_in_vs_fp32_conv3d(dtype, case):
     pwc = ops.pack_weight(w.to(DEV).reshape(128, 3, 27), b.to(DEV), (3, 3, 3), cin_pad=16)
     yc = ops.conv(xd, pwc, pad=(tpad, (1, 1), (1, 1)), pad_mode_t=mode_t, pad_mode_hw=mode_hw)
     assert (yc.float() - y.float()).abs().max().item() <= 4 * ulp * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("case", ["sd3", "vae3d", "odd", "image"])
+def test_tapsn_conv_out_vs_fp32_conv3d(dtype, case):
+    """conv_out (128 -> 3, 3x3x3, GroupNorm + SiLU prologue) as the taps-in-N (3,1,1) conv + the fp32 gather pass
+    (cvvae_conv_out_gather): against F.conv3d in fp32 on the same activation values, both decoders' paddings (sd3: replicate on every
+    face; vae3d: zero on every face), frame counts that do not fill the four-frame tile, a single frame, batch 2; the uint8 store
+    against the scripts' post-processing of the float result; and against the 32-column form of the same layer."""
+    import torch.nn.functional as F
+    ops, L = _ops()
+    mode, shape = {"sd3": (REP, (2, 5, 24, 40)), "vae3d": (ZERO, (1, 4, 16, 64)), "odd": (REP, (1, 3, 20, 50)), "image": (REP, (1, 1, 32, 32))}[case]
+    B, T, H, W = shape
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((B, T, H, W, 128), generator=g).to(dtype)
+    w = (torch.randn((3, 128, 3, 3, 3), generator=g) / (128 * 27) ** 0.5).to(dtype)
+    b = torch.randn(3, generator=g) * 0.1
+    gamma, beta = 1.0 + 0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g)
+    xd = x.to(DEV)
+    gn = ops.gn_stats(xd, gamma.to(DEV), beta.to(DEV), 1e-6)
+    a = F.silu(F.group_norm(x.float().permute(0, 4, 1, 2, 3), 32, gamma, beta, 1e-6)).to(dtype).float()   # what the kernel stages
+    ap = F.pad(a, (1, 1, 1, 1, 1, 1), mode="replicate") if mode == REP else F.pad(a, (1, 1, 1, 1, 1, 1))
+    ref = F.conv3d(ap, w.float(), b)
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    pad = ((1, 1), (0, 0), (0, 0))
+    for tf in ((False, True) if mode == REP else (False,)):
+        pw = ops.pack_weight_tapsn(w.to(DEV), time_folds=tf)
+        v = ops.conv(xd, pw, pad=pad, pad_mode_t=mode, pad_mode_hw=mode, prologue=L.PRO_GN_SILU, gn=gn, out_f32=True)
+        assert tuple(v.shape) == (B, T, H, W, 32) and v.dtype == torch.float32
+        y = ops.conv_out_gather(v, 3, b.to(DEV), mode, dtype)
+        got = y.float().cpu()
+        assert got.shape == ref.shape
+        err = (got - ref).abs().max().item()
+        # (the kernel's GroupNorm statistics / SiLU differ from torch's in the last bit of some staged values: x3 as in test_gpu_ops)
+        assert err <= (2 if tf else 1) * 3 * ulp * ref.abs().max().item() + 1e-6, (case, tf, err)
+    if B == 1:
+        u8 = ops.conv_out_gather(v, 3, b.to(DEV), mode, dtype, u8=True)
+        assert torch.equal(u8, ops.ncdhw_to_frames_u8(y))
+    pw3 = ops.pack_weight(w.to(DEV).reshape(3, 128, 27), b.to(DEV), (3, 3, 3))
+    y3 = ops.conv(xd, pw3, pad=((1, 1), (1, 1), (1, 1)), pad_mode_t=mode, pad_mode_hw=mode, prologue=L.PRO_GN_SILU, gn=gn,
+                  out_mode=L.OUT_NCDHW)
+    assert (y3.float() - y.float()).abs().max().item() <= 4 * ulp * ref.abs().max().item()
+
+
+def test_decode_to_frames_u8_fused_store_matches_separate_pass():
+    """decode_to_frames_u8 on a one-window, one-tile clip stores uint8 from the decoder's last pass: same bytes as decode() + the
+    conversion pass"""
+    import cvvae_amd
+    from oracle import parity as P
+    for cls in (cvvae_amd.CVVAESD3Model, cvvae_amd.CVVAEModel):
+        m = cls()
+        P.load_seeded(m, 0)
+        m = m.to(torch.bfloat16).cuda().eval()
+        zc = m.decoder.conv_in.weight.shape[1]
+        z = (torch.randn((1, zc, 3, 8, 8), generator=torch.Generator().manual_seed(1)) * 0.5).to(torch.bfloat16).cuda()
+        a = m.decode_to_frames_u8(z)
+        b = ops_u8(m, z)
+        assert a.dtype == torch.uint8 and tuple(a.shape) == (9, 64, 64, 3) and torch.equal(a, b)
+
+
+def ops_u8(m, z):
+    from cvvae_amd import ops
+    return ops.ncdhw_to_frames_u8(m.decode(z).sample.contiguous())
