@@ -84,6 +84,21 @@ PROTOTYPES = {
 _lib = None
 
 
+def source_fingerprint() -> str:
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from (csrc/*.h, csrc/*.hip, include/cvvae.h):
+    measurements kept under profiles/ are stamped with it, and bench.py flags them stale when the sources have moved on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(_HERE, "csrc", "*.h")) + glob.glob(os.path.join(_HERE, "csrc", "*.hip")))
+    files.append(os.path.join(os.path.dirname(_HERE), "include", "cvvae.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 class CvvaeError(RuntimeError):
     pass
 

@@ -1036,36 +1036,57 @@ template <typename T, int CO>
 __global__ __launch_bounds__(256) void conv_out_gather_kernel(const float* __restrict__ V, int T_, int H, int W, long long ldv,
                                                               const float* __restrict__ bias, int replicate, long long npix,
                                                               T* __restrict__ out, uint8_t* __restrict__ u8) {
-  // XCD-aware block order: consecutive blocks run on different XCDs (8, round-robin), each with its own L2; every V row is read
-  // by the three output rows around it, so each XCD gets a CONTIGUOUS band of blocks (rows) -- the neighbours' reads hit its L2
-  // instead of fetching the row into eight L2s
+  // XCD-aware block order: consecutive blocks run on different XCDs (8, round-robin), each with its own L2; neighbouring patches
+  // share their halo records, so each XCD gets a CONTIGUOUS band of patches
   const long long nblk = gridDim.x, q8 = nblk / 8, bid = blockIdx.x;
   const long long lb = bid < q8 * 8 ? (bid % 8) * q8 + bid / 8 : bid;
-  const long long pix = lb * 256 + threadIdx.x;  // over B*T*H*W
-  if (pix >= npix) return;
-  const int x = (int)(pix % W);
-  const long long r1 = pix / W;
-  const int y = (int)(r1 % H);
-  const long long bt = r1 / H;  // b*T + t
+  // A block is an 8 x 32 pixel patch.  The 10 x 34 records around it are staged ONCE into LDS with coalesced 16-byte loads (every
+  // thread reading its nine neighbours' 12 bytes straight from memory touched nine 128-byte lines per pixel: 3.8 GB fetched for
+  // a 0.57 GB V, 0.56 ms); the nine-neighbour sums then come from LDS.  Pixel pitch in LDS: 9*CO + 2 floats (odd: no bank conflicts
+  // between the lanes of a row).  Halo pixels outside the frame are staged from the clamped coordinate (replicate padding) or as
+  // zeros (zero padding), so the sum below needs no bounds logic.
+  constexpr int PW = 34, PH = 10, NV = 9 * CO, PITCH = NV + 2;
+  __shared__ float sv[PH * PW * PITCH];
+  const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+  const int tx = (int)(lb % tiles_x);
+  const long long r0 = lb / tiles_x;
+  const int ty = (int)(r0 % tiles_y);
+  const long long bt = r0 / tiles_y;  // b*T + t
+  const int x0 = tx * 32 - 1, y0 = ty * 8 - 1;
+  // stage: one thread per (pixel, 16-byte quarter-record): NV = 27 floats = 6.75 quarters -> 7 loads per pixel
+  constexpr int QP = (NV + 3) / 4;
+  for (int i = threadIdx.x; i < PH * PW * QP; i += 256) {
+    const int q = i % QP, pp = i / QP;
+    const int px = pp % PW, py = pp / PW;
+    int ys = y0 + py, xs = x0 + px;
+    const bool outside = ys < 0 || ys >= H || xs < 0 || xs >= W;
+    ys = ys < 0 ? 0 : (ys >= H ? H - 1 : ys);
+    xs = xs < 0 ? 0 : (xs >= W ? W - 1 : xs);
+    float4 v = *reinterpret_cast<const float4*>(V + ((bt * H + ys) * W + xs) * ldv + q * 4);  // (ldv % 4 == 0: 16-byte aligned)
+    if (outside && !replicate) v = make_float4(0.f, 0.f, 0.f, 0.f);
+    float* d = sv + pp * PITCH + q * 4;
+    d[0] = v.x;
+    if (q * 4 + 1 < NV) d[1] = v.y;
+    if (q * 4 + 2 < NV) d[2] = v.z;
+    if (q * 4 + 3 < NV) d[3] = v.w;
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & 31, ly = threadIdx.x >> 5;
+  const int x = tx * 32 + lx, y = ty * 8 + ly;
+  if (x >= W || y >= H) return;
+  const long long pix = (bt * H + y) * W + x;
+  (void)npix;
   float acc[CO];
 #pragma unroll
   for (int c = 0; c < CO; ++c) acc[c] = bias[c];
 #pragma unroll
-  for (int dy = 0; dy < 3; ++dy) {
-    int ys = y + dy - 1;
-    const bool oy = ys < 0 || ys >= H;
-    ys = ys < 0 ? 0 : (ys >= H ? H - 1 : ys);
+  for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
-      int xs = x + dx - 1;
-      const bool ox = xs < 0 || xs >= W;
-      xs = xs < 0 ? 0 : (xs >= W ? W - 1 : xs);
-      if (!replicate && (oy || ox)) continue;  // zero padding: the neighbour is outside the frame
-      const float* v = V + ((bt * H + ys) * W + xs) * ldv + (dy * 3 + dx) * CO;
+      const float* v = sv + ((ly + dy) * PW + (lx + dx)) * PITCH + (dy * 3 + dx) * CO;
 #pragma unroll
       for (int c = 0; c < CO; ++c) acc[c] += v[c];
     }
-  }
   const long long thw = (long long)T_ * H * W;
   const long long b = bt / T_, s = pix - b * thw;
 #pragma unroll
@@ -1593,12 +1614,15 @@ int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t
 
 int cvvae_conv_out_gather(int32_t dtype, const float* V, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Cout, int64_t ldv,
                           const float* bias, int32_t pad_mode_hw, void* out_ncdhw, uint8_t* out_u8, void* stream) {
-  if (!V || !bias || B <= 0 || T <= 0 || H <= 0 || W <= 0 || ldv < 9LL * Cout || (pad_mode_hw != 0 && pad_mode_hw != 1)) return CVVAE_EINVAL;
+  if (!V || !bias || B <= 0 || T <= 0 || H <= 0 || W <= 0 || ldv < ((9LL * Cout + 3) & ~3LL) || (ldv & 3) || (pad_mode_hw != 0 && pad_mode_hw != 1))
+    return CVVAE_EINVAL;
   if ((out_ncdhw != nullptr) == (out_u8 != nullptr)) return CVVAE_EINVAL;
   if (Cout != 3) return CVVAE_EUNSUPPORTED;  // the shipped decoders: RGB
   if (out_u8 && B != 1) return CVVAE_EINVAL;
   const long long npix = (long long)B * T * H * W;
-  const int grid = (int)((npix + 255) / 256);
+  const long long nblk = (long long)B * T * ((H + 7) / 8) * ((W + 31) / 32);
+  if (nblk >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
+  const int grid = (int)nblk;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == CVVAE_BF16)
     hipLaunchKernelGGL((conv_out_gather_kernel<__bf16, 3>), dim3(grid), dim3(256), 0, s, V, T, H, W, (long long)ldv, bias, pad_mode_hw,

@@ -527,7 +527,8 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
 # --------------------------------------------------------------------------------------------------------
 # the frozen 2-D "constraint" decoder of the training path (SD3 image VAE decoder per frame)
 # --------------------------------------------------------------------------------------------------------
-def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool = True, tape: Optional[list] = None):
+def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool = True, tape: Optional[list] = None,
+               sc: str = ".conv_shortcut"):
     """ResnetBlock2D.forward, lvdm/modules/diffusionmodules/vae_blocks_sd3.py:368-421, on [frames,1,H,W,C]: GN(eps 1e-6)+SiLU
     fused into conv1 and conv2 (per-frame 3x3, zero pad), 1x1 shortcut and residual add in conv2's launch."""
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
@@ -536,7 +537,7 @@ def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool 
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     if tape is not None:
         tape.append(dict(op="resnet", pre=pre, x=x, xp=xp, h=h, hp=hp))
-    return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
+    return resnet_tail(wc, x, h, pre, pre + sc, g2, want_stats)
 
 
 def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
@@ -572,6 +573,80 @@ def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Opti
     y = ops.conv(h, wc.conv("conv_out", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g,
                  out_mode=L.OUT_NCDHW)                      # [b*t, 3, 1, H, W]
     return y.view(B, T, y.shape[1], y.shape[3], y.shape[4]).transpose(1, 2).contiguous()
+
+
+# --------------------------------------------------------------------------------------------------------
+# SURVEY 8(f) rank 4, second half: the frozen 2-D encoder / decoder of the SD2.1-compatible family (LDM layout) per frame
+# --------------------------------------------------------------------------------------------------------
+def _frames_in(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
+    """[b,c,t,h,w] -> NDHWC [(b t),1,h,w,cpad]: 'b c t h w -> (b t) c h w' (frames are the batch rows: every GroupNorm is per frame)"""
+    h = ops.ncdhw_to_ndhwc(x, cpad, dtype)
+    return h.view(h.shape[0] * h.shape[1], 1, h.shape[2], h.shape[3], cpad)
+
+
+def _frames_out(y: torch.Tensor, B: int, T: int) -> torch.Tensor:
+    """NCDHW [(b t),c,1,h,w] -> [b,c,t,h,w]"""
+    return y.view(B, T, y.shape[1], y.shape[3], y.shape[4]).transpose(1, 2).contiguous()
+
+
+def ldm2d_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """EncoderWith3DWrapper.forward over Encoder.forward (lvdm/modules/diffusionmodules/model.py:587-614, 877-887): every frame
+    through conv_in -> levels of ResnetBlocks (GroupNorm eps 1e-6 + swish + 3x3, 1x1 nin_shortcut) with Downsample (zero pad
+    right / bottom, 3x3 stride 2) -> mid (block_1, single-head attn_1, block_2) -> norm_out + swish + conv_out -> quant_conv 1x1.
+    x NCDHW [b,c,t,h,w] -> moments [b,2z,t,h/f,w/f]."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    B, T = x.shape[0], x.shape[2]
+    nlev = len(cfg["ch_mult"])
+    h = _frames_in(x, 32, dtype)
+    h, hp = ops.conv(h, wc.conv("conv_in", (1, 3, 3), cin_pad=32), pad=P2D, pad_mode_hw=ZERO, gn_out=G32)
+    for lvl in range(nlev):
+        for j in range(cfg["num_res_blocks"]):
+            h, hp = c2d_resnet(wc, h, hp, f"down.{lvl}.block.{j}", sc=".nin_shortcut")
+        if lvl != nlev - 1:  # Downsample: F.pad (0,1,0,1) zeros, conv 3x3 stride 2 pad 0 (model.py:88-95)
+            h, hp = ops.conv(h, wc.conv(f"down.{lvl}.downsample.conv", (1, 3, 3)), stride=(1, 2, 2), pad=((0, 0), (0, 1), (0, 1)),
+                             pad_mode_hw=ZERO, gn_out=G32)
+    h, _ = c2d_resnet(wc, h, hp, "mid.block_1", want_stats=False, sc=".nin_shortcut")
+    a = "mid.attn_1"
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32)
+    h, hp = c2d_resnet(wc, h, hp, "mid.block_2", sc=".nin_shortcut")
+    g = _norm(wc, h, hp, "norm_out", 1e-6)
+    zc = wc.m.get_parameter("conv_out.weight").shape[0]
+    m = ops.conv(h, wc.conv("conv_out", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g,
+                 cout_pad=ops.round_up(zc, 128) if wc.has("quant_conv.weight") else None,
+                 out_mode=L.OUT_NDHWC if wc.has("quant_conv.weight") else L.OUT_NCDHW)
+    if wc.has("quant_conv.weight"):  # legacy=True: nn.Conv2d(2z, 2z, 1) on the moments (model.py:870-885)
+        pq = wc.conv("quant_conv", (1, 1, 1), cin_pad=m.shape[-1])
+        q = ops.conv(_flat(m), pq).view(*m.shape[:-1], pq.cout)
+        m = ops.ndhwc_to_ncdhw(q, pq.cout)
+    return _frames_out(m, B, T)
+
+
+def ldm2d_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
+    """DecoderWith3DWrapper.forward over Decoder.forward (model.py:728-772, 820-830): post_quant_conv 1x1 -> conv_in -> mid ->
+    levels (num_res_blocks + 1 ResnetBlocks, Upsample = nearest x2 + 3x3) from the coarsest -> norm_out + swish + conv_out.
+    z NCDHW [b,zc,t,h,w] -> pixels [b,out_ch,t,f*h,f*w]."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    B, T = z.shape[0], z.shape[2]
+    nlev = len(cfg["ch_mult"])
+    if wc.has("post_quant_conv.weight"):
+        h = _frames_in(z, 128, dtype)
+        pq = wc.conv("post_quant_conv", (1, 1, 1), cin_pad=128)
+        h = ops.conv(_flat(h), pq, cout_pad=32).view(*h.shape[:-1], 32)
+    else:
+        h = _frames_in(z, 32, dtype)
+    h, hp = ops.conv(h, wc.conv("conv_in", (1, 3, 3), cin_pad=32), pad=P2D, pad_mode_hw=ZERO, gn_out=G32)
+    h, _ = c2d_resnet(wc, h, hp, "mid.block_1", want_stats=False, sc=".nin_shortcut")
+    a = "mid.attn_1"
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32)
+    h, hp = c2d_resnet(wc, h, hp, "mid.block_2", sc=".nin_shortcut")
+    for lvl in reversed(range(nlev)):
+        for j in range(cfg["num_res_blocks"] + 1):
+            h, hp = c2d_resnet(wc, h, hp, f"up.{lvl}.block.{j}", sc=".nin_shortcut")
+        if lvl != 0:  # Upsample: nearest x2 + conv 3x3 pad 1 (model.py:68-75), as four folded 1x2x2 phase convs
+            h, hp = ops.conv(h, wc.conv_upfold2d(f"up.{lvl}.upsample.conv"), pad=P2D, pad_mode_hw=ZERO, upsample2x=2, gn_out=G32)
+    g = _norm(wc, h, hp, "norm_out", 1e-6)
+    y = ops.conv(h, wc.conv("conv_out", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
+    return _frames_out(y, B, T)
 
 
 # --------------------------------------------------------------------------------------------------------

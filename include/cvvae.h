@@ -203,7 +203,7 @@ int cvvae_ncdhw_to_rowpack(int32_t src_dtype, int32_t dst_dtype, const void* in,
  * columns, no spatial halo, every activation staged 1.5x (time halo) instead of 2.7x, a ninth of the MFMAs -- and this pass
  * finishes the convolution:   out[co][t][y][x] = bias[co] + sum over (dy, dx) of V[t][y+dy-1][x+dx-1][(dy*3+dx)*Cout + co]
  * with the spatial padding of the layer (replicate: clamped neighbour coordinates; zero: neighbours outside the frame add nothing),
- * summed in fp32 in the fixed order dy, dx.  V: fp32 [B,T,H,W,ldv] (ldv >= 9*Cout).  Exactly one of out_ncdhw ([B,Cout,T,H,W] of
+ * summed in fp32 in the fixed order dy, dx.  V: fp32 [B,T,H,W,ldv] (ldv >= 9*Cout rounded up to 4, multiple of 4).  Exactly one of out_ncdhw ([B,Cout,T,H,W] of
  * `dtype`) and out_u8 (B = 1, Cout = 3: uint8 frames [T,H,W,3] = the scripts' (clamp(x,-1,1)+1)*127.5 -> uint8 on the value
  * rounded to `dtype`, cvvae_inference_video.py:47-50) is non-NULL.
  */

@@ -22,6 +22,18 @@ CONSTRAINT_CASES = {
 }
 
 
+# the frozen 2-D halves of the SD2.1-compatible family (lvdm/modules/diffusionmodules/model.py:775-887):
+# name -> (class name, constructor kwargs, input shape, weight seed, input seed)
+LDM_CFG = dict(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+               resolution=256, z_channels=4, double_z=True)   # the SD2.1 image VAE (first_stage_config of the SD2.1 family)
+LDM_CASES = {
+    "ldm2d_enc_t3_32": ("EncoderWith3DWrapper", LDM_CFG, (1, 3, 3, 32, 32), 0, 20),    # clip: every frame on its own
+    "ldm2d_enc_4d_24x16": ("EncoderWith3DWrapper", LDM_CFG, (2, 3, 24, 16), 0, 21),    # two images, non-square
+    "ldm2d_dec_t3_8": ("DecoderWith3DWrapper", LDM_CFG, (1, 4, 3, 8, 8), 0, 22),
+    "ldm2d_dec_4d_6x4": ("DecoderWith3DWrapper", LDM_CFG, (2, 4, 6, 4), 0, 23),
+}
+
+
 # BASELINE.json configs at FULL size (SURVEY 8c "and on GPU the BASELINE shapes"): fixtures hold the full `moments` and a
 # bounded part of `recon` -- recon_sub[t] = recon[:, :, t, (t % s)::s, (3t % s)::s] (stride s over H and W with a per-frame phase,
 # so every kernel tile and every pixel phase of the frame is sampled) -- plus fp64 global moments of the whole recon.

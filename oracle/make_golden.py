@@ -65,6 +65,25 @@ def main_constraint():
         print(f"{name}: latents {tuple(zshape)} recon {tuple(recon.shape)} wsum {wsum:.6f}")
 
 
+def main_ldm():
+    """fixtures of the frozen SD2.1-family 2-D encoder / decoder wrappers, from the reference's own classes"""
+    from oracle.golden_cases import LDM_CASES
+    from oracle.ref_loader import load_reference_ldm
+
+    ref = load_reference_ldm()
+    torch.set_grad_enabled(False)
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, (cls, cfg, shape, wseed, xseed) in LDM_CASES.items():
+        model = getattr(ref, cls)(**cfg).eval()
+        sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+        model.load_state_dict(sd, strict=True)
+        out = model(seeded_input(shape, xseed))
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), out=out.numpy().astype(np.float32),
+                            weight_abs_sum=np.float64(wsum), n_tensors=np.int64(len(sd)))
+        print(f"{name}: in {tuple(shape)} out {tuple(out.shape)} wsum {wsum:.6f}")
+
+
 def main_big(only=None):
     """BASELINE-size fixtures (cfg 1 / 2 / 3 and one window of cfg 4) from the reference's own modules; minutes of CPU each.
     The reference's fp16 / bf16 CPU runs of the same case are recorded too (its own low-precision noise at THIS shape: the
@@ -117,6 +136,8 @@ def main_big(only=None):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "constraint":
         main_constraint()
+    elif len(sys.argv) > 1 and sys.argv[1] == "ldm":
+        main_ldm()
     elif len(sys.argv) > 1 and sys.argv[1] == "big":
         main_big(sys.argv[2:])
     else:

@@ -54,3 +54,26 @@ def load_reference_constraint():
     sys.modules["cvvae_ref_constraint"] = pkg
     return importlib.import_module(name)
 
+
+
+def load_reference_ldm():
+    """returns the reference module lvdm/modules/diffusionmodules/model.py (classes Encoder, Decoder, EncoderWith3DWrapper,
+    DecoderWith3DWrapper -- the SD2.1-family 2-D halves), unmodified.  Its relative import `...modules.attention` is served by the
+    reference's own lvdm/modules/attention.py, both loaded into a synthetic package tree `cvvae_ref_lvdm` whose package __init__
+    files are empty (the real ones pull in the conditioners and training engines)."""
+    name = "cvvae_ref_lvdm.modules.diffusionmodules.model"
+    if name in sys.modules:
+        return sys.modules[name]
+    root = os.path.join(REF_ROOT, "lvdm")
+    if not os.path.isfile(os.path.join(root, "modules", "diffusionmodules", "model.py")):
+        raise FileNotFoundError(f"reference not found under {REF_ROOT}")
+    if _SHIMS not in sys.path:
+        sys.path.insert(0, _SHIMS)
+    import types
+
+    for pkg, path in (("cvvae_ref_lvdm", root), ("cvvae_ref_lvdm.modules", os.path.join(root, "modules")),
+                      ("cvvae_ref_lvdm.modules.diffusionmodules", os.path.join(root, "modules", "diffusionmodules"))):
+        m = types.ModuleType(pkg)
+        m.__path__ = [path]
+        sys.modules[pkg] = m
+    return importlib.import_module(name)

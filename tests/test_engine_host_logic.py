@@ -188,3 +188,42 @@ def test_fp32_fused_shortcut_falls_back_when_scale_would_overflow():
         assert engine._shortcut_scale_fits(wc, "down_blocks.2.resnets.0.conv_shortcut",
                                            wc.conv("down_blocks.2.resnets.0.conv2", (1, 3, 3)), torch.float32)
     assert sum(calls) == 1, "only the other channel-changing block keeps its fused shortcut"
+
+
+def _ldm_model(name):
+    import cvvae_amd.constraint_ldm as C
+    from oracle.golden_cases import LDM_CASES
+    cls, cfg, shape, wseed, xseed = LDM_CASES[name]
+    m = getattr(C, cls)(**cfg)
+    m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, wseed), strict=True)
+    return m.eval().requires_grad_(False), seeded_input(shape, xseed)
+
+
+@pytest.mark.parametrize("name", ["ldm2d_enc_t3_32", "ldm2d_enc_4d_24x16", "ldm2d_dec_t3_8", "ldm2d_dec_4d_6x4"])
+def test_ldm_2d_wrappers_match_reference_golden_through_emulated_kernels(name, golden_dir):
+    """EncoderWith3DWrapper / DecoderWith3DWrapper of the SD2.1-compatible family (model.py:775-887) -- the launch
+    programs (per-frame rows, zero-pad downsample, folded upsample, quant / post_quant 1x1 layers, middle attention) against fixtures
+    produced by the reference's own classes (oracle/make_golden.py ldm)"""
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    m, x = _ldm_model(name)
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        out = m(x)
+    assert out.shape == gold["out"].shape
+    assert np.abs(out.numpy() - gold["out"]).max() <= TOL
+
+
+def test_ldm_2d_wrappers_import_path_and_state_dict():
+    """the reference's module path and, when it is mounted, its classes' state-dict names and shapes"""
+    from lvdm.modules.diffusionmodules.model import DecoderWith3DWrapper, EncoderWith3DWrapper
+    from oracle.golden_cases import LDM_CFG
+    from oracle.ref_loader import load_reference_ldm, reference_available
+    e, d = EncoderWith3DWrapper(**LDM_CFG), DecoderWith3DWrapper(**LDM_CFG)
+    assert len(e.state_dict()) == 108 and len(d.state_dict()) == 140
+    assert "quant_conv.weight" in e.state_dict() and "post_quant_conv.weight" in d.state_dict()
+    assert "quant_conv.weight" not in EncoderWith3DWrapper(legacy=False, **LDM_CFG).state_dict()
+    if reference_available():
+        ref = load_reference_ldm()
+        for mine, theirs in ((e, ref.EncoderWith3DWrapper(**LDM_CFG)), (d, ref.DecoderWith3DWrapper(**LDM_CFG))):
+            assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
+    with pytest.raises(NotImplementedError):
+        EncoderWith3DWrapper(**dict(LDM_CFG, attn_resolutions=[32]))

@@ -208,3 +208,28 @@ def test_decode_to_frames_u8_fused_store_matches_separate_pass():
 def ops_u8(m, z):
     from cvvae_amd import ops
     return ops.ncdhw_to_frames_u8(m.decode(z).sample.contiguous())
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16, torch.float32])
+@pytest.mark.parametrize("name", ["ldm2d_enc_t3_32", "ldm2d_enc_4d_24x16", "ldm2d_dec_t3_8", "ldm2d_dec_4d_6x4"])
+def test_ldm_2d_wrappers_golden(name, dtype, golden_dir):
+    """the frozen SD2.1-family EncoderWith3DWrapper / DecoderWith3DWrapper (lvdm/modules/diffusionmodules/model.py:
+    775-887) on the HIP kernels against fixtures of the reference's own classes (fp32 CPU): one-rounding-per-layer bands as for the
+    3-D models (tests/test_gpu_model.py)"""
+    import os
+    import numpy as np
+    import cvvae_amd.constraint_ldm as C
+    from oracle.golden_cases import LDM_CASES
+    from oracle.seeded import seeded_input, seeded_state_dict
+    cls, cfg, shape, wseed, xseed = LDM_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))["out"]
+    m = getattr(C, cls)(**cfg)
+    m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, wseed), strict=True)
+    m = m.to(dtype).cuda().eval().requires_grad_(False)
+    with torch.no_grad():
+        out = m(seeded_input(shape, xseed).to(dtype).cuda())
+    assert tuple(out.shape) == gold.shape and out.dtype == dtype
+    err = np.abs(out.float().cpu().numpy() - gold)
+    tol_max, tol_mean = {torch.float32: (1e-4, 1e-5), torch.float16: (8e-3, 1.2e-3), torch.bfloat16: (6e-2, 9e-3)}[dtype]
+    print(f"\n{name} {dtype}: max|d| {err.max():.3e} mean|d| {err.mean():.3e} (range {np.abs(gold).max():.2f})")
+    assert err.max() <= tol_max * max(1.0, float(np.abs(gold).max())) and err.mean() <= tol_mean

@@ -16,15 +16,28 @@ def short(n):
     m = re.search(r"conv_fwd_kernel<(.*?)>\(", n)
     if m:
         f = [x.strip() for x in m.group(1).split(",")]
-        xp = ""
-        if f[-1] in ("true", "false"):  # trailing template argument XP (split-precision instances) since ABI 6
-            xp = "_xp" if f[-1] == "true" else ""
+        sfx = ""
+        if f[-1] in ("true", "false"):  # ABI 6-7: one trailing bool XP
+            sfx = "_xp" if f[-1] == "true" else ""
             f = f[:-1]
+        else:  # ABI 8: trailing ints XP (0 / 1 split precision / 2 fast fp32) and NB (N-blocks per wave)
+            xp, nb = int(f[-2]), int(f[-1])
+            sfx = {0: "", 1: "_xp", 2: "_xq"}[xp] + ("_nb2" if nb == 2 else "")
+            f = f[:-2]
         t = f[-9:]
-        return f"conv_*_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{t[8]}{xp}"
+        return f"conv_*_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{t[8]}{sfx}"
     n = re.sub(r"\(.*", "", n)
     n = re.sub(r"^void ", "", n)
     return n[-60:]
+
+
+def _fingerprint():
+    """the kernel sources these counters were measured on (cvvae_amd._lib.source_fingerprint): bench.py compares it with the running tree"""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cvvae_amd import _lib
+    return _lib.source_fingerprint()
 
 
 def main(d, flt=None, json_out=None, sq_out=None, steps=0):
@@ -64,6 +77,7 @@ def main(d, flt=None, json_out=None, sq_out=None, steps=0):
         # whole-step HBM traffic (every kernel of the run, conv or not) when the number of profiled steps is known
         tot = sum((fe * 2 * 1024 + wr * 1024) * n for _, k, n, dur, fe, wr, *_ in rows if fe is not None and wr is not None)
         doc = json.load(open(json_out))
+        doc["library_source_fingerprint"] = _fingerprint()
         if steps:
             doc["steps_profiled"] = steps
             doc["step_total_bytes"] = round(tot / steps)
@@ -100,7 +114,7 @@ def main(d, flt=None, json_out=None, sq_out=None, steps=0):
             js[k[len("conv_*_"):] if k.startswith("conv_*_") else k] = e
         json.dump({"source": "rocprofv3 --pmc SQ_* passes of bench.py (separate from the traffic passes); mfma_busy = "
                              "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs), mean per dispatch",
-                   "kernels": js}, open(sq_out, "w"), indent=1)
+                   "library_source_fingerprint": _fingerprint(), "kernels": js}, open(sq_out, "w"), indent=1)
     fmt = lambda v, s: ("%" + s) % v if v is not None else " " * (int(s.split(".")[0]) - 1) + "-"
     for _, k, n, dur, fe, wr, hit, miss, ga, durg in sorted(rows, reverse=True):
         print(f"{k:58s} {n:5d} {dur:9.1f} {fmt(fe * 2 * 1024 / 1e9 if fe is not None else None, '9.3f')} "
