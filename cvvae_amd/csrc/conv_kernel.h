@@ -135,6 +135,7 @@ struct ConvArgs {
   int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
   int probe_nostore;  // probe builds (-DCVVAE_CONV_PROBE) only: run the store tail without its stores
   int stats_noshift;  // debug aid (CVVAE_STATS_NOSHIFT=1): fused statistics as plain sums (shift K = 0)
+  int ws_window;      // UPS == 2: weight-stationary window of the tile order (tile_map.h), 0 / 1 = off
   int phase_sync;     // 1: every wave multiplies chunk c, THEN stages chunk c+1 (no wave stages beside another's MFMA stream);
                       // 0: the two wave groups run opposite phase orders (X: stage -> MFMA, Y: MFMA -> stage)
 };
@@ -339,7 +340,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   // ---- XCD-aware, bijective block -> tile map (tile_map.h): each XCD (bid % 8) gets a contiguous run of logical tiles, so
   //      neighbouring halo tiles and all N-tiles of one M-tile share one L2; short (time-folded) tiles run last on every XCD
   const int logical = logical_tile_of_block((int)gridDim.x, (int)blockIdx.x, p.ntiles_n * (UPS == 2 ? 4 : 1), p.tiles_t,
-                                            p.t_short_lo, p.t_short_hi);
+                                            p.t_short_lo, p.t_short_hi, UPS == 2 ? p.ws_window : 0);
   // logical order: N-tile fastest (the N-tiles of one pixel tile re-use its halo from L2), then TIME, then x, y, b.
   // Time-adjacent tiles share 2 of their 3 halo frames; with time next-fastest they run at the same moment on CUs of
   // the same XCD, so the K-chunk passes over the halo stay inside that XCD's 4 MiB L2 instead of thrashing it.

@@ -387,6 +387,10 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   const long long grid = (long long)d->B * a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n * (fold ? 4 : 1);
   if (grid <= 0 || grid >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
   short_time_tiles(d, e->tt, e->kg, a, (fold ? 4 : 1));
+  if (fold) {  // weight-stationary windows of the folded upsample convs (tile_map.h); CVVAE_UPS_WINDOW: tuning aid
+    static const int env_win = getenv("CVVAE_UPS_WINDOW") ? atoi(getenv("CVVAE_UPS_WINDOW")) : 16;  // measured: 0 -> 8 -> 16: 6.20 / 6.03 / 5.99 ms (256 -> 512 @9x256^2)
+    a.ws_window = (a.ntiles_n * 4 >= 8) ? env_win : 0;
+  }
   rc = e->fn[d->dtype](a, (int)grid, (hipStream_t)stream);
   if (rc != 0 || !e2) return rc;
   // the last (odd) frame, one-frame tiles

@@ -20,12 +20,35 @@ namespace cvvae {
 //     share of part 2 (longest-processing-time-first: the launch tail is bounded by a short tile).  The XCD's workgroup count
 //     is fixed by the hardware, so its part-2 share is what remains after its part-1 share.  Requires part 2 to hold >= 8
 //     tiles (the host checks), which keeps every XCD's part-1 share within its workgroup count.
-CVVAE_HD int logical_tile_of_block(int nwg, int bid, int inner, int tiles_t, int short_lo, int short_hi) {
+//   * weight-stationary windows (win > 1; the folded upsample convs, whose `inner` = 4 phases x N-tiles weight sets of 1.5-3 MB each
+//     do not fit an XCD's 4 MiB L2 together): inside every run of `win` consecutive pixel tiles the PIXEL TILE is the fastest
+//     index and the weight set the next one -- the ~32 workgroups an XCD runs at a time cover `win` pixel tiles x 32/win weight
+//     sets instead of 2 x 16, so a weight set is fetched once per `win` pixel tiles instead of once per pixel tile, while the
+//     window's halos (win x ~0.35 MB) stay in L2.  split() turns a position inside a part into (pixel tile v, weight set w).
+CVVAE_HD void tile_split(int idx, int inner, int nv, int win, int& v, int& w) {
+  if (win <= 1) {
+    w = idx % inner;
+    v = idx / inner;
+    return;
+  }
+  const int g = idx / (win * inner), rr = idx - g * (win * inner);
+  const int first = g * win;
+  const int wc = nv - first < win ? nv - first : win;  // (the last window of a part may be short)
+  v = first + rr % wc;
+  w = rr / wc;
+}
+
+CVVAE_HD int logical_tile_of_block(int nwg, int bid, int inner, int tiles_t, int short_lo, int short_hi, int win = 0) {
   const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
   const int pre = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;  // logical tiles of the XCDs before mine
   const int j = bid >> 3;                                                 // my index inside my XCD's run
   const int ns = short_lo + short_hi;
-  if (ns <= 0) return pre + j;
+  if (ns <= 0) {
+    if (win <= 1) return pre + j;
+    int v, w;
+    tile_split(pre + j, inner, nwg / inner, win, v, w);
+    return v * inner + w;
+  }
   const int nsp = nwg / (inner * tiles_t);  // spatial tiles x batch
   const int tl = tiles_t - ns;
   const int size1 = nsp * tl * inner;
@@ -35,7 +58,8 @@ CVVAE_HD int logical_tile_of_block(int nwg, int bid, int inner, int tiles_t, int
   const bool part1 = j < n1;
   const int idx = part1 ? pre1 + j : (pre - pre1) + (j - n1);
   const int per = part1 ? tl : ns;
-  const int w = idx % inner, v = idx / inner;
+  int w, v;
+  tile_split(idx, inner, nsp * per, win, v, w);
   const int ts = v % per, sp = v / per;
   const int tt = part1 ? short_lo + ts : (ts < short_lo ? ts : tiles_t - short_hi + (ts - short_lo));
   return (sp * tiles_t + tt) * inner + w;

@@ -8,12 +8,12 @@
 
 #include "tile_map.h"
 
-static int check(int nsp, int tiles_t, int inner, int lo, int hi) {
+static int check(int nsp, int tiles_t, int inner, int lo, int hi, int win = 0) {
   const int nwg = nsp * tiles_t * inner;
   std::vector<char> seen(nwg, 0);
   std::vector<int> last_long(8, -1), first_short(8, 1 << 30);
   for (int bid = 0; bid < nwg; ++bid) {
-    const int l = cvvae::logical_tile_of_block(nwg, bid, inner, tiles_t, lo, hi);
+    const int l = cvvae::logical_tile_of_block(nwg, bid, inner, tiles_t, lo, hi, win);
     if (l < 0 || l >= nwg || seen[l]) {
       std::printf("not a bijection: nsp %d tiles_t %d inner %d lo %d hi %d: bid %d -> %d\n", nsp, tiles_t, inner, lo, hi, bid, l);
       return 1;
@@ -107,6 +107,31 @@ int main() {
             ++cases;
           }
       }
+  // weight-stationary windows (folded upsample convs): every window size against every grid, with and without short tiles;
+  // and inside a full window the pixel tile must be the fastest index
+  for (int win : {2, 4, 8, 16})
+    for (int inner : {4, 8, 16})
+      for (int tiles_t = 1; tiles_t <= 9; ++tiles_t)
+        for (int nsp = 1; nsp <= 40; ++nsp) {
+          if (check(nsp, tiles_t, inner, 0, 0, win)) return 1;
+          ++cases;
+          for (int lo = 0; lo <= 1; ++lo)
+            for (int hi = 0; hi <= 1; ++hi) {
+              if (lo + hi == 0 || lo + hi >= tiles_t || (long)nsp * (lo + hi) * inner < 8) continue;
+              if (check(nsp, tiles_t, inner, lo, hi, win)) return 1;
+              ++cases;
+            }
+        }
+  {
+    const int inner = 16, win = 8, nwg = 64 * inner;  // one XCD's run starts at a window boundary: positions 0..7 = 8 pixel tiles of set 0
+    for (int k = 0; k < 8; ++k) {
+      const int l = cvvae::logical_tile_of_block(nwg, k * 8, inner, 1, 0, 0, win);  // XCD 0, j = k
+      if (l % inner != 0 || l / inner != k) {
+        std::printf("window order wrong: j %d -> pixel tile %d set %d\n", k, l / inner, l % inner);
+        return 1;
+      }
+    }
+  }
   // the grids of BASELINE config 3 / 4 layers
   const int big[][5] = {{1024, 8, 1, 1, 0}, {256, 9, 1, 2, 0}, {256, 9, 8, 1, 1}, {64, 9, 2, 2, 0}, {16, 5, 2, 1, 1}, {1188, 8, 1, 1, 0}};
   for (auto& g : big) {
