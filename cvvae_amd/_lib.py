@@ -60,6 +60,7 @@ PROTOTYPES = {
     "cvvae_conv_fwd_gn": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "cvvae_conv_fwd_gn_sc": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "cvvae_gn_finalize": (_i32, [_vp, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "cvvae_gn_finalize_frames": (_i32, [_vp, _i32, _i32, _i64, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_gn_workspace_bytes": (ctypes.c_size_t, [_i32, _i32, _i64]),
     "cvvae_gn_stats": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_gn_silu_apply": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp]),

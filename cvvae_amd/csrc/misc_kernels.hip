@@ -399,11 +399,18 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restric
 // Finalize for the statistics fused into the conv epilogue: grid (G, rows); the block merges the `slabs` records of
 // its (row, group) -- ws[(row*G + g)*slabs + s] = (n, mean, M2), contiguous -- in a fixed order (thread-strided, then a Chan tree)
 // and writes the affine table of the group's channels.
-__global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __restrict__ ws, long long slabs, int G, int C,
+// frames > 1: per-FRAME statistics (the per-frame GroupNorm of the attention blocks) from the records of a per-frame producer
+// (kT = 1 convs: one-frame tiles in frame-major order): table row = sample * frames + frame, merging that frame's slabs / frames
+// consecutive records.
+__global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __restrict__ ws, long long slabs_total, int G, int C,
                                                                 float eps, const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta, float* __restrict__ scale,
-                                                                float* __restrict__ shift) {
-  const int g = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+                                                                float* __restrict__ shift, int frames) {
+  const int g = blockIdx.x, tid = threadIdx.x;
+  const int orow = blockIdx.y;                      // output table row
+  const int row = orow / frames, fr = orow - row * frames;
+  const long long slabs = slabs_total / frames;
+  const float* base = ws + (((long long)row * G + g) * slabs_total + (long long)fr * slabs) * 3;  // my (row, group, frame) records
   WStat acc = {0.f, 0.f, 0.f};
   // keep 8 independent loads in flight per thread and merge them in index order afterwards (the merge order, hence the
   // result, does not depend on the batching); a wave's loads cover 768 contiguous bytes
@@ -413,7 +420,7 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
     WStat q[U];
 #pragma unroll
     for (int i = 0; i < U; ++i) {
-      const float* o = ws + (((long long)row * G + g) * slabs + s + (long long)i * 256) * 3;
+      const float* o = base + (s + (long long)i * 256) * 3;
       q[i].n = o[0];
       q[i].mean = o[1];
       q[i].m2 = o[2];
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
     for (int i = 0; i < U; ++i) chan_merge(acc, q[i]);
   }
   for (; s < slabs; s += 256) {
-    const float* o = ws + (((long long)row * G + g) * slabs + s) * 3;
+    const float* o = base + s * 3;
     WStat q = {o[0], o[1], o[2]};
     chan_merge(acc, q);
   }
@@ -448,8 +455,8 @@ __global__ __launch_bounds__(256) void gn_finalize_slabs_kernel(const float* __r
   const int cpg = C / G;
   for (int c = g * cpg + tid; c < (g + 1) * cpg; c += 256) {
     const float sc = gamma[c] * rstd;
-    scale[(long long)row * C + c] = sc;
-    shift[(long long)row * C + c] = beta[c] - mean * sc;
+    scale[(long long)orow * C + c] = sc;
+    shift[(long long)orow * C + c] = beta[c] - mean * sc;
   }
 }
 
@@ -1325,10 +1332,16 @@ int cvvae_gn_silu_apply(int32_t dtype, const void* x, int32_t rows, int64_t S, i
 
 int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_t C, int32_t groups, float eps,
                       const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
-  if (!partials || !gamma || !beta || !scale || !shift || rows <= 0 || slabs <= 0 || groups <= 0 || C <= 0 || C % groups)
+  return cvvae_gn_finalize_frames(partials, rows, 1, slabs, C, groups, eps, gamma, beta, scale, shift, stream);
+}
+
+int cvvae_gn_finalize_frames(const float* partials, int32_t rows, int32_t frames, int64_t slabs, int32_t C, int32_t groups, float eps,
+                             const float* gamma, const float* beta, float* scale, float* shift, void* stream) {
+  if (!partials || !gamma || !beta || !scale || !shift || rows <= 0 || frames <= 0 || slabs <= 0 || slabs % frames || groups <= 0 ||
+      C <= 0 || C % groups)
     return CVVAE_EINVAL;
-  hipLaunchKernelGGL(gn_finalize_slabs_kernel, dim3(groups, rows), dim3(256), 0, (hipStream_t)stream, partials, (long long)slabs,
-                     groups, C, eps, gamma, beta, scale, shift);
+  hipLaunchKernelGGL(gn_finalize_slabs_kernel, dim3(groups, rows * frames), dim3(256), 0, (hipStream_t)stream, partials,
+                     (long long)slabs, groups, C, eps, gamma, beta, scale, shift, frames);
   CHECK_LAUNCH();
 }
 

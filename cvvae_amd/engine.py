@@ -130,12 +130,14 @@ class WeightCache:
         key = self._key(w, b)
         tag = f"{pre}#tapsn{'tf' if time_folds else ''}"
         hit = self._c.get(tag)
-        if hit is not None and hit[0] == key:
-            return hit[1], hit[3]
-        pw = ops.pack_weight_tapsn(w.detach(), time_folds=time_folds)
-        bias = b.detach().float().contiguous()
-        self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"), bias)
-        return pw, bias
+        if hit is None or hit[0] != key:
+            hit = (key, ops.pack_weight_tapsn(w.detach(), time_folds=time_folds), (pre + ".weight", pre + ".bias"))
+            self._c[tag] = hit
+        bhit = self._c.get(pre + "#f32bias")  # (its own entry: the packed-weight file carries packed weights only)
+        if bhit is None or bhit[0] != key:
+            bhit = (key, b.detach().float().contiguous())
+            self._c[pre + "#f32bias"] = bhit
+        return hit[1], bhit[1]
 
     def conv_t1(self, pre: str, mode: str, cin_pad: Optional[int] = None) -> ops.PackedConv:
         """3 x kH x kW weights as the single-frame (T = 1) input sees them: time taps summed ('sum') or centre tap ('center')."""
@@ -376,14 +378,19 @@ def _norm(wc: WeightCache, x: torch.Tensor, part, pre: str, eps: float):
 # single-head spatial self-attention per frame (both families)
 # --------------------------------------------------------------------------------------------------------
 def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: str, v: str, proj: str, eps: float,
-                      residual: bool, gn_out: int = 0, tape: Optional[list] = None):
+                      residual: bool, gn_out: int = 0, tape: Optional[list] = None, xp=None):
     """sd3: AttentionWithExtraDim (vae_blocks3d_sd3.py:119-147) over diffusers Attention.
     vae3d: MemoryEfficientAttnBlock.attention + proj_out (vae_models.py:500-537).
     Per frame: GN(32) over (C/32, H*W) -> q,k,v (1x1) -> softmax(q k^T / sqrt(C)) v -> proj (+ x)."""
     B, T, H, W, C = x.shape
     N = H * W
     gamma, beta = wc.norm(norm)
-    gn = ops.gn_stats(x, gamma, beta, eps, per_frame=True)           # rows = B*T
+    # rows = B*T: per-frame statistics -- merged from the producer's epilogue records when it was a per-frame conv over these
+    # frames (xp.frames: the ResnetBlock tail in front of the attention), else by a statistics pass over x
+    if xp is not None and getattr(xp, "frames", 0) == T and xp.slabs % T == 0 and per_frame_stats_from_records():
+        gn = ops.gn_finalize(xp, gamma, beta, eps, frames=T)
+    else:
+        gn = ops.gn_stats(x, gamma, beta, eps, per_frame=True)
     xf = x.view(B * T, 1, 1, N, C)                                    # frames as batch: GN row = frame
     qq = ops.conv(xf, wc.conv(q, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
     kk = ops.conv(xf, wc.conv(k, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
@@ -446,6 +453,12 @@ def decoder_conv_out(wc: WeightCache, h: torch.Tensor, g, pad, mode_t, mode_hw, 
     return ops.ncdhw_to_frames_u8(y) if u8 else y
 
 
+def per_frame_stats_from_records() -> bool:
+    """the attention blocks' per-frame GroupNorm statistics come from the records the preceding ResnetBlock tail already wrote
+    (cvvae_gn_finalize_frames) instead of a pass over the tensor.  CVVAE_FRAME_STATS_FROM_RECORDS=0: always the pass."""
+    return os.environ.get("CVVAE_FRAME_STATS_FROM_RECORDS", "1") != "0"
+
+
 def _encoder_input(x: torch.Tensor, cfg: dict, dtype: torch.dtype):
     """the encoder's NDHWC input, channel-padded for conv_in's K chunk: converted from the caller's NCDHW clip, or -- cfg
     "ndhwc_in" (the device-side pixel pre-processing, modeling.encode_frames_u8) -- the padded NDHWC clip as it arrives."""
@@ -475,11 +488,11 @@ def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, wan
 
 def sd3_mid(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, attention: bool):
     """UNetMidBlock3D.forward, vae_blocks3d_sd3.py:847-856."""
-    x, xp = sd3_resnet(wc, x, xp, pre + ".resnets.0", causal, want_stats=not attention)
+    x, xp = sd3_resnet(wc, x, xp, pre + ".resnets.0", causal)  # (its records also give the attention's per-frame statistics)
     if attention:
         a = pre + ".attentions.0"
         x, xp = spatial_attention(wc, x, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True,
-                                  gn_out=G32)
+                                  gn_out=G32, xp=xp)
     return sd3_resnet(wc, x, xp, pre + ".resnets.1", causal)
 
 
@@ -605,9 +618,9 @@ def ldm2d_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
         if lvl != nlev - 1:  # Downsample: F.pad (0,1,0,1) zeros, conv 3x3 stride 2 pad 0 (model.py:88-95)
             h, hp = ops.conv(h, wc.conv(f"down.{lvl}.downsample.conv", (1, 3, 3)), stride=(1, 2, 2), pad=((0, 0), (0, 1), (0, 1)),
                              pad_mode_hw=ZERO, gn_out=G32)
-    h, _ = c2d_resnet(wc, h, hp, "mid.block_1", want_stats=False, sc=".nin_shortcut")
+    h, hp = c2d_resnet(wc, h, hp, "mid.block_1", sc=".nin_shortcut")
     a = "mid.attn_1"
-    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32)
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32, xp=hp)
     h, hp = c2d_resnet(wc, h, hp, "mid.block_2", sc=".nin_shortcut")
     g = _norm(wc, h, hp, "norm_out", 1e-6)
     zc = wc.m.get_parameter("conv_out.weight").shape[0]
@@ -635,9 +648,9 @@ def ldm2d_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     else:
         h = _frames_in(z, 32, dtype)
     h, hp = ops.conv(h, wc.conv("conv_in", (1, 3, 3), cin_pad=32), pad=P2D, pad_mode_hw=ZERO, gn_out=G32)
-    h, _ = c2d_resnet(wc, h, hp, "mid.block_1", want_stats=False, sc=".nin_shortcut")
+    h, hp = c2d_resnet(wc, h, hp, "mid.block_1", sc=".nin_shortcut")
     a = "mid.attn_1"
-    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32)
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32, xp=hp)
     h, hp = c2d_resnet(wc, h, hp, "mid.block_2", sc=".nin_shortcut")
     for lvl in reversed(range(nlev)):
         for j in range(cfg["num_res_blocks"] + 1):
@@ -682,20 +695,20 @@ def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
             st = (2, 2, 2) if lvl % 2 == 0 else (1, 2, 2)
             h, hp = conv3(wc, h, f"down.{lvl}.downsample.conv", stride=st, pad=((2, 0), (0, 1), (0, 1)),
                              pad_mode_t=REP, pad_mode_hw=ZERO, gn_out=G32)
-    h, _ = v3_resnet(wc, h, hp, "mid.block_1", causal, want_stats=False)
+    h, hp = v3_resnet(wc, h, hp, "mid.block_1", causal)
     a = "mid.attn_1"
-    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True, gn_out=G32)
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True, gn_out=G32, xp=hp)
     h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
     return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
 
 
-def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str):
+def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str, xp=None):
     """MemoryEfficientAttnVideoBlock.forward, vae_models.py:619-629: spatial attention without residual, then over T
     per pixel: LayerNorm -> q_t,k_t,v_t -> attention -> proj_out_t; one residual.  Stays NDHWC throughout.
     Returns (out, GroupNorm partials of out)."""
-    h = spatial_attention(wc, x, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, False)
+    h = spatial_attention(wc, x, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, False, xp=xp)
     n = ops.layernorm(h, *wc.norm(a + ".norm_t"), 1e-5)
     q = conv1x1(wc, n, a + ".q_t")
     k = conv1x1(wc, n, a + ".k_t")
@@ -715,8 +728,8 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
     h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw,
                      gn_out=G32)
-    h, _ = v3_resnet(wc, h, hp, "mid.block_1", causal, want_stats=False)
-    h, hp = v3_attn_spatial_temporal(wc, h, "mid.attn_1")
+    h, hp = v3_resnet(wc, h, hp, "mid.block_1", causal)
+    h, hp = v3_attn_spatial_temporal(wc, h, "mid.attn_1", xp=hp)
     h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
     for lvl in reversed(range(nlev)):
         for j in range(cfg["num_res_blocks"] + 1):

@@ -209,6 +209,7 @@ class GNPartials:
     slabs: int
     C: int
     groups: int
+    frames: int = 0     # > 0: written by a per-frame conv (kT = 1) over this many frames: per-frame statistics can be merged from it
 
 
 def pack_weight_batched(w: torch.Tensor, k: Tuple[int, int, int], cin_pad: int, strides: Tuple[int, int, int], cout: int,
@@ -396,7 +397,8 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
         cst = cout // 2 if out_mode == L.OUT_TIME_SHUFFLE else cout
         # time-shuffle outputs: workgroups whose whole tile is the dropped frame exit without writing their records
         alloc = torch.zeros if out_mode == L.OUT_TIME_SHUFFLE else torch.empty
-        part = GNPartials(alloc((B, gn_out, slabs, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out)
+        part = GNPartials(alloc((B, gn_out, slabs, 3), dtype=torch.float32, device=x.device), B, int(slabs), cst, gn_out,
+                          frames=To if (kT == 1 and out_mode == L.OUT_NDHWC and not upsample2x) else 0)
 
     def launch():
         if shortcut is not None:
@@ -420,14 +422,17 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     return (out, part) if gn_out else out
 
 
-def gn_finalize(part: GNPartials, gamma: torch.Tensor, beta: torch.Tensor, eps: float) -> Tuple[torch.Tensor, torch.Tensor]:
-    """merge the conv-epilogue statistics into the (scale, shift) fp32 tables [rows, C] the next conv's prologue consumes"""
+def gn_finalize(part: GNPartials, gamma: torch.Tensor, beta: torch.Tensor, eps: float, frames: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """merge the conv-epilogue statistics into the (scale, shift) fp32 tables [rows, C] the next conv's prologue consumes.
+    frames > 1: per-FRAME tables [rows * frames, C] (row = sample * frames + frame) -- only for records of a per-frame conv (kT = 1)
+    over `frames` frames (part.frames says so)."""
     lib = L.load()
     assert gamma.dtype == torch.float32 and gamma.numel() == part.C and beta.numel() == part.C
-    scale = torch.empty((part.rows, part.C), dtype=torch.float32, device=part.buf.device)
-    shift = torch.empty((part.rows, part.C), dtype=torch.float32, device=part.buf.device)
-    L.check(lib.cvvae_gn_finalize(part.buf.data_ptr(), part.rows, part.slabs, part.C, part.groups, eps, gamma.data_ptr(),
-                                  beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream(part.buf)), "cvvae_gn_finalize")
+    assert frames == 1 or (part.frames == frames and part.slabs % frames == 0), "per-frame statistics need a per-frame producer"
+    scale = torch.empty((part.rows * frames, part.C), dtype=torch.float32, device=part.buf.device)
+    shift = torch.empty((part.rows * frames, part.C), dtype=torch.float32, device=part.buf.device)
+    L.check(lib.cvvae_gn_finalize_frames(part.buf.data_ptr(), part.rows, frames, part.slabs, part.C, part.groups, eps, gamma.data_ptr(),
+                                         beta.data_ptr(), scale.data_ptr(), shift.data_ptr(), _stream(part.buf)), "cvvae_gn_finalize_frames")
     return scale, shift
 
 

@@ -214,6 +214,11 @@ int cvvae_ndhwc_to_rowpack(int32_t dtype, const void* in, int32_t B, int32_t C, 
                            int32_t pad_mode_w, void* out, void* stream);
 int cvvae_gn_finalize(const float* partials, int32_t rows, int64_t slabs, int32_t C, int32_t groups, float eps,
                       const float* gamma, const float* beta, float* scale, float* shift, void* stream);
+/* Per-FRAME statistics from the same records (the per-frame GroupNorm of the attention blocks, models/vae_blocks3d_sd3.py:119-147,
+ * vae_models.py:500-537): valid when the records come from a per-frame convolution (kT = 1: one-frame tiles, frame-major record
+ * order) over `frames` frames; slabs % frames == 0.  Tables [rows * frames][C]: row = sample * frames + frame. */
+int cvvae_gn_finalize_frames(const float* partials, int32_t rows, int32_t frames, int64_t slabs, int32_t C, int32_t groups, float eps,
+                             const float* gamma, const float* beta, float* scale, float* shift, void* stream);
 
 /*
  * GroupNorm statistics -> per-(row, channel) affine table consumed by the conv prologue.

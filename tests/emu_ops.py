@@ -37,6 +37,8 @@ class FakePart:
     rows: int
     C: int
     groups: int
+    frames: int = 0
+    slabs: int = 0
 
 
 def _bias(cout, bias, dev):
@@ -164,8 +166,10 @@ def gn_stats(x, gamma, beta, eps, groups=32, per_frame=False):
     return _tables(x, gamma, beta, eps, groups, per_frame)
 
 
-def gn_finalize(part, gamma, beta, eps):
-    return _tables(part.x, gamma, beta, eps, part.groups, False)
+def gn_finalize(part, gamma, beta, eps, frames=1):
+    if frames > 1:
+        assert part.frames == frames
+    return _tables(part.x, gamma, beta, eps, part.groups, frames > 1)
 
 
 def _pad3(f, pad, mode_t, mode_hw):
@@ -230,7 +234,8 @@ def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.
         res = torch.zeros(*y.shape[:-1], cp, dtype=odt)
         res[..., :pw.cout] = y.to(odt)
     if gn_out:
-        return res, FakePart(res, B, cst, gn_out)
+        kt1 = pw.k[0] == 1 and out_mode == L.OUT_NDHWC and not upsample2x
+        return res, FakePart(res, B, cst, gn_out, frames=res.shape[1] if kt1 else 0, slabs=res.shape[1] * 4 if kt1 else 0)
     return res
 
 

@@ -233,3 +233,26 @@ def test_ldm_2d_wrappers_golden(name, dtype, golden_dir):
     tol_max, tol_mean = {torch.float32: (1e-4, 1e-5), torch.float16: (8e-3, 1.2e-3), torch.bfloat16: (6e-2, 9e-3)}[dtype]
     print(f"\n{name} {dtype}: max|d| {err.max():.3e} mean|d| {err.mean():.3e} (range {np.abs(gold).max():.2f})")
     assert err.max() <= tol_max * max(1.0, float(np.abs(gold).max())) and err.mean() <= tol_mean
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
+def test_per_frame_statistics_from_producer_records(dtype):
+    """the attention blocks' per-frame GroupNorm tables merged from the records of the per-frame conv in front of them
+    (cvvae_gn_finalize_frames) equal the statistics pass over the stored tensor"""
+    ops, L = _ops()
+    g = torch.Generator().manual_seed(3)
+    B, T, H, W, C = 2, 5, 24, 40, 256
+    x = torch.randn((B, T, H, W, C), generator=g).to(dtype).to(DEV)
+    res = (torch.randn((B, T, H, W, C), generator=g) + 3.0).to(dtype).to(DEV)
+    w = (torch.randn((C, C, 9), generator=g) / 48.0).to(dtype).to(DEV)
+    pw = ops.pack_weight(w, torch.zeros(C, device=DEV), (1, 3, 3))
+    y, part = ops.conv(x, pw, pad=((0, 0), (1, 1), (1, 1)), residual=res, gn_out=32)
+    assert part.frames == T
+    gamma, beta = (1.0 + 0.1 * torch.randn(C, generator=g)).to(DEV), (0.1 * torch.randn(C, generator=g)).to(DEV)
+    a = ops.gn_finalize(part, gamma, beta, 1e-6, frames=T)
+    b = ops.gn_stats(y, gamma, beta, 1e-6, per_frame=True)
+    assert tuple(a[0].shape) == (B * T, C)
+    assert torch.allclose(a[0], b[0], rtol=3e-4) and torch.allclose(a[1], b[1], rtol=3e-4, atol=3e-4)
+    # and the per-sample merge of the same records is unchanged
+    a1, b1 = ops.gn_finalize(part, gamma, beta, 1e-6), ops.gn_stats(y, gamma, beta, 1e-6)
+    assert torch.allclose(a1[0], b1[0], rtol=3e-4) and torch.allclose(a1[1], b1[1], rtol=3e-4, atol=3e-4)
