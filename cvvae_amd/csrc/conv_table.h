@@ -50,6 +50,8 @@
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
   X(1,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
 // (the 64-pixel tile also with 32-channel K-chunks: the 128-pixel one would need 2 x 134 KiB of LDS)
+// (Cout = 128 -- the first downsampler -- leaves half of the BN = 256 instances' waves without channels; 128-pixel tiles as 2 pixel
+//  slabs x 4 N-blocks, two-frame or 8-row, with every wave busy were measured in round 3 and are SLOWER: 0.90-0.92 vs 0.85 ms)
 #define CVVAE_CONV_G5(X) \
   X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 1, 0,0) \
