@@ -1,0 +1,40 @@
+"""stress of the 4-wave per-frame conv's fused GroupNorm records under co-residency: N repetitions at the cfg-3 layer size, records
+compared bit for bit with the first run and with the 8-wave instance's finalized tables"""
+import os, sys
+sys.path.insert(0, os.getcwd())
+import torch
+from cvvae_amd import ops
+torch.manual_seed(0)
+dt = torch.bfloat16
+N = int(os.environ.get("REPS", "100"))
+x = torch.randn((1, 17, 512, 512, 128), device="cuda").to(dt)
+res = (torch.randn((1, 17, 512, 512, 128), device="cuda") + 2.0).to(dt)
+gsc = (1 + 0.1 * torch.randn((1, 128), device="cuda")); gsh = 0.1 * torch.randn((1, 128), device="cuda")
+w = (torch.randn((128, 128, 9), device="cuda") / (128 * 9) ** 0.5).to(dt)
+pw = ops.pack_weight(w, torch.randn(128, device="cuda"), (1, 3, 3))
+kw = dict(pad=((0, 0), (1, 1), (1, 1)), prologue=1, gn=(gsc, gsh), residual=res, gn_out=32)
+def run(force):
+    os.environ["CVVAE_CONV_FORCE"] = force
+    names = []
+    ops.PROFILE = lambda d, p, l: (names.append(ops.conv_kernel_name(d)), l())
+    y, part = ops.conv(x, pw, **kw)
+    ops.PROFILE = None
+    torch.cuda.synchronize()
+    return y, part, names[-1]
+y8, p8, n8 = run("1x16x32:2x4x1:2")
+ones, zeros = torch.ones(128, device="cuda"), torch.zeros(128, device="cuda")
+t8 = ops.gn_finalize(p8, ones, zeros, 1e-6)
+y4, p4, n4 = run("1x8x32:1x4x1:2")
+print(n8, "|", n4, flush=True)
+first = p4.buf.clone()
+bad_runs, bad_records, worst = 0, 0, 0.0
+for i in range(N):
+    y, p, _ = run("1x8x32:1x4x1:2")
+    d = (p.buf != first)
+    nb = int(d.any(-1).sum())
+    t4 = ops.gn_finalize(p, ones, zeros, 1e-6)
+    worst = max(worst, float((t4[1] - t8[1]).abs().max()))
+    if nb or not torch.equal(y, y4):
+        bad_runs += 1; bad_records += nb
+print(f"reps {N}: runs with differing records {bad_runs}, differing records {bad_records} of {first.numel() // 3} per run, "
+      f"worst |shift(4-wave) - shift(8-wave)| {worst:.3e}", flush=True)
