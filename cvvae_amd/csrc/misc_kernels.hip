@@ -1037,6 +1037,27 @@ __global__ __launch_bounds__(256) void ncdhw_to_frames_u8_kernel(const T* __rest
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// one axis of the uint8 antialiased bilinear frame resize (include/cvvae.h cvvae_resize_u8_axis)
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void resize_u8_axis_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, long long n_out,
+                                                             int in_size, int out_size, long long inner,
+                                                             const int* __restrict__ xmin, const int* __restrict__ xsize,
+                                                             const int* __restrict__ w, int ksize, int precision) {
+  const long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // over outer * out_size * inner
+  if (e >= n_out) return;
+  const long long r = e % inner, q = e / inner;
+  const int i = (int)(q % out_size);
+  const long long o = q / out_size;
+  const uint8_t* src = in + (o * in_size + xmin[i]) * inner + r;
+  const int* wi = w + (long long)i * ksize;
+  int acc = 1 << (precision - 1);
+  const int n = xsize[i];
+  for (int j = 0; j < n; ++j) acc += wi[j] * (int)src[(long long)j * inner];
+  acc >>= precision;
+  out[e] = (uint8_t)(acc < 0 ? 0 : (acc > 255 ? 255 : acc));
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // the last layer's spatial taps, gathered from the (3,1,1) conv's per-input-pixel columns (include/cvvae.h cvvae_conv_out_gather)
 // ---------------------------------------------------------------------------------------------------------
 template <typename T, int CO>
@@ -1622,6 +1643,18 @@ int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t
                        frames);
   else
     return CVVAE_EINVAL;
+  CHECK_LAUNCH();
+}
+
+int cvvae_resize_u8_axis(const uint8_t* in, uint8_t* out, int64_t outer, int32_t in_size, int32_t out_size, int64_t inner,
+                         const int32_t* xmin, const int32_t* xsize, const int32_t* w, int32_t ksize, int32_t precision, void* stream) {
+  if (!in || !out || !xmin || !xsize || !w || outer <= 0 || in_size <= 0 || out_size <= 0 || inner <= 0 || ksize <= 0 || precision < 1 ||
+      precision > 22)
+    return CVVAE_EINVAL;
+  const long long n = (long long)outer * out_size * inner;
+  if (n >= (1LL << 31) * 256) return CVVAE_EUNSUPPORTED;
+  hipLaunchKernelGGL(resize_u8_axis_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, in, out, n, in_size, out_size,
+                     (long long)inner, xmin, xsize, w, ksize, precision);
   CHECK_LAUNCH();
 }
 

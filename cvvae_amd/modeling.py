@@ -710,12 +710,15 @@ class _CVVAEBase(nn.Module):
 
     # ---- device-side pixel pre/post-processing of the inference scripts ------------------------
     @torch.no_grad()
-    def encode_frames_u8(self, frames: torch.Tensor, return_dict: bool = True):
+    def encode_frames_u8(self, frames: torch.Tensor, return_dict: bool = True, size: Optional[Tuple[int, int]] = None):
         """frames: uint8 [T,H,W,3] on the device (decord's layout).  Equivalent to the scripts' host-side
         `rearrange -> .half() -> / 127.5 - 1.0 -> [:, :, :frame_end]` (cvvae_inference_video.py:24-38) followed by
         `encode`; the normalisation runs on the MI355X in the model's dtype with the scripts' rounding steps."""
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3:
             raise ValueError(f"expected uint8 frames [T,H,W,3], got {frames.dtype} {tuple(frames.shape)}")
+        if size is not None:  # the scripts' transforms.Resize(size=(height, width)) on the uint8 clip (:14-16, 28), on the device
+            with torch.cuda.device(frames.device):
+                frames = ops.resize_frames_u8(frames.contiguous(), size)
         T = frames.shape[0]
         frame_end = 1 + (T - 1) // 4 * 4
         # the NDHWC clip, channel-padded for conv_in's K chunk (32 on the single-frame fold path), goes to the encoder as it is:

@@ -620,6 +620,66 @@ def blend_(a: torch.Tensor, b: torch.Tensor, overlap: int, axis: int) -> torch.T
     return b
 
 
+def resize_tables(in_size: int, out_size: int):
+    """Tables of ONE axis of torch's antialiased bilinear interpolation of uint8 tensors (what `transforms.Resize` runs on the scripts'
+    uint8 clip, cvvae_inference_video.py:14-16,28): per output position the first input position, the tap count and the int16-scaled
+    triangle-filter weights, and the weights' precision.  Plain Python (host logic; CPU-tested bit for bit against
+    F.interpolate(uint8, mode="bilinear", antialias=True), tests/test_host_logic.py) -> (xmin, xsize, weights [out, ksize], ksize, precision)."""
+    import math
+    scale = in_size / out_size
+    support = scale if scale >= 1.0 else 1.0
+    invscale = 1.0 / scale if scale >= 1.0 else 1.0
+    ksize = int(math.ceil(support)) * 2 + 1
+    xmin, xsize, wf = [], [], []
+    for i in range(out_size):
+        center = scale * (i + 0.5)
+        lo = max(0, int(center - support + 0.5))
+        hi = min(in_size, int(center + support + 0.5))
+        ws = [max(0.0, 1.0 - abs((j + lo - center + 0.5) * invscale)) for j in range(hi - lo)]
+        tot = sum(ws)
+        xmin.append(lo)
+        xsize.append(hi - lo)
+        wf.append([v / tot for v in ws] + [0.0] * (ksize - (hi - lo)))
+    mx = max(max(r) for r in wf)
+    prec = 0
+    while prec < 22 and int(0.5 + mx * (1 << (prec + 1))) < (1 << 15):
+        prec += 1
+    wi = [[int(0.5 + v * (1 << prec)) for v in r] for r in wf]  # (triangle weights are never negative)
+    return xmin, xsize, wi, ksize, prec
+
+
+def resize_frames_u8(frames: torch.Tensor, size: Tuple[int, int]) -> torch.Tensor:
+    """uint8 frames [T,H,W,C] -> [T,size[0],size[1],C]: the scripts' `transforms.Resize(size=(height, width))` (antialiased bilinear on
+    uint8, width pass then height pass, fixed-point weights) on the device; bit-exact against torch's CPU kernel."""
+    lib = L.load()
+    _need_gpu(frames)
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.is_contiguous()
+    T, H, W, C = frames.shape
+    oh, ow = int(size[0]), int(size[1])
+    cur = frames
+    for axis, (n_in, n_out) in ((2, (W, ow)), (1, (H, oh))):
+        if n_in == n_out:
+            continue
+        xmin, xsize, wi, ksize, prec = resize_tables(n_in, n_out)
+        dev = frames.device
+        t_xmin = torch.tensor(xmin, dtype=torch.int32, device=dev)
+        t_xsize = torch.tensor(xsize, dtype=torch.int32, device=dev)
+        t_w = torch.tensor(wi, dtype=torch.int32, device=dev).contiguous()
+        shp = list(cur.shape)
+        outer = 1
+        for d in shp[:axis]:
+            outer *= d
+        inner = 1
+        for d in shp[axis + 1:]:
+            inner *= d
+        shp[axis] = n_out
+        out = torch.empty(shp, dtype=torch.uint8, device=dev)
+        L.check(lib.cvvae_resize_u8_axis(cur.data_ptr(), out.data_ptr(), outer, n_in, n_out, inner, t_xmin.data_ptr(), t_xsize.data_ptr(),
+                                         t_w.data_ptr(), ksize, prec, _stream(frames)), "cvvae_resize_u8_axis")
+        cur = out
+    return cur
+
+
 def frames_u8_to_ndhwc(frames: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
     """uint8 frames [T,H,W,3] -> [1,T,H,W,cpad] dtype = u8/127.5 - 1 (the scripts' normalisation, in dtype arithmetic)."""
     lib = L.load()

@@ -209,6 +209,16 @@ int cvvae_ncdhw_to_rowpack(int32_t src_dtype, int32_t dst_dtype, const void* in,
  */
 int cvvae_conv_out_gather(int32_t dtype, const float* V, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Cout, int64_t ldv,
                           const float* bias, int32_t pad_mode_hw, void* out_ncdhw, uint8_t* out_u8, void* stream);
+/*
+ * One axis of the scripts' frame resize (`transforms.Resize(size=(height, width))` on the uint8 clip, cvvae_inference_video.py:14-16,28
+ * = torch's antialiased bilinear interpolation of uint8 tensors): fixed-point triangle filter
+ *   out[o][i][r] = clip_u8( ( (1 << (precision-1)) + sum_{j < xsize[i]} w[i*ksize + j] * in[o][xmin[i] + j][r] ) >> precision )
+ * over a tensor viewed as [outer][in_size][inner] -> [outer][out_size][inner] (frames 't h w c': width pass inner = C, height pass
+ * inner = W*C).  xmin / xsize / w (int32, device) and `precision` are the tables of that interpolation (cvvae_amd/ops.py
+ * resize_tables: the filter support, the int16 weight scale and the rounding follow ATen's uint8 kernel, horizontal pass first).
+ */
+int cvvae_resize_u8_axis(const uint8_t* in, uint8_t* out, int64_t outer, int32_t in_size, int32_t out_size, int64_t inner,
+                         const int32_t* xmin, const int32_t* xsize, const int32_t* w, int32_t ksize, int32_t precision, void* stream);
 /* the same from an NDHWC tensor [B,T,H,W] of `dtype` with pixel stride pix_stride (>= C) elements: its first C (<= 4) channels */
 int cvvae_ndhwc_to_rowpack(int32_t dtype, const void* in, int32_t B, int32_t C, int32_t T, int32_t H, int32_t W, int64_t pix_stride,
                            int32_t pad_mode_w, void* out, void* stream);

@@ -270,6 +270,11 @@ def frames_u8_to_ndhwc(frames, cpad, dtype):
     return out
 
 
+def resize_frames_u8(frames, size):
+    """[T,H,W,C] uint8 -> [T,oh,ow,C]: torch's own uint8 antialiased bilinear kernel (what transforms.Resize runs)"""
+    return F.interpolate(frames.permute(0, 3, 1, 2), size=tuple(size), mode="bilinear", antialias=True).permute(0, 2, 3, 1).contiguous()
+
+
 def ncdhw_to_frames_u8(x):
     """[1,3,T,H,W] -> uint8 [T,H,W,3] = u8((clamp(x, -1, 1) + 1) * 127.5) (cvvae_inference_video.py:47-50)"""
     return ((torch.clamp(x[0], -1.0, 1.0) + 1.0) * 127.5).to(torch.uint8).permute(1, 2, 3, 0).contiguous()
@@ -341,7 +346,7 @@ def upsample2x_sum(g):
 
 _NAMES = ["ncdhw_to_rowpack", "ndhwc_to_rowpack", "pack_weight_rowpack", "pack_weight_tapsn", "conv_out_gather", "pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
           "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "temporal_attention", "ncdhw_to_ndhwc",
-          "ndhwc_to_ncdhw", "blend_", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
+          "ndhwc_to_ncdhw", "blend_", "resize_frames_u8", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
 
 
 @contextlib.contextmanager

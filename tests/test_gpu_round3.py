@@ -256,3 +256,32 @@ def test_per_frame_statistics_from_producer_records(dtype):
     # and the per-sample merge of the same records is unchanged
     a1, b1 = ops.gn_finalize(part, gamma, beta, 1e-6), ops.gn_stats(y, gamma, beta, 1e-6)
     assert torch.allclose(a1[0], b1[0], rtol=3e-4) and torch.allclose(a1[1], b1[1], rtol=3e-4, atol=3e-4)
+
+
+@pytest.mark.parametrize("shape", [(3, 40, 64, 24, 40), (2, 37, 53, 64, 96), (2, 48, 80, 48, 50), (1, 270, 480, 144, 256), (5, 1080, 1920, 576, 1024)])
+def test_device_resize_matches_torch_uint8_antialiased_bilinear(shape):
+    """f1: the scripts' transforms.Resize(size=(height, width)) on the uint8 clip (cvvae_inference_video.py:14-16,28) on the device
+    (cvvae_resize_u8_axis, two passes), bit for bit against torch's CPU kernel -- including the script's default 576 x 1024 from 1080p"""
+    import torch.nn.functional as F
+    ops, L = _ops()
+    T, H, W, oh, ow = shape
+    frames = torch.randint(0, 256, (T, H, W, 3), generator=torch.Generator().manual_seed(T * H), dtype=torch.uint8)
+    ref = F.interpolate(frames.permute(0, 3, 1, 2), size=(oh, ow), mode="bilinear", antialias=True).permute(0, 2, 3, 1)
+    got = ops.resize_frames_u8(frames.to(DEV), (oh, ow)).cpu()
+    assert got.shape == ref.shape and torch.equal(got, ref)
+
+
+def test_encode_frames_u8_with_resize_equals_script_ops():
+    """encode_frames_u8(frames, size=...) == the script: Resize on uint8 -> .half()/127.5-1 -> encode"""
+    import torch.nn.functional as F
+    import cvvae_amd
+    from oracle import parity as P
+    m = cvvae_amd.CVVAESD3Model()
+    P.load_seeded(m, 0)
+    m = m.to(torch.float16).cuda().eval()
+    frames = torch.randint(0, 256, (5, 90, 120, 3), generator=torch.Generator().manual_seed(4), dtype=torch.uint8)
+    video = F.interpolate(frames.permute(0, 3, 1, 2), size=(64, 96), mode="bilinear", antialias=True)           # 't c h w' uint8
+    video = video.permute(1, 0, 2, 3).unsqueeze(0).half() / 127.5 - 1.0                                         # the script's ops
+    a = m.encode(video.cuda()).latent_dist.mode()
+    b = m.encode_frames_u8(frames.cuda(), size=(64, 96)).latent_dist.mode()
+    assert torch.equal(a, b)

@@ -162,3 +162,29 @@ def test_posterior():
     assert d.logvar.max() <= 20 and d.logvar.min() >= -30
     g1, g2 = torch.Generator().manual_seed(7), torch.Generator().manual_seed(7)
     assert torch.equal(d.sample(generator=g1), d.mean + d.std * torch.randn(d.mean.shape, generator=g2))
+
+
+@pytest.mark.parametrize("shape", [(40, 64, 24, 40), (37, 53, 64, 96), (48, 80, 48, 50), (30, 30, 7, 11), (20, 36, 33, 20), (270, 480, 144, 256)])
+def test_resize_tables_reproduce_torch_uint8_antialiased_bilinear(shape):
+    """ops.resize_tables (the host side of cvvae_resize_u8_axis: filter support, int16 weight scale, rounding) applied in plain integer
+    arithmetic -- width pass, then height pass, as the kernel does -- equals F.interpolate(uint8, mode='bilinear', antialias=True),
+    i.e. what the scripts' transforms.Resize computes on the uint8 clip (cvvae_inference_video.py:14-16,28), bit for bit"""
+    from cvvae_amd import ops
+    H, W, oh, ow = shape
+    x = torch.randint(0, 256, (2, 3, H, W), generator=torch.Generator().manual_seed(H * W), dtype=torch.uint8)
+    ref = F.interpolate(x, size=(oh, ow), mode="bilinear", antialias=True)
+    cur = x.long()
+    for axis, (ni, no) in ((3, (W, ow)), (2, (H, oh))):
+        if ni == no:
+            continue
+        xmin, xsize, wi, ks, prec = ops.resize_tables(ni, no)
+        assert all(len(r) == ks for r in wi) and 1 <= prec <= 22
+        cur = cur.movedim(axis, -1)
+        out = torch.zeros(cur.shape[:-1] + (no,), dtype=torch.long)
+        for i in range(no):
+            acc = torch.full(cur.shape[:-1], 1 << (prec - 1), dtype=torch.long)
+            for j in range(xsize[i]):
+                acc += wi[i][j] * cur[..., xmin[i] + j]
+            out[..., i] = (acc >> prec).clamp(0, 255)
+        cur = out.movedim(-1, axis)
+    assert torch.equal(cur, ref.long())
