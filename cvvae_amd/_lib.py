@@ -75,6 +75,7 @@ PROTOTYPES = {
     "cvvae_ncdhw_to_ndhwc": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_ncdhw_to_rowpack": (_i32, [_i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_conv_out_gather": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
+    "cvvae_attention_d512": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _f32, _vp]),
     "cvvae_resize_u8_axis": (_i32, [_vp, _vp, _i64, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _vp]),
     "cvvae_ndhwc_to_rowpack": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _i32, _vp, _vp]),
     "cvvae_ndhwc_to_ncdhw": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i64, _vp, _vp]),

@@ -395,18 +395,28 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
     qq = ops.conv(xf, wc.conv(q, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
     kk = ops.conv(xf, wc.conv(k, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
     vv = ops.conv(xf, wc.conv(v, (1, 1, 1)), prologue=L.PRO_GN, gn=gn)
-    npad = ops.round_up(N, 128)
-    vt = ops.transpose(vv.view(B * T, N, C))                          # [BT, C, N]
     scale = float(C) ** -0.5
-    # every frame's K (and V^T) is a weight matrix of its own: packed in one launch, consumed by ONE batched conv launch
-    # (cvvae_conv_desc.w_batch_stride) -- QK^T with fp32 scores, softmax, PV
-    kp = ops.pack_weight_batched(kk.view(B * T, N, C), (1, 1, 1), cin_pad=C, strides=(C, 1, 0), cout=N, cin=C)
-    s = ops.conv(qq, kp, out_f32=True, alpha=scale, cout_pad=npad)                              # [BT,1,1,N,npad] fp32
-    p = ops.softmax_rows(s.view(B * T * N, npad), N, x.dtype)                                  # [BT*N, npad]
-    vp = ops.pack_weight_batched(vt, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
-    o = ops.conv(p.view(B * T, 1, 1, N, npad), vp)                                             # [BT,1,1,N,C]
-    if tape is not None:  # what the input-gradient pass (grad.py) needs again
-        tape.append(dict(op="attn", x=x, qq=qq, kk=kk, vv=vv, p=p, names=(norm, q, k, v, proj), eps=eps, residual=residual))
+    fused = fused_attention() and C == 512 and x.dtype in (torch.float16, torch.bfloat16)
+    o = None
+    if fused:
+        # one launch: S = Q K^T, softmax, O = P V (csrc/attention_kernel.hip); scores and probabilities never reach HBM
+        vt = ops.transpose(vv.view(B * T, N, C), ld_out=ops.round_up(N, 32))        # [BT, C, ldvt], zero padded
+        o = ops.attention_d512(qq.view(B * T, N, C), kk.view(B * T, N, C), vt, N, scale)
+    if o is None or tape is not None:
+        # the five-launch form: every frame's K (and V^T) is a weight matrix of its own, packed in one launch and consumed by ONE
+        # batched conv launch (cvvae_conv_desc.w_batch_stride) -- QK^T with fp32 scores, softmax, PV.  It is the forward of fp32
+        # models, and it supplies the probabilities the input-gradient pass reads again (tape): a taped pass of a 16-bit model takes
+        # its OUTPUT from the fused launch above, so that it equals the inference pass bit for bit
+        npad = ops.round_up(N, 128)
+        kp = ops.pack_weight_batched(kk.view(B * T, N, C), (1, 1, 1), cin_pad=C, strides=(C, 1, 0), cout=N, cin=C)
+        s = ops.conv(qq, kp, out_f32=True, alpha=scale, cout_pad=npad)                              # [BT,1,1,N,npad] fp32
+        p = ops.softmax_rows(s.view(B * T * N, npad), N, x.dtype)                                  # [BT*N, npad]
+        if o is None:
+            vt = ops.transpose(vv.view(B * T, N, C))                                               # [BT, C, N]
+            vp = ops.pack_weight_batched(vt, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
+            o = ops.conv(p.view(B * T, 1, 1, N, npad), vp)                                         # [BT,1,1,N,C]
+        if tape is not None:  # what the input-gradient pass (grad.py) needs again
+            tape.append(dict(op="attn", x=x, qq=qq, kk=kk, vv=vv, p=p, names=(norm, q, k, v, proj), eps=eps, residual=residual))
     return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 
@@ -451,6 +461,13 @@ def decoder_conv_out(wc: WeightCache, h: torch.Tensor, g, pad, mode_t, mode_hw, 
         return ops.conv_out_gather(v, w.shape[0], bias, mode_hw, h.dtype, u8=u8)
     y = conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
     return ops.ncdhw_to_frames_u8(y) if u8 else y
+
+
+def fused_attention() -> bool:
+    """the attention core (QK^T, softmax, PV) of 16-bit models with 512 channels as one launch (cvvae_attention_d512) instead of
+    pack K / QK^T with fp32 scores / row softmax / pack V^T / PV.  CVVAE_FUSED_ATTENTION=0: the five-launch form (also what fp32
+    models and the input-gradient tape use)."""
+    return os.environ.get("CVVAE_FUSED_ATTENTION", "1") != "0"
 
 
 def per_frame_stats_from_records() -> bool:

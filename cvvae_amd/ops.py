@@ -571,6 +571,19 @@ def upsample2x_sum(g: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def attention_d512(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, n: int, scale: float) -> torch.Tensor:
+    """softmax(q k^T * scale) v per batch item in ONE launch (cvvae_attention_d512): q, k [batch, N, 512] fp16 / bf16 (contiguous),
+    vt = transpose(v, ld_out=round_up(N, 32)) [batch, 512, ldvt] with zero padding -> [batch, N, 512]."""
+    lib = L.load()
+    _need_gpu(q)
+    assert q.dim() == 3 and q.shape[-1] == 512 and q.shape == k.shape and q.is_contiguous() and k.is_contiguous() and vt.is_contiguous()
+    assert vt.shape[0] == q.shape[0] and vt.shape[1] == 512 and vt.shape[2] >= round_up(n, 32) and q.shape[1] == n
+    out = torch.empty_like(q)
+    L.check(lib.cvvae_attention_d512(_dt(q.dtype), q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), q.shape[0], n, vt.shape[2],
+                                     float(scale), _stream(q)), "cvvae_attention_d512")
+    return out
+
+
 def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
     """q,k,v: NDHWC [B,T,H,W,C] -> softmax(q k^T / sqrt(C)) v over the T frames of every pixel (T <= 8)."""
     lib = L.load()

@@ -210,6 +210,16 @@ int cvvae_ncdhw_to_rowpack(int32_t src_dtype, int32_t dst_dtype, const void* in,
 int cvvae_conv_out_gather(int32_t dtype, const float* V, int32_t B, int32_t T, int32_t H, int32_t W, int32_t Cout, int64_t ldv,
                           const float* bias, int32_t pad_mode_hw, void* out_ncdhw, uint8_t* out_u8, void* stream);
 /*
+ * Fused single-head attention core, head dimension 512 (csrc/attention_kernel.hip):  o = softmax(q k^T * scale) v  per batch item
+ * (= frame).  Replaces F.scaled_dot_product_attention of diffusers' AttnProcessor2_0 under AttentionWithExtraDim
+ * (models/vae_blocks3d_sd3.py:119-147) and xformers.ops.memory_efficient_attention (models/vae_models.py:518-520, 581-583).
+ * q, k, o: [batch][N][512] of `dtype` (fp16 / bf16); vt: the TRANSPOSED values [batch][512][ldvt] (cvvae_transpose), ldvt >= N rounded
+ * up to 32 and a multiple of 8, columns >= N zero.  fp32 accumulation, online softmax; probabilities rounded to `dtype` before the
+ * second product (as the two-launch form did).
+ */
+int cvvae_attention_d512(int32_t dtype, const void* q, const void* k, const void* vt, void* o, int32_t batch, int32_t N,
+                         int64_t ldvt, float scale, void* stream);
+/*
  * One axis of the scripts' frame resize (`transforms.Resize(size=(height, width))` on the uint8 clip, cvvae_inference_video.py:14-16,28
  * = torch's antialiased bilinear interpolation of uint8 tensors): fixed-point triangle filter
  *   out[o][i][r] = clip_u8( ( (1 << (precision-1)) + sum_{j < xsize[i]} w[i*ksize + j] * in[o][xmin[i] + j][r] ) >> precision )

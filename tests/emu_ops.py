@@ -251,6 +251,13 @@ def layernorm(x, gamma, beta, eps):
     return F.layer_norm(x.float(), (x.shape[-1],), gamma, beta, eps).to(x.dtype)
 
 
+def attention_d512(q, k, vt, n, scale):
+    """softmax(q k^T * scale) v per batch item; probabilities rounded to the storage dtype before the second product"""
+    s = torch.einsum("bnd,bmd->bnm", q.float(), k.float()) * scale
+    p = torch.softmax(s, -1).to(q.dtype).float()
+    return torch.einsum("bnm,bdm->bnd", p, vt.float()[:, :, :n]).to(q.dtype)
+
+
 def temporal_attention(q, k, v):
     """[B,T,H,W,C]: softmax(q k^T / sqrt(C)) v over the T frames of every pixel"""
     qf, kf, vf = (t.float().permute(0, 2, 3, 1, 4) for t in (q, k, v))  # [B,H,W,T,C]
@@ -345,7 +352,7 @@ def upsample2x_sum(g):
 
 
 _NAMES = ["ncdhw_to_rowpack", "ndhwc_to_rowpack", "pack_weight_rowpack", "pack_weight_tapsn", "conv_out_gather", "pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
-          "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "temporal_attention", "ncdhw_to_ndhwc",
+          "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "attention_d512", "temporal_attention", "ncdhw_to_ndhwc",
           "ndhwc_to_ncdhw", "blend_", "resize_frames_u8", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
 
 
