@@ -219,6 +219,14 @@ def cpu_baseline(family, T=17, H=512, W=512, full=False):
     return out
 
 
+def _rccl_version(torch):
+    try:  # (diagnostic only: never let it take the bench line down)
+        v = torch.cuda.nccl.version()
+        return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
+    except Exception as e:  # noqa: BLE001
+        return f"unavailable ({type(e).__name__})"
+
+
 def reference_noise(case, dtype_tag):
     from oracle import parity as P
     return P.reference_self_noise(case, dtype_tag)
@@ -342,7 +350,7 @@ def main():
                                    f"independent clips x{world} (no collective)")},
         "multi_gpu": None if dist is None else {
             "n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
-            "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version()) if hasattr(torch.cuda, "nccl") else None,
+            "rccl_version": _rccl_version(torch),
             "ms_per_step_by_rank": rank_times, "devices": torch.cuda.device_count(),
             "device_name": torch.cuda.get_device_name(local_rank),
             "data_path_collectives": ("all_gather of the latents (15 MB) once per step; tile results point-to-point only when a "
