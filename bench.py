@@ -227,6 +227,22 @@ def _rccl_version(torch):
         return f"unavailable ({type(e).__name__})"
 
 
+def torch_rocm_baseline(family, shape, dtype_tag, ms_per_step):
+    """The reference's arithmetic on PyTorch-ROCm's own kernels (MIOpen / ATen) on an MI355X: a KEPT measurement of
+    tools/torch_gpu_baseline.py (profiles/r3_torch_gpu_baseline.json; it needs minutes and is not re-run here)."""
+    f = os.path.join(ROOT, "profiles", "r3_torch_gpu_baseline.json")
+    try:
+        runs = json.load(open(f))["runs"]
+    except (OSError, ValueError, KeyError):
+        return None
+    hit = [r for r in runs if r["family"] == family and r["shape"] == list(shape) and r["dtype"] == dtype_tag]
+    if not hit:
+        return None
+    return {"source": "profiles/r3_torch_gpu_baseline.json (tools/torch_gpu_baseline.py, round-3 gpurun box)", "measured_in_this_run": False,
+            "runs": [{"kernels": "MIOpen" if "MIOpen conv" in r["what"] else "ATen vol2col + rocBLAS", "ms_per_clip": r["ms_per_clip"],
+                      "frames_per_s": r["frames_per_s"], "this_run_speedup": round(r["ms_per_clip"] / ms_per_step, 1)} for r in hit]}
+
+
 def reference_noise(case, dtype_tag):
     from oracle import parity as P
     return P.reference_self_noise(case, dtype_tag)
@@ -479,6 +495,8 @@ def main():
         del vq
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(family, T, H, W, full=args.cpu_baseline_full)
+    if rank == 0 and world == 1:
+        out["reference_ops_on_this_gpu_model"] = torch_rocm_baseline(family, [B, 3, T, H, W], args.dtype, out["ms_per_step"])
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

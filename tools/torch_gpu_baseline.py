@@ -18,7 +18,27 @@ ap.add_argument("--family", default="sd3")
 ap.add_argument("--shape", default="1,3,17,512,512")
 ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
 ap.add_argument("--iters", type=int, default=3)
+ap.add_argument("--no-miopen", action="store_true", help="torch.backends.cudnn.enabled = False: ATen's vol2col + rocBLAS GEMM convolutions")
+ap.add_argument("--trace-first", action="store_true", help="print the time of every convolution call of the first (warm-up) step to stderr")
 a = ap.parse_args()
+if a.no_miopen:
+    torch.backends.cudnn.enabled = False
+if a.trace_first:
+    import torch.nn.functional as F
+    _t_begin = time.time()
+
+    def _traced(fn, name):
+        def f(x, w, *args, **kw):
+            torch.cuda.synchronize()
+            t0 = time.time()
+            y = fn(x, w, *args, **kw)
+            torch.cuda.synchronize()
+            if _traced.on:
+                print(f"[{time.time() - _t_begin:7.1f}s] {name} x{tuple(x.shape)} w{tuple(w.shape)} {1e3 * (time.time() - t0):9.2f} ms", file=sys.stderr, flush=True)
+            return y
+        return f
+    _traced.on = True
+    F.conv3d, F.conv2d = _traced(F.conv3d, "conv3d"), _traced(F.conv2d, "conv2d")
 dt = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[a.dtype]
 shape = tuple(int(v) for v in a.shape.split(","))
 sd = {k: v.to(dt).cuda() for k, v in seeded_state_dict(state_dict_shapes(a.family), 0).items()}
@@ -35,6 +55,8 @@ with torch.no_grad():
     mom, rec = step()  # warm-up (MIOpen picks its kernels here)
     torch.cuda.synchronize()
     warm = time.time() - t0
+    if a.trace_first:
+        _traced.on = False
     ts = []
     for _ in range(a.iters):
         torch.cuda.synchronize()
@@ -43,7 +65,8 @@ with torch.no_grad():
         torch.cuda.synchronize()
         ts.append(time.time() - t0)
 ms = sorted(ts)[len(ts) // 2] * 1e3
-out = {"what": "oracle restatement on PyTorch-ROCm (MIOpen / ATen kernels), same seeded weights and input", "family": a.family,
+out = {"what": "oracle restatement on PyTorch-ROCm (" + ("ATen vol2col + rocBLAS convolutions, cudnn/MIOpen disabled" if a.no_miopen else "MIOpen convolutions") +
+       "; ATen GroupNorm / SiLU / SDPA), same seeded weights and input", "family": a.family,
        "shape": list(shape), "dtype": a.dtype, "ms_per_clip": round(ms, 2), "frames_per_s": round(shape[0] * shape[2] / ms * 1e3, 2),
        "first_call_s": round(warm, 1), "torch": torch.__version__, "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
 
