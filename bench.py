@@ -68,7 +68,7 @@ def parse():
     ap.add_argument("--workload", default="cfg3_sd3_T17_512", choices=sorted(WORKLOADS))
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32q"],
                     help="model dtype; f32 = fp32 model in split precision (three fp16 MFMAs per product), f32q = fp32 model in fast "
-                         "split precision (fp16 MFMA + bf8 correction MFMA): the cheapest mode inside north_star's 1e-3 latent bound")
+                         "split precision (fp16 MFMA + bf8 / fp6 correction MFMA): the cheapest mode inside north_star's 1e-3 latent bound")
     ap.add_argument("--no-tolerance-mode", action="store_true",
                     help="skip the annex that times and checks the f32q model (the mode that meets |delta| <= 1e-3) beside the bench dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -486,7 +486,7 @@ def main():
         tq = (time.perf_counter() - tq) / nq
         rq = P.measure(vq, GOLDEN_OF[args.workload])
         out["tolerance_mode"] = {
-            "dtype": "f32q", "what": "fp32 model, every product = fp16 MFMA + bf8 correction MFMA (fp32_mode='fast'); bench.py --dtype f32q",
+            "dtype": "f32q", "what": "fp32 model, every product = fp16 MFMA + bf8 / fp6 correction MFMA (fp32_mode='fast'); bench.py --dtype f32q",
             "value": round(B * T / tq, 3), "unit": "frames/s", "ms_per_step": round(tq * 1e3, 3),
             "latent_max_abs": float(f"{rq['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{rq['latent_mean_abs']:.3e}"),
             "recon_psnr_db": round(rq["recon_psnr_db"], 2), "meets_north_star_tolerance": bool(rq["latent_max_abs"] <= 1e-3),

@@ -8,11 +8,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # CVVAE_LIB: tuning aid -- load another build of the same ABI (A/B of kernel variants); the product path is the in-tree file
 LIB_PATH = os.environ.get("CVVAE_LIB") or os.path.join(_HERE, "libcvvae_hip.so")
 
-F16, BF16, F32, F32Q = 0, 1, 2, 3
+F16, BF16, F32, F32Q, F32Q6 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class ConvDesc(ctypes.Structure):
@@ -38,7 +38,7 @@ class ConvDesc(ctypes.Structure):
         ("w_batch_stride", ctypes.c_int64),
         ("sc_Cin", ctypes.c_int32), ("w_time_folds", ctypes.c_int32),
         ("sc_in_pix_stride", ctypes.c_int64),
-        ("in_overlap", ctypes.c_int32), ("reserved0", ctypes.c_int32),
+        ("in_overlap", ctypes.c_int32), ("act_bound", ctypes.c_float),
     ]
 
 

@@ -75,6 +75,30 @@ __device__ __forceinline__ f32x16 mfma_bf8_k64(f16x8 a_lo, f16x8 a_hi, f16x8 b_l
   const i32x8 b = __builtin_shufflevector(bl, bh, 0, 1, 2, 3, 4, 5, 6, 7);
   return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 1, 1, 0, 0, 0, 0);  // cbsz = blgp = 1: bf8; scales 0: unscaled form
 }
+// v_mfma_scale_f32_32x32x64_f8f6f4 with both operands "bf6" (OCP MX e3m2: 6 bits, normals 0.25 .. 28, subnormal quantum 1/16):
+// K = 64 at FOUR times the fp16 rate per K element.  An operand is 32 six-bit codes per lane (24 bytes, element i at bits 6i..6i+5
+// of the lane's first six dwords), same lane -> (row, k) map as above; each LANE carries one E8M0 scale byte (value 2^(byte-127),
+// byte 0 of the scale operand) for its 32 elements -- the hardware's block scale (tools/fp6_probe.hip, profiles/r3_fp6_probe.txt).
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_bf6_k64(uint4 a03, uint4 a47, uint4 b03, uint2 b45, int scale_b, f32x16 c) {
+  const i32x8_t a = {(int)a03.x, (int)a03.y, (int)a03.z, (int)a03.w, (int)a47.x, (int)a47.y, 0, 0};
+  const i32x8_t b = {(int)b03.x, (int)b03.y, (int)b03.z, (int)b03.w, (int)b45.x, (int)b45.y, 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 3, 3, 0, (int)a47.z, 0, scale_b);  // cbsz = blgp = 3: bf6
+}
+// 16 halves (8 dwords) -> 16 bf6 codes = 96 bits, code i at bits 6i: v_cvt_scalef32_pk32_bf6_f16 (code = round-to-nearest-even of
+// value / scale, saturating at +-28; only the exponent of `scale` is used) on a 32-half operand whose upper half is don't-care
+typedef _Float16 f16x16_t __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x32_t __attribute__((ext_vector_type(32)));
+typedef unsigned u32x6_t __attribute__((ext_vector_type(6)));
+__device__ __forceinline__ uint3 cvt16_bf6(uint4 h07, uint4 h8f, float scale) {
+  typedef unsigned u32x8_t __attribute__((ext_vector_type(8)));
+  const u32x8_t w = {h07.x, h07.y, h07.z, h07.w, h8f.x, h8f.y, h8f.z, h8f.w};
+  const f16x16_t v = __builtin_bit_cast(f16x16_t, w);
+  const f16x32_t v32 = __builtin_shufflevector(v, v, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, -1, -1, -1, -1, -1, -1, -1, -1,
+                                               -1, -1, -1, -1, -1, -1, -1, -1);
+  const u32x6_t r = __builtin_amdgcn_cvt_scalef32_pk32_bf6_f16(v32, scale);
+  return make_uint3(r[0], r[1], r[2]);
+}
 // 8 floats -> 8 bf8 (e5m2, round to nearest even), packed in two dwords
 __device__ __forceinline__ uint2 pack8_bf8(const float (&f)[8]) {
   int a = 0, b = 0;
@@ -133,6 +157,9 @@ struct ConvArgs {
   int t_short_lo, t_short_hi;  // leading / trailing time tiles that are short (time folds): scheduled after the long ones
   int w_taps;    // taps per k16 record group of the packed weights: NTAPS, or 2*NTAPS with the time-fold slots (KT == 3)
   int res_pre;   // residual is accumulated during the K loop instead of in the store tail (needs alpha == 1, 16-bit NDHWC output)
+  // XP == 3 (fp6 corrections): the activations' static power-of-two scale -- codes = value / q6_scale, MFMA scale byte q6_eb
+  float q6_scale;
+  int q6_eb;
   int probe_nostore;  // probe builds (-DCVVAE_CONV_PROBE) only: run the store tail without its stores
   int stats_noshift;  // debug aid (CVVAE_STATS_NOSHIFT=1): fused statistics as plain sums (shift K = 0)
   int ws_window;      // UPS == 2: weight-stationary window of the tile order (tile_map.h), 0 / 1 = off
@@ -157,7 +184,7 @@ constexpr int cmax(int a, int b) { return a > b ? a : b; }
 // to PF KiB past the last real fragment: cvvae_packed_weight_bytes() appends this many readable bytes.
 constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
 
-// XP: 0 = 16-bit model; 1 = fp32 model, three fp16 MFMAs per product ("exact"); 2 = fp32 model, one fp16 MFMA + bf8 correction
+// XP: 0 = 16-bit model; 1 = fp32 model, three fp16 MFMAs per product ("exact"); 2 / 3 = fp32 model, one fp16 MFMA + bf8 / bf6 correction
 // terms on the K = 64 fp8 MFMA ("fast", see conv_fwd_kernel)
 // NB: 32-channel N-blocks per wave.  NB = 2: a wave multiplies every activation fragment it reads from LDS with TWO weight
 // fragments (a 2 x MREP register block): half the LDS operand reads per MFMA -- the LDS pipe (128 B/clk/CU = one 1-KiB fragment
@@ -173,6 +200,7 @@ struct Geo {
   static constexpr int CK = 16 * KSUB;
   // XP (fp32 activations, split-fp16 MFMA): a pixel holds, per 16 channels, hi[0..7] hi[8..15] lo[0..7] lo[8..15] (64 bytes);
   // XP == 2: hi[0..15] (fp16, 32 bytes) | lo[0..15] (bf8, 16 bytes) | hi[0..15] (bf8, 16 bytes)
+  // XP == 3: hi[0..15] (fp16, 32 bytes) | bf6 codes of [lo*2^11 (8) | hi (8)] of channels 0..7, then of channels 8..15 (24 bytes) | pad
   static constexpr int PIXB = (XP ? CK * 4 : CK * 2) + 16;
   static constexpr int XPM = XP ? 3 : 1;  // weight records per k16 sub-chunk and tap (XP == 1: one MFMA each)
   static constexpr int BUFB = NPIX * PIXB;
@@ -312,6 +340,12 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
 // 6; error ~2^-14 relative per product (oracle/precision_ladder.py: latent max |delta| 1.3e-4 where the fp16 model has 2.6e-3
 // and the three-MFMA form 1.9e-5).  The packed weights keep three 1-KiB records per (k16, tap): [0] Whi (fp16), [1], [2] the
 // two halves of the pair's bf8 record (at the pair's FIRST tap; pairs never cross a run of KH*KW taps).
+//
+// XP == 3 (dtype CVVAE_F32Q6): the same with the correction terms in "bf6" (e3m2) on the block-scaled form of that instruction, at four
+// times the fp16 rate per K element.  A lane's 32 codes are [lo * 2^11 | hi] of ONE tap's 16 channels (lanes 0-31: tap a, 32-63: tap
+// b) against [Whi | Wlo * 2^11]: both halves have the operand's own magnitude, so ONE power of two per lane (the E8M0 block scale)
+// serves both terms -- per (output channel, tap) for the weights (stored in the record), one per launch for the activations
+// (ConvArgs.q6_scale / q6_eb from the caller's bound of the operand).  An LDS pixel holds hi (fp16, 32 B) | 24 bytes of codes.
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
           int PRO, int UPS, int XP = 0, int NB = 1>
 __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) void conv_fwd_kernel(const ConvArgs p) {
@@ -546,7 +580,23 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               fl[j] = f[j] - h;
               f[j] = h;
             }
-            if constexpr (XP == 2) {  // hi fp16 | bf8(lo) | bf8(hi)
+            if constexpr (XP == 3) {  // hi fp16 (32 bytes) | 24 bytes of bf6 codes: my 8 channels' [lo * 2^11 (8) | hi (8)] at +12 * (sq & 1)
+#pragma unroll
+              for (int j = 0; j < 8; ++j) fl[j] *= 2048.0f;
+              uint4 oh = pack8<T>(f);
+              const uint4 ol = pack8<T>(fl);
+              uint3 q = cvt16_bf6(ol, oh, p.q6_scale);
+              if (srcpix[k] < 0) {
+                oh = make_uint4(0, 0, 0, 0);
+                q = make_uint3(0, 0, 0);
+              }
+              // dense 24-byte field at +32: item 0 = dwords 0-2, item 1 = dwords 3-5 -> an 8-byte and a 4-byte store each
+              const bool odd = (sq & 1) != 0;
+              char* d6 = smem + bufsel * G::BUFB + lds_q8 - (sq & 1) * 8 + k * (G::PPP * PIXB);
+              *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = oh;
+              *reinterpret_cast<uint2*>(d6 + (odd ? 16 : 0)) = odd ? make_uint2(q.y, q.z) : make_uint2(q.x, q.y);
+              *reinterpret_cast<unsigned*>(d6 + (odd ? 12 : 8)) = odd ? q.x : q.z;
+            } else if constexpr (XP == 2) {  // hi fp16 | bf8(lo) | bf8(hi)
               uint4 oh = pack8<T>(f);
               uint2 l8 = pack8_bf8(fl), h8 = pack8_bf8(f);
               if (srcpix[k] < 0) {
@@ -612,8 +662,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                        : (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512)) + lane * 8;
   // XP == 2: the ring holds the FOUR records of one pair of taps -- [0] Whi of tap a, [1], [2] the halves of the pair's bf8
   // record, [3] Whi of tap b -- each refilled with the next pair's right after its last use
-  constexpr int NWF = XP == 2 ? 4 : PF;
-  static_assert(XP != 2 || TFOLD || KT == 1, "fast-fp32 instances: 3-tap time kernels walk time groups, the others have KT = 1");
+  constexpr int NWF = XP >= 2 ? 4 : PF;
+  static_assert(XP < 2 || TFOLD || KT == 1, "fast-fp32 instances: 3-tap time kernels walk time groups, the others have KT = 1");
   const long long wq_ks = (long long)(TFOLD ? p.w_taps : NTAPS * 3) * 512, wq_cs = wq_ks * KSUB;  // (XP == 2)
   const T* wqx = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
                  (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
@@ -621,7 +671,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   // elements between the packed weights of consecutive 32-channel blocks (NB = 2: the wave's second block)
   const long long wq_nbs = (long long)p.nchunks * (TFOLD ? w_cs : (long long)(STEPS * 512));
   v8 wf[NB][NWF];
-  if constexpr (XP == 2) {
+  if constexpr (XP >= 2) {
     const T* e = wqx + (TFOLD ? tf_w0 : 0);  // chunk 0, time group 0, pair 0 (taps 0 and 1 of k16 sub-chunk 0)
     wf[0][0] = *reinterpret_cast<const v8*>(e);
     wf[0][1] = *reinterpret_cast<const v8*>(e + 512);
@@ -681,7 +731,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     const bool stage_first = grp == 0 && !p.phase_sync;
     if (stage_first && more) stage(c + 1, cur ^ 1);
     CVVAE_PROBE_MARK();
-    if constexpr (XP == 2) {
+    if constexpr (XP >= 2) {
       // ---- fast fp32: per pair of taps (a, b) of a run of R = KH*KW taps:  Whi.hi (a), Whi.hi (b) on the fp16 MFMA, then both
       //      correction terms of both taps on ONE bf8 K = 64 MFMA.  A run with an odd tap count ends with a half-empty pair (the
       //      packer zero-fills its second half; the B operand repeats tap a so that 0 x finite = 0).  LDS fragments and weight
@@ -693,6 +743,12 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         const T* wnx = more ? wcb + wq_cs : wcb;  // the last chunk's read-ahead re-reads its own records
         const int ngq = TFOLD ? tf_ng : 1;
         v8 fa[MREP], fb[MREP], qa[MREP], qb[MREP];
+        // XP == 3: ONE bf6 operand per fragment -- 24 bytes of the LANE's tap (lanes 0-31: tap a, lanes 32-63: tap b of the pair):
+        // [lo * 2^11 | hi] codes of the pixel's 16 channels
+        uint4 q6a[XP == 3 ? MREP : 1];
+        uint2 q6b[XP == 3 ? MREP : 1];
+        const unsigned aq6 = XP == 3 ? 32u - (unsigned)((lane >> 5) * 16) : 0u;  // (aoff[] carries the fp16 k split: undo it)
+        const bool lhi = lane >= 32;
 #pragma unroll
         for (int r = 0; r < MREP; ++r) fa[r] = *reinterpret_cast<const v8*>(&smem[lb + (TFOLD ? tf_l0 : 0u) + aoff[r]]);
         for (int g = 0; g < ngq; ++g) {
@@ -711,12 +767,16 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
             const T* ne = lastq ? wn : wg + (long long)nks * wq_ks + nta * (3 * 512);  // record [0] of the next pair
             const bool nhasb = lastq ? (R > 1) : (nta + 1 < R);
             const unsigned ona = (unsigned)(((nta / KW) * G::FW + (nta % KW)) * PIXB + nks * 64);
+            const unsigned oq6 = (hasb && lhi ? ob : oa) + aq6;  // XP == 3: my tap's pixel (an unpaired tap: both halves read tap a)
             // Whi.hi of tap a
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
               acc[r] = Tr<T>::mfma(wf[0][0], fa[r], acc[r]);
               if (hasb) fb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob]);
-              else qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
+              else if constexpr (XP == 3) {
+                q6a[r] = *reinterpret_cast<const uint4*>(&smem[lbg + aoff[r] + oq6]);
+                q6b[r] = *reinterpret_cast<const uint2*>(&smem[lbg + aoff[r] + oq6 + 16]);
+              } else qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
             }
             wf[0][0] = *reinterpret_cast<const v8*>(ne);
             __builtin_amdgcn_sched_barrier(0);
@@ -724,16 +784,24 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
                 acc[r] = Tr<T>::mfma(wf[0][3], fb[r], acc[r]);
-                qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
-                qb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob + 32]);
+                if constexpr (XP == 3) {
+                  q6a[r] = *reinterpret_cast<const uint4*>(&smem[lbg + aoff[r] + oq6]);
+                  q6b[r] = *reinterpret_cast<const uint2*>(&smem[lbg + aoff[r] + oq6 + 16]);
+                } else {
+                  qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
+                  qb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob + 32]);
+                }
               }
             }
             wf[0][3] = *reinterpret_cast<const v8*>(ne + (nhasb ? 3 * 512 : 0));
             __builtin_amdgcn_sched_barrier(0);
-            // bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi) of both taps
+            // q(Whi).q(lo) + q(Wlo).q(hi) of both taps (bf8: K = 64 at twice the fp16 rate; bf6: four times)
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
-              acc[r] = mfma_bf8_k64(wf[0][1], wf[0][2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
+              if constexpr (XP == 3)
+                acc[r] = mfma_bf6_k64(__builtin_bit_cast(uint4, wf[0][1]), __builtin_bit_cast(uint4, wf[0][2]), q6a[r], q6b[r], p.q6_eb, acc[r]);
+              else
+                acc[r] = mfma_bf8_k64(wf[0][1], wf[0][2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
               if (!lastq) fa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ona]);
               else if (!lastg) fa[r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
@@ -862,7 +930,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   }
   // ---- fused 1x1 shortcut: more K chunks over the second input through the centre tap (the final barrier of the loop
   //      above has released both halo buffers)
-  if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0 && XP != 2) {
+  if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0 && XP < 2) {
     if (p.in2 != nullptr) {
       const TIO* __restrict__ inp2 = reinterpret_cast<const TIO*>(p.in2);
       auto stage2 = [&](int chunk, int bufsel) {

@@ -172,6 +172,14 @@
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
   X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
 #define CVVAE_CONV_XQ(X) CVVAE_CONV_XQ_A(X) CVVAE_CONV_XQ_B(X)
+// Fast-fp32 with fp6 corrections (XP = 3, dtype CVVAE_F32Q6): the GroupNorm + SiLU prologue instances of the list above -- the layers
+// whose operand has a bound the host can derive from the GroupNorm affine (cvvae_conv_desc.act_bound)
+#define CVVAE_CONV_XQ6(X) \
+  X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 2,4,32, 8,1,1, 1, 1,0) \
+  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0)
 
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \

@@ -22,6 +22,9 @@ CVVAE_CONV_XP(CVVAE_EXTERN_XP)
 #define CVVAE_EXTERN_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_XQ(CVVAE_EXTERN_XQ)
+#define CVVAE_EXTERN_XQ6(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_XQ6(CVVAE_EXTERN_XQ6)
 #define CVVAE_EXTERN_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t); \
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t);
@@ -32,26 +35,29 @@ typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 struct Instance {
   int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, kg, ksub, pro, ups;
   int nbw;  // 32-channel N-blocks per wave (1; 2 = the register-blocked instances: a wave's tile is 64 channels wide)
-  launch_fn fn[4];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one), [CVVAE_F32Q] (fast fp32)
+  launch_fn fn[5];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one), [CVVAE_F32Q], [CVVAE_F32Q6] (fast fp32)
   char name[96];
 };
 
 #define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
-    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr, nullptr}, ""},
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr, nullptr, nullptr}, ""},
 #define CVVAE_ROW_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 2, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, \
-    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, nullptr, nullptr}, ""},
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, nullptr, nullptr, nullptr}, ""},
 #define CVVAE_ROW_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
-   {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>, nullptr}, ""},
+   {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>, nullptr, nullptr}, ""},
 #define CVVAE_ROW_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
-   {nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>}, ""},
+   {nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>, nullptr}, ""},
+#define CVVAE_ROW_XQ6(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
+   {nullptr, nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3>}, ""},
 
-static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ)};
+static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ) CVVAE_CONV_XQ6(CVVAE_ROW_XQ6)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -177,16 +183,19 @@ static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
     snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d%s", e->kt, e->kh, e->kw, e->st,
              e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups,
-             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->nbw == 2 ? "_nb2" : "")));
+             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->fn[4] ? "_xq6" : (e->nbw == 2 ? "_nb2" : ""))));
   (void)dtype;
   return e->name;
 }
 
 static int check_desc(const cvvae_conv_desc* d) {
   if (!d) return CVVAE_EINVAL;
-  if (d->dtype != CVVAE_F16 && d->dtype != CVVAE_BF16 && d->dtype != CVVAE_F32 && d->dtype != CVVAE_F32Q) return CVVAE_EINVAL;
+  if (d->dtype < CVVAE_F16 || d->dtype > CVVAE_F32Q6) return CVVAE_EINVAL;
   // fast fp32: multi-tap convolutions without a fused shortcut or per-item weights (those run as CVVAE_F32)
-  if (d->dtype == CVVAE_F32Q && (d->kH * d->kW == 1 || d->sc_Cin || d->w_batch_stride)) return CVVAE_EUNSUPPORTED;
+  const bool fastq = d->dtype == CVVAE_F32Q || d->dtype == CVVAE_F32Q6;
+  if (fastq && (d->kH * d->kW == 1 || d->sc_Cin || d->w_batch_stride)) return CVVAE_EUNSUPPORTED;
+  // fp6 corrections: the activations' scale comes from the caller's bound (finite, > 0)
+  if (d->dtype == CVVAE_F32Q6 ? !(d->act_bound > 0.0f && d->act_bound < 3.0e38f) : d->act_bound != 0.0f) return CVVAE_EINVAL;
   if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0)
     return CVVAE_EINVAL;
   const int ck = cvvae_conv_kchunk(d->kT, d->kH, d->kW);
@@ -345,7 +354,7 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
     a.in2_ps = d->sc_in_pix_stride;
     a.nchunks2 = d->sc_Cin / (16 * e->ksub);
   }
-  const int xpm = (d->dtype == CVVAE_F32 || d->dtype == CVVAE_F32Q) ? 3 : 1;  // packed records per (k16, tap): the fp32 layouts carry three
+  const int xpm = d->dtype >= CVVAE_F32 ? 3 : 1;  // packed records per (k16, tap): the fp32 layouts carry three
   a.w_phase_stride = fold ? (long long)(cvvae_packed_weight_bytes(d->Cout, d->Cin, 4 * d->kT * (d->w_time_folds ? 2 : 1) * xpm) / 2) : 0;
   a.out_ps = d->out_pix_stride;
   a.pt = d->pad_t; a.ph = d->pad_h; a.pw = d->pad_w;
@@ -369,6 +378,17 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   // (two knobs stay per launch because the GPU tests flip them inside one process: CVVAE_CONV_FORCE in select_instance and this one)
   if (const char* f = getenv("CVVAE_CONV_PHASE_SYNC")) a.phase_sync = atoi(f) ? 1 : 0;  // conv_kernel.h phase_sync
   a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1) * xpm;
+  a.q6_scale = 1.0f;
+  a.q6_eb = 127;
+  if (d->dtype == CVVAE_F32Q6) {  // activations: codes = value * 2^s with 2^s * act_bound <= 28 (e3m2's largest value)
+    int ex = 0;
+    const float fr = frexpf(28.0f / d->act_bound, &ex);  // 28 / bound = fr * 2^ex, fr in [0.5, 1)  ->  floor(log2) = ex - 1
+    (void)fr;
+    int sft = ex - 1;
+    sft = sft < -100 ? -100 : (sft > 100 ? 100 : sft);
+    a.q6_scale = ldexpf(1.0f, -sft);
+    a.q6_eb = 127 - sft;
+  }
   static const bool res_pre_off = getenv("CVVAE_RES_PRELOAD") && atoi(getenv("CVVAE_RES_PRELOAD")) == 0;  // tuning aid
   a.res_pre = (residual && d->alpha == 1.0f && !d->out_f32 && !res_pre_off) ? 1 : 0;
   // tuning aid (tools/tune_instances.py re-launches recorded calls under CVVAE_CONV_FORCE: the record table was sized for

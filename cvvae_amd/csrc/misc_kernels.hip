@@ -102,14 +102,69 @@ __device__ __forceinline__ uint4 xq_half(int kh, const float (&w)[16]) {
   const uint2 lo = pack8_bf8(a), hi = pack8_bf8(b);
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
+// e3m2 ("bf6": sign, 3 exponent bits of bias 3, 2 mantissa bits; normals 0.25 .. 28, subnormals k/16), round to nearest even,
+// saturating -- the rounding of v_cvt_scalef32_pk32_bf6_f16 (tools/fp6_probe.hip)
+__device__ __forceinline__ unsigned enc_e3m2(float v) {
+  const unsigned sgn = (__float_as_uint(v) >> 31) << 5;
+  const float a = fminf(fabsf(v), 28.0f);
+  if (!(a >= 0.25f)) return sgn | (unsigned)(int)rintf(a * 16.0f);  // subnormals (and 0.25 itself from below: code 4)
+  int e;
+  const float fr = frexpf(a, &e);  // a = fr * 2^e, fr in [0.5, 1)  ->  a = (2 fr) * 2^(e-1)
+  int m = (int)rintf((2.0f * fr - 1.0f) * 4.0f), ex = e - 1;
+  if (m == 4) {
+    m = 0;
+    ++ex;
+  }
+  return sgn | (unsigned)((ex + 3) << 2) | (unsigned)m;
+}
+// Fast-fp32 records with fp6 corrections (dtype CVVAE_F32Q6, conv_fwd_kernel<..., XP = 3>): [0] as above; [1], [2] = the 32 bytes of a
+// lane's operand of the K = 64 bf6 MFMA: lanes 0-31 tap a, lanes 32-63 tap b of the pair (zero when the run ends on tap a), row =
+// output channel; 32 six-bit codes, slot 16 i + 8 t + c = channel 8 i + c of term t:  t = 0: Whi (x the activation's lo * 2^11),
+// t = 1: Wlo * 2^11 (x the activation's hi) -- both of the magnitude of the weight, so that ONE power of two per lane (2^sh, the
+// largest with max |value| 2^sh <= 28) puts them into e3m2's range; bytes 0-23 = the codes, byte 24 = the lane's E8M0 block scale
+// 127 - sh - 11 (it also undoes the 2^11 of either term).
+__device__ __forceinline__ void xq6_lane(const float (&w)[16], uint4& q1, uint4& q2) {
+  float v[32];
+  float mx = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const float hi = (float)(_Float16)w[j];
+    const int sl = 16 * (j >> 3) + (j & 7);
+    v[sl] = hi;
+    v[sl + 8] = (w[j] - hi) * 2048.0f;
+    mx = fmaxf(mx, fmaxf(fabsf(v[sl]), fabsf(v[sl + 8])));
+  }
+  int sh = 0;
+  if (mx > 0.f) {
+    int e;
+    (void)frexpf(28.0f / mx, &e);
+    sh = e - 1;  // floor(log2(28 / mx))
+    sh = sh < -100 ? -100 : (sh > 100 ? 100 : sh);
+  }
+  const float mul = ldexpf(1.0f, sh);
+  unsigned d[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int i = 0; i < 32; ++i) {
+    const unsigned long long c = enc_e3m2(v[i] * mul);
+    const int bit = 6 * i, dw = bit >> 5, o = bit & 31;
+    d[dw] |= (unsigned)(c << o);
+    if (o > 26) d[dw + 1] |= (unsigned)(c >> (32 - o));
+  }
+  q1 = make_uint4(d[0], d[1], d[2], d[3]);
+  q2 = make_uint4(d[4], d[5], (unsigned)(127 - sh - 11), 0u);
+}
 __device__ __forceinline__ void xq_store(_Float16* dst, long long rec3, int lane, const float (&wa)[16], const float (&wb)[16],
-                                         bool pair_start, bool has_b) {
+                                         bool pair_start, bool has_b, bool q6) {
   const int kh = lane >> 5;
   f16x8 p0;
 #pragma unroll
   for (int j = 0; j < 8; ++j) p0[j] = (_Float16)wa[kh * 8 + j];
   uint4 q1 = make_uint4(0, 0, 0, 0), q2 = make_uint4(0, 0, 0, 0);
-  if (pair_start) {
+  if (pair_start && q6) {
+    if (kh == 0) xq6_lane(wa, q1, q2);
+    else if (has_b) xq6_lane(wb, q1, q2);
+    else q2 = make_uint4(0u, 0u, 127u, 0u);
+  } else if (pair_start) {
     q1 = xq_half(kh, wa);
     if (has_b) q2 = xq_half(kh, wb);
   }
@@ -122,7 +177,7 @@ __device__ __forceinline__ void xq_store(_Float16* dst, long long rec3, int lane
 __global__ void pack_weights_xp_kernel(const float* __restrict__ src, int Cout_src, int Cin_src, int taps, long long s_co,
                                        long long s_ci, long long s_tap, int nchunks, _Float16* __restrict__ dst,
                                        long long nfrag_lanes, int fold_n, long long s_fold, long long s_batch,
-                                       long long d_batch, int dst_taps, int dst_tap0, int qrun) {
+                                       long long d_batch, int dst_taps, int dst_tap0, int qrun, int q6) {
   const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= nfrag_lanes) return;
   src += (long long)blockIdx.y * s_batch;
@@ -158,7 +213,7 @@ __global__ void pack_weights_xp_kernel(const float* __restrict__ src, int Cout_s
 #pragma unroll
       for (int j = 0; j < 16; ++j) wb[j] = 0.f;
     }
-    xq_store(dst, rec * 3, lane, w, wb, start, has_b);
+    xq_store(dst, rec * 3, lane, w, wb, start, has_b, q6 != 0);
   } else {
     xp_store(dst, rec * 3, lane, w);
   }
@@ -258,7 +313,7 @@ __global__ void pack_upfold_xp_kernel(const float* __restrict__ src, int Cout, i
 #pragma unroll
       for (int j = 0; j < 16; ++j) wb[j] = 0.f;
     }
-    xq_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16, wb, start, start);
+    xq_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16, wb, start, start, false);
   } else {
     xp_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16);
   }
@@ -1191,7 +1246,7 @@ int cvvae_pack_weights_fold(int32_t dtype, const void* src, int32_t Cout_src, in
 int cvvae_pack_weights_batched(int32_t dtype, const void* src, int32_t batch, int64_t s_batch, int32_t Cout_src,
                                int32_t Cin_src, int32_t taps, int64_t s_co, int64_t s_ci, int64_t s_tap, int32_t Cin_pad,
                                int32_t kchunk, void* dst, int64_t dst_batch_stride, void* stream) {
-  if (dtype == CVVAE_F32Q) return CVVAE_EUNSUPPORTED;  // per-item (attention) weights are 1x1: they stay in the three-MFMA form
+  if (dtype == CVVAE_F32Q || dtype == CVVAE_F32Q6) return CVVAE_EUNSUPPORTED;  // per-item (attention) weights are 1x1: they stay in the three-MFMA form
   if (batch <= 0 || dst_batch_stride % 16 || (size_t)dst_batch_stride < cvvae_packed_weight_bytes(Cout_src, Cin_pad, taps * (dtype == CVVAE_F32 ? 3 : 1)))
     return CVVAE_EINVAL;
   return pack_impl(dtype, src, batch, s_batch, Cout_src, Cin_src, taps, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst,
@@ -1219,17 +1274,17 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
     hipLaunchKernelGGL(pack_weights_kernel<_Float16>, dim3(grid, batch), dim3(256), 0, s, (const _Float16*)src, Cout_src,
                        Cin_src, taps, (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, ksub, (_Float16*)dst, n,
                        fold_n, (long long)s_fold, (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0);
-  else if (dtype == CVVAE_F32 || dtype == CVVAE_F32Q) {  // fp32 source -> split-precision records (3 per (k16, tap); one thread per record TRIPLE)
+  else if (dtype == CVVAE_F32 || dtype == CVVAE_F32Q || dtype == CVVAE_F32Q6) {  // fp32 source -> split-precision records (3 per (k16, tap); one thread per record TRIPLE)
     // fast-fp32 pairs stay inside a run of kH*kW taps (the kernel walks 3-tap time kernels as time groups of kH*kW steps):
     // 27 / 54 (time-fold slots) / 9 -> runs of 9, 12 / 24 / 4 -> runs of 4 (the folded-upsample phases come through upfold_launch)
     int qrun = 0;
-    if (dtype == CVVAE_F32Q) {
+    if (dtype == CVVAE_F32Q || dtype == CVVAE_F32Q6) {
       qrun = taps % 9 == 0 ? 9 : (taps % 4 == 0 ? 4 : 0);
       if (!qrun || dst_taps % qrun || dst_tap0 % qrun) return CVVAE_EUNSUPPORTED;  // (1x1x1 weights: use CVVAE_F32)
     }
     hipLaunchKernelGGL(pack_weights_xp_kernel, dim3(grid, batch), dim3(256), 0, s, (const float*)src, Cout_src, Cin_src, taps,
                        (long long)s_co, (long long)s_ci, (long long)s_tap, nchunks, (_Float16*)dst, n, fold_n, (long long)s_fold,
-                       (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0, qrun);
+                       (long long)s_batch, (long long)(d_batch_bytes / 2), dst_taps, dst_tap0, qrun, dtype == CVVAE_F32Q6 ? 1 : 0);
   }
   else
     return CVVAE_EINVAL;
@@ -1244,7 +1299,7 @@ static int pack_impl(int32_t dtype, const void* src, int32_t batch, int64_t s_ba
 int cvvae_pack_weights_tfolds(int32_t dtype, const void* src, int32_t Cout_src, int32_t Cin_src, int32_t nsp, int64_t s_co,
                               int64_t s_ci, int64_t s_tap, int32_t Cin_pad, int32_t kchunk, void* dst, void* stream) {
   if (nsp <= 0) return CVVAE_EINVAL;
-  const int es = (dtype == CVVAE_F32 || dtype == CVVAE_F32Q) ? 4 : 2;  // bytes per source element
+  const int es = dtype >= CVVAE_F32 ? 4 : 2;  // bytes per source element
   const char* sp = (const char*)src;
   int rc = pack_impl(dtype, src, 1, 0, Cout_src, Cin_src, 3 * nsp, s_co, s_ci, s_tap, 1, 0, Cin_pad, kchunk, dst, 0, stream, 6 * nsp, 0);
   if (rc) return rc;

@@ -29,31 +29,56 @@ class WeightCache:
         # fp32 models: pack multi-tap conv weights in the fast layout (CVVAE_F32Q: fp16 MFMA + bf8 correction MFMA, DESIGN.md
         # section 4) instead of the three-MFMA split-precision one; set through the model's `fp32_mode`
         self.fast = False
+        # ... and, behind a GroupNorm + SiLU, with e3m2 ("fp6") corrections (CVVAE_F32Q6: 1.5x instead of 2x the MFMA time of a 16-bit
+        # model); CVVAE_F32_FP6=0 keeps the bf8 form everywhere (A/B aid)
+        self.fast6 = os.environ.get("CVVAE_F32_FP6", "1") != "0"
 
     def _q(self) -> str:
         return "#q" if self.fast else ""
+
+    def act_bound(self, norm_pre: str, sigmas: float = 8.0) -> float:
+        """upper bound of |SiLU(gamma n + beta)| for a normalised n within `sigmas`: sigmas max|gamma| + max|beta| (one host sync per
+        GroupNorm, cached with its parameters).  Elements beyond it lose only their fp6 CORRECTION terms (include/cvvae.h)."""
+        g = self.m.get_parameter(norm_pre + ".weight")
+        b = self.m.get_parameter(norm_pre + ".bias")
+        key = self._key(g, b)
+        tag = norm_pre + "#bound"
+        hit = self._c.get(tag)
+        if hit is None or hit[0] != key:
+            hit = (key, max(float(sigmas * g.detach().abs().max() + b.detach().abs().max()), 1e-6))
+            self._c[tag] = hit
+        return hit[1]
 
     def _key(self, *ps):
         return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps if p is not None)
 
     def conv(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None, time_folds: bool = False,
-             wscale: Optional[float] = None) -> ops.PackedConv:
+             wscale: Optional[float] = None, act_norm: Optional[str] = None) -> ops.PackedConv:
         """time_folds (k = (3, kH, kW)): packed with the summed time slots for boundary frames (ops.pack_weight_tfolds);
-        wscale (fp32 models): pack with this power-of-two scale (a fused shortcut shares its conv's accumulators)"""
+        wscale (fp32 models): pack with this power-of-two scale (a fused shortcut shares its conv's accumulators);
+        act_norm: the GroupNorm whose output (+ SiLU) this stride-1 conv consumes through its prologue -- fast fp32 models then take
+        the fp6-correction form with the bound derived from that norm's affine"""
         w = self.m.get_parameter(pre + ".weight")
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
-        tag = (pre + "#tf" if time_folds else (pre if wscale is None else f"{pre}#ws{wscale}")) + self._q()
+        q6 = (self.fast and self.fast6 and act_norm is not None and w.dtype == torch.float32 and wscale is None
+              and tuple(k) in ((3, 3, 3), (1, 3, 3)))
+        fast = "fp6" if q6 else self.fast
+        tag = (pre + "#tf" if time_folds else (pre if wscale is None else f"{pre}#ws{wscale}")) + ("#q6" if q6 else self._q())
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
+            if q6:
+                hit[1].act_bound = self.act_bound(act_norm)
             return hit[1]
         taps = k[0] * k[1] * k[2]
         co, ci = w.shape[0], w.shape[1]
         assert w.numel() == co * ci * taps, f"{pre}: weight {tuple(w.shape)} is not a {k} kernel"
         if time_folds:
-            pw = ops.pack_weight_tfolds(w.detach().reshape(co, ci, *k), b.detach(), cin_pad=cin_pad, fast=self.fast)
+            pw = ops.pack_weight_tfolds(w.detach().reshape(co, ci, *k), b.detach(), cin_pad=cin_pad, fast=fast)
         else:
-            pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad, wscale=wscale, fast=self.fast)
+            pw = ops.pack_weight(w.detach().reshape(co, ci, taps), b.detach(), k, cin_pad=cin_pad, wscale=wscale, fast=fast)
+        if q6:
+            pw.act_bound = self.act_bound(act_norm)
         if wscale is not None:  # one scaled form per prefix: older '#ws<scale>' variants (another conv2 scale) are dead weight
             for t in [t for t in self._c if t.startswith(pre + "#ws") and t != tag]:
                 del self._c[t]
@@ -281,16 +306,20 @@ def _shortcut_scale_fits(wc: WeightCache, sc_name: str, pw2, dtype) -> bool:
     return hit[1] * pw2.wscale < 32768.0
 
 
+def _fused_prologue() -> bool:
+    return os.environ.get("CVVAE_PREPASS", "auto") in ("auto", "0")
+
+
 def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
     """conv2 (per-frame 3x3 over GN+SiLU(h), zero pad) + shortcut(x) + add -- vae_blocks3d_sd3.py:559-567, vae_models.py:404-410."""
-    pw2 = wc.conv(pre + ".conv2", (1, 3, 3))
+    pw2 = wc.conv(pre + ".conv2", (1, 3, 3), act_norm=pre + ".norm2" if _fused_prologue() else None)
     kw = dict(pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2, gn_out=G32 if want_stats else 0)
     if prepass(h, (1, 3, 3), pw2.cout):
         h = ops.gn_silu_apply(h, g2)
         kw.update(prologue=L.PRO_NONE, gn=None)
     if not wc.has(sc_name + ".weight"):
         y = ops.conv(h, pw2, residual=x, **kw)
-    elif fuse_shortcut() and pw2.dt != L.F32Q and _shortcut_scale_fits(wc, sc_name, pw2, x.dtype):
+    elif fuse_shortcut() and pw2.dt not in (L.F32Q, L.F32Q6) and _shortcut_scale_fits(wc, sc_name, pw2, x.dtype):
         # (fp32 models: the shortcut weights are packed with conv2's power-of-two scale -- one accumulator set; the fast-fp32
         # kernels have no fused shortcut, and a shortcut whose weights would overflow fp16 under conv2's scale is not fused
         # either: the 1x1 then runs as its own three-MFMA launch with its own scale)
@@ -317,15 +346,19 @@ def fold_time() -> bool:
     return os.environ.get("CVVAE_FOLD_TIME", "1") != "0"
 
 
-def conv3(wc: WeightCache, x: torch.Tensor, pre: str, *, pad, pad_mode_t, pad_mode_hw, stride=(1, 1, 1), cin_pad=None, **kw):
+def conv3(wc: WeightCache, x: torch.Tensor, pre: str, *, pad, pad_mode_t, pad_mode_hw, stride=(1, 1, 1), cin_pad=None,
+          act_norm: Optional[str] = None, **kw):
     """One 3x3x3 convolution of the path (CausalConv3d / Conv3d / nn.Conv3d / Downsample3D).  On a single-frame input whose
-    time padding makes the three taps coincide it runs as the temporally folded 1x3x3 conv (fold_t1)."""
+    time padding makes the three taps coincide it runs as the temporally folded 1x3x3 conv (fold_t1).
+    act_norm: name of the GroupNorm behind the GN+SiLU prologue (WeightCache.conv)."""
+    if not (kw.get("prologue") == L.PRO_GN_SILU and tuple(stride) == (1, 1, 1) and _fused_prologue()):
+        act_norm = None
     if x.shape[1] == 1 and fold_t1() and pad[0][0] + pad[0][1] == 2:
         pw = wc.conv_t1(pre, "sum" if pad_mode_t == REP else "center", cin_pad=cin_pad)
         x, kw = _activated(x, kw, (1, 3, 3), pw.cout)
         return ops.conv(x, pw, stride=(1, stride[1], stride[2]), pad=((0, 0), pad[1], pad[2]), pad_mode_hw=pad_mode_hw, **kw)
     tf = pad_mode_t == REP and fold_time()
-    pw = wc.conv(pre, (3, 3, 3), cin_pad=cin_pad, time_folds=tf)
+    pw = wc.conv(pre, (3, 3, 3), cin_pad=cin_pad, time_folds=tf, act_norm=act_norm)
     x, kw = _activated(x, kw, (3, 3, 3), pw.cout)
     return ops.conv(x, pw, stride=stride, pad=pad, pad_mode_t=pad_mode_t, pad_mode_hw=pad_mode_hw, **kw)
 
@@ -498,7 +531,7 @@ def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, wan
     xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
     h, hp = conv3(wc, x, pre + ".conv1", pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
-                     prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32)
+                     prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32, act_norm=pre + ".norm1")
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
 
@@ -562,8 +595,8 @@ def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool 
     """ResnetBlock2D.forward, lvdm/modules/diffusionmodules/vae_blocks_sd3.py:368-421, on [frames,1,H,W,C]: GN(eps 1e-6)+SiLU
     fused into conv1 and conv2 (per-frame 3x3, zero pad), 1x1 shortcut and residual add in conv2's launch."""
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
-    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g1,
-                     gn_out=G32)
+    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (1, 3, 3), act_norm=pre + ".norm1" if _fused_prologue() else None), pad=P2D,
+                     pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     if tape is not None:
         tape.append(dict(op="resnet", pre=pre, x=x, xp=xp, h=h, hp=hp))
@@ -693,7 +726,7 @@ def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want
     pad, mt, mhw = _v3_pad(causal)
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-5)
     h, hp = conv3(wc, x, pre + ".conv1", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU,
-                     gn=g1, gn_out=G32)
+                     gn=g1, gn_out=G32, act_norm=pre + ".norm1")
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-5)
     return resnet_tail(wc, x, h, pre, pre + ".nin_shortcut", g2, want_stats)
 

@@ -18,12 +18,16 @@ SUPPORTS_FP32 = True
 # ... or, per model (`fp32_mode = "fast"`), with the two correction terms on the fp8 matrix pipe (CVVAE_F32Q; conv_kernel.h
 # XP == 2): ~6e-5 relative error at 2x the MFMA time of a 16-bit model -- the cheapest mode inside north_star's 1e-3 bound
 SUPPORTS_FP32_FAST = True
+# ... and, for the convolutions behind a GroupNorm + SiLU (whose operand has a bound the host knows), with the correction terms in the
+# 6-bit e3m2 format at four times the fp16 rate (CVVAE_F32Q6; XP == 3): 1.5x the MFMA time of a 16-bit model (`fast="fp6"`)
+SUPPORTS_FP32_FP6 = True
 
 
-def _pack_dt(w: torch.Tensor, taps_hw: int, fast: bool) -> int:
-    """dtype code a weight is packed with: fp32 weights of multi-tap convolutions take the fast layout when asked to"""
+def _pack_dt(w: torch.Tensor, taps_hw: int, fast) -> int:
+    """dtype code a weight is packed with: fp32 weights of multi-tap convolutions take the fast layout when asked to
+    (fast = True: bf8 corrections, any operand; fast = "fp6": e3m2 corrections, the launch then needs PackedConv.act_bound)"""
     if fast and w.dtype == torch.float32 and taps_hw > 1:
-        return L.F32Q
+        return L.F32Q6 if fast == "fp6" else L.F32Q
     return _dt(w.dtype)
 
 
@@ -88,7 +92,8 @@ class PackedConv:
     alg_taps: int = 0        # taps of the REFERENCE op when the packed weights are a folded form (0: kT*kH*kW)
     time_folds: bool = False  # packed with the time-fold slots (pack_weight_tfolds / pack_weight_upfold(time_folds=True))
     wscale: float = 1.0       # fp32 (split-precision) weights were packed as w * wscale (a power of two); conv() undoes it
-    dt: int = -1              # dtype code of the packed layout (L.F32 / L.F32Q for fp32 weights); -1: that of the input tensor
+    dt: int = -1              # dtype code of the packed layout (L.F32 / L.F32Q / L.F32Q6 for fp32 weights); -1: that of the input tensor
+    act_bound: float = 0.0    # L.F32Q6 weights: upper bound of |operand| after the prologue (set by whoever knows the GroupNorm affine)
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], k: Tuple[int, int, int], cin_pad: Optional[int] = None,
@@ -322,10 +327,12 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
         assert residual is None and shortcut is None and not upsample2x and stride[2] == 1
     else:
         assert pw.k != (3, 3, 1), "(3,3,1) weights are the row-packed first layer: conv(..., row_packed=True)"
-    if dt == L.F32 and pw.dt == L.F32Q:  # the layout the weights were packed in selects the fp32 arithmetic of this launch
+    if dt == L.F32 and pw.dt in (L.F32Q, L.F32Q6):  # the layout the weights were packed in selects the fp32 arithmetic of this launch
         if shortcut is not None:
             raise ValueError("fast-fp32 weights (CVVAE_F32Q) have no fused-shortcut kernel: run the 1x1 shortcut as its own launch")
-        dt = L.F32Q
+        if pw.dt == L.F32Q6 and not (pw.act_bound > 0.0 and prologue == L.PRO_GN_SILU):
+            raise ValueError("fp6-correction weights (CVVAE_F32Q6) go with the GroupNorm + SiLU prologue and a PackedConv.act_bound > 0")
+        dt = pw.dt
     B, Ti, Hi, Wi, Cs = x.shape
     assert row_packed or Cs >= pw.cin, f"input has {Cs} channels, packed weights consume {pw.cin}"
     kT, kH, kW = pw.k
@@ -341,6 +348,7 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, pw.cin
     d.in_pix_stride = Cs
     d.in_overlap = 1 if row_packed else 0
+    d.act_bound = float(pw.act_bound) if dt == L.F32Q6 else 0.0
     if pw.folded != (upsample2x == 2):
         raise ValueError("folded upsample weights (pack_weight_upfold) go with upsample2x=2 and only with it")
     d.upsample2x = int(upsample2x)

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 8
+#define CVVAE_ABI_VERSION 9
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
@@ -33,8 +33,15 @@ extern "C" {
  * (Whi.hi on the fp16 MFMA + bf8(Whi).bf8(lo) + bf8(Wlo).bf8(hi) on v_mfma_f32_32x32x64_f8f6f4, one per pair of taps): ~2^-14
  * relative error per product at 2x the MFMA time of a 16-bit model -- the CHEAPEST mode that meets the 1e-3 bound.  It exists
  * for convolutions with more than one tap (cvvae_pack_weights* and cvvae_conv_fwd* with kH*kW > 1, no fused shortcut); 1x1x1
- * layers of such a model run as CVVAE_F32.  Every other entry point takes CVVAE_F32 for float tensors. */
-enum { CVVAE_F16 = 0, CVVAE_BF16 = 1, CVVAE_F32 = 2, CVVAE_F32Q = 3 };
+ * layers of such a model run as CVVAE_F32.  Every other entry point takes CVVAE_F32 for float tensors.
+ * CVVAE_F32Q6 = CVVAE_F32Q with the correction terms in the 6-bit format "bf6" (OCP MX e3m2) at FOUR times the fp16 rate per K
+ * element (1.5x the MFMA time of a 16-bit model; same ~2^-14 relative error per product: the corrections only need 2-3 mantissa
+ * bits).  e3m2 spans 9 binades, so the operands are scaled: the weights per output channel and pair of taps by the packer (the MFMA's
+ * block scales), the activations by ONE power of two per launch derived from cvvae_conv_desc.act_bound, an upper bound of the
+ * magnitude of the conv's operand (after the prologue) that the caller supplies -- e.g. 8 max|gamma| + max|beta| behind a
+ * GroupNorm.  Values beyond the bound saturate in the CORRECTION terms only (those products fall back to ~2^-11 relative error).
+ * Exists for the stride-1 3x3x3 and 1x3x3 convolutions with the GroupNorm + SiLU prologue; weights packed with the SAME dtype code. */
+enum { CVVAE_F16 = 0, CVVAE_BF16 = 1, CVVAE_F32 = 2, CVVAE_F32Q = 3, CVVAE_F32Q6 = 4 };
 enum { CVVAE_PAD_ZERO = 0, CVVAE_PAD_REPLICATE = 1 };         /* out-of-range taps */
 enum { CVVAE_PRO_NONE = 0, CVVAE_PRO_GN_SILU = 1, CVVAE_PRO_GN = 2 };   /* fused prologue on the input */
 enum { CVVAE_OUT_NDHWC = 0, CVVAE_OUT_NCDHW = 1, CVVAE_OUT_TIME_SHUFFLE = 2 };
@@ -68,7 +75,7 @@ static inline int cvvae_conv_kchunk(int kT, int kH, int kW) {
  *   nn.Linear / 1x1 Conv2d of the attention blocks (kT=kH=kW=1)
  */
 typedef struct cvvae_conv_desc {
-  int32_t dtype;              /* CVVAE_F16 | CVVAE_BF16: input, weights, residual, (non-f32) output; CVVAE_F32 / CVVAE_F32Q: float
+  int32_t dtype;              /* CVVAE_F16 | CVVAE_BF16: input, weights, residual, (non-f32) output; CVVAE_F32 / CVVAE_F32Q / CVVAE_F32Q6: float
                                * input / residual / shortcut input / output, weights packed from float with the SAME dtype code */
   /* input, NDHWC, as stored */
   int32_t B, Ti, Hi, Wi;
@@ -108,7 +115,7 @@ typedef struct cvvae_conv_desc {
    * (dx, c) = the three kW taps x 4 channel slots: K = 9 x 16 = 144 per output instead of 27 x 16 = 432 with the channels
    * padded 3 -> 16, and a 36 MB instead of a 142 MB input at 17 x 512^2.  The buffer must stay readable 32 bytes past its end. */
   int32_t in_overlap;
-  int32_t reserved0;
+  float act_bound;            /* CVVAE_F32Q6 only: upper bound (> 0) of |operand| after the prologue; 0 otherwise */
 } cvvae_conv_desc;
 
 /* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */

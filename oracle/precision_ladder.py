@@ -11,6 +11,10 @@ unmodified fp32 run on the same seeded weights and input (latent = posterior mea
   w-xhi        weights exact (hi + lo), operands fp16                      (2 MFMAs: Whi.hi + Wlo.hi, rung (iii))
   hi+fp8       Whi.hi + fp8(Whi).fp8(lo) + fp8(Wlo).fp8(hi)                (1 fp16 MFMA + 1 fp8 MFMA of twice the K: "2 MFMAs")
   hi+bf8       the same with unscaled e5m2 operands (the device form, CVVAE_F32 "fast": conv_kernel.h XQ)
+  hi+fp6 *     the same with e3m2 (fp6 "bf6") operands at FOUR times the fp16 rate (1 fp16 MFMA + 1 fp6 MFMA of 4x the K: "1.5
+               MFMAs"): weights scaled per output channel, activations by ONE static scale per layer = 28 / (k * rms of the
+               operand) -- k = 8: a bound a host can derive from the GroupNorm affine; k = 32: a bound four times too loose;
+               "max": the tensor's true maximum (what a statistics pass would give)
   x3           Whi.hi + Whi.lo + Wlo.hi                                    (3 MFMAs: the fp32 model's split precision)
 
     python -m oracle.precision_ladder [sd3|vae3d] [T H W]
@@ -44,6 +48,17 @@ def r8(t, fmt):
     return (t * s).to(dt).float() / s
 
 
+def q_e3m2(t, bound):
+    """e3m2 (2 mantissa bits, normals 0.25 .. 28, subnormal quantum 0.0625, saturating) after the power-of-two scale that puts
+    `bound` (a tensor broadcastable to t, or a float) at or below 28"""
+    bound = torch.as_tensor(bound, dtype=t.dtype).clamp_min(1e-30)
+    s = torch.exp2(torch.floor(torch.log2(28.0 / bound)))
+    a = (t.abs() * s).clamp(max=28.0)
+    e = torch.floor(torch.log2(a.clamp_min(1e-30))).clamp(min=-2.0)
+    qn = torch.exp2(e - 2.0)
+    return torch.sign(t) * torch.round(a / qn) * qn / s
+
+
 class Mode:
     def __init__(self, name, w="f16", x="f16", store="f32", fp8=None):
         self.name, self.w, self.x, self.store, self.fp8 = name, w, x, store, fp8
@@ -57,6 +72,9 @@ MODES = [
     Mode("hi+fp8 e5m2", fp8="e5m2"),
     Mode("hi+fp8 e4m3", fp8="e4m3"),
     Mode("hi+bf8", fp8="bf8"),
+    Mode("hi+fp6 max", fp8="fp6:max"),
+    Mode("hi+fp6 8rms", fp8="fp6:8"),
+    Mode("hi+fp6 32rms", fp8="fp6:32"),
     Mode("x3", w="x3", x="x3"),
 ]
 
@@ -81,6 +99,15 @@ def instrument(model, mode):
                 wsh = r16(w * k)
                 wsl = r16(w * k - wsh)
                 y = (op(xh, wsh) + op(b8(r16(xl)), b8(wsh)) + op(b8(x), b8(wsl))) / k
+            elif mode.fp8.startswith("fp6"):
+                k = 2.0 ** (9 - int(torch.floor(torch.log2(w.abs().max())).item()))
+                wsh = r16(w * k)
+                wsl = r16(w * k - wsh)
+                red = tuple(range(1, w.dim()))
+                pol = mode.fp8.split(":")[1]
+                xb = float(x.abs().max()) if pol == "max" else float(pol) * float((x.double() ** 2).mean().sqrt())
+                y = (op(xh, wsh) + op(q_e3m2(r16(xl), xb * 2.0 ** -11), q_e3m2(wsh, wsh.abs().amax(red, keepdim=True)))
+                     + op(q_e3m2(xh, xb), q_e3m2(wsl, wsl.abs().amax(red, keepdim=True)))) / k
             elif mode.fp8:
                 y = op(xh, wh) + op(r8(xl, mode.fp8), r8(wh, mode.fp8)) + op(r8(xh, mode.fp8), r8(wl, mode.fp8))
             elif mode.w == "x3":
@@ -127,7 +154,10 @@ def main(argv):
     z0 = base.encode(x).latent_dist.mode()
     r0 = base.decode(z0).sample
     print(f"{family} T={T} {H}x{W}: latent {tuple(z0.shape)} std {float(z0.std()):.3f}", flush=True)
+    only = os.environ.get("LADDER_ONLY")
     for mode in MODES:
+        if only and not any(o in mode.name for o in only.split(",")):
+            continue
         m = build()
         instrument(m, mode)
         z = m.encode(x).latent_dist.mode()

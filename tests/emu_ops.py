@@ -29,6 +29,7 @@ class FakePacked:
     wscale: float = 1.0
     alg_taps: int = 0
     dt: int = -1
+    act_bound: float = 0.0
 
 
 @dataclass
@@ -39,6 +40,9 @@ class FakePart:
     groups: int
     frames: int = 0
     slabs: int = 0
+
+
+Q6_CALLS = []  # (max |operand|, bound) of every emulated CVVAE_F32Q6 launch
 
 
 def _bias(cout, bias, dev):
@@ -57,7 +61,8 @@ def pack_weight(w, bias, k, cin_pad=None, strides=None, cout=None, cin=None, fol
     # (the power-of-two pack scale of fp32 weights is recorded as the real packer records it -- the host logic reads it, e.g. the
     #  fused-shortcut range check -- but the emulated weights stay unscaled: conv() below never divides by it)
     ws = (ops._wscale(w) if wscale is None else float(wscale)) if w.dtype == torch.float32 else 1.0
-    return FakePacked(w.detach().float().reshape(co, ci, taps), _bias(co, bias, w.device), co, cp, tuple(k), ci, wscale=ws)
+    return FakePacked(w.detach().float().reshape(co, ci, taps), _bias(co, bias, w.device), co, cp, tuple(k), ci, wscale=ws,
+                      dt=ops._pack_dt(w, k[1] * k[2], fast))
 
 
 def ncdhw_to_rowpack(x, dtype, pad_mode_w):
@@ -108,7 +113,7 @@ def pack_weight_rowpack(w, bias, time_folds=False):
 def pack_weight_tfolds(w, bias, cin_pad=None, fast=False):
     """the summed time slots only change HOW boundary frames are multiplied, not the result: the plain weight"""
     co, ci, _, kh, kw = w.shape
-    pw = pack_weight(w.reshape(co, ci, 3 * kh * kw), bias, (3, kh, kw), cin_pad=cin_pad)
+    pw = pack_weight(w.reshape(co, ci, 3 * kh * kw), bias, (3, kh, kw), cin_pad=cin_pad, fast=fast)
     pw.time_folds = True
     return pw
 
@@ -206,6 +211,9 @@ def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.
         if prologue == L.PRO_GN_SILU:
             a = F.silu(a)
         a = a.to(x.dtype).float()  # the kernel stages the activation in the storage dtype
+    if pw.dt == L.F32Q6:  # fp6 corrections: the host supplies a bound of the operand (ops.conv raises without one)
+        assert prologue == L.PRO_GN_SILU and pw.act_bound > 0.0 and shortcut is None and tuple(stride) == (1, 1, 1)
+        Q6_CALLS.append((float(a.abs().max()), pw.act_bound))
     if pw.batch_stride:
         assert pw.k == (1, 1, 1) and pw.w.shape[0] == B
         y = torch.einsum("bthwc,boc->bthwo", a, pw.w)

@@ -29,9 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from cvvae_amd import _lib
-    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, 2 x i32 = 160 bytes (ABI 8)
+    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, 2 x i32 + f32 = 160 bytes (ABI 9)
     assert ctypes.sizeof(_lib.ConvDesc) == 160 and _lib.ConvDesc.w_batch_stride.offset == 128
-    assert _lib.ConvDesc.in_overlap.offset == 152
+    assert _lib.ConvDesc.in_overlap.offset == 152 and _lib.ConvDesc.act_bound.offset == 156
     assert _lib.ConvDesc.sc_Cin.offset == 136 and _lib.ConvDesc.sc_in_pix_stride.offset == 144
     assert _lib.ConvDesc.in_pix_stride.offset == 24 and _lib.ConvDesc.out_pix_stride.offset == 112
     assert _lib.ConvDesc.alpha.offset == 120
@@ -48,6 +48,16 @@ def test_argument_checks_without_gpu():
     d.sT = d.sH = d.sW = 1
     d.To, d.Ho, d.Wo, d.Cout, d.out_pix_stride, d.gn_rows_per_batch = 5, 16, 16, 128, 128, 1
     assert lib.cvvae_conv_kernel_name(d).decode().startswith("conv_k333_s111")
+    # fp6-correction instances: fp32 tensors, GroupNorm + SiLU prologue, and a bound of the operand from the caller
+    d.dtype, d.prologue, d.pad_t, d.pad_h, d.pad_w, d.pad_mode_t, d.pad_mode_hw = _lib.F32Q6, 1, 1, 1, 1, 1, 1
+    assert lib.cvvae_conv_kernel_name(d) is None  # act_bound missing
+    d.act_bound = 8.0
+    assert lib.cvvae_conv_kernel_name(d).decode().endswith("_xq6")
+    d.prologue = 0
+    assert lib.cvvae_conv_kernel_name(d) is None  # no instance without the prologue
+    d.dtype, d.prologue = _lib.F32Q, 0
+    assert lib.cvvae_conv_kernel_name(d) is None  # a bound with any other dtype is an argument error
+    d.act_bound, d.dtype = 0.0, 1
     d.kT = 5
     assert lib.cvvae_conv_fwd(d, 1, 1, 1, None, None, None, 1, None) == -2  # unsupported kernel size
     assert lib.cvvae_packed_weight_bytes(128, 128, 27) == 128 * 128 * 27 * 2 + 16384

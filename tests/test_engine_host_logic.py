@@ -227,3 +227,34 @@ def test_ldm_2d_wrappers_import_path_and_state_dict():
             assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == {k: tuple(v.shape) for k, v in theirs.state_dict().items()}
     with pytest.raises(NotImplementedError):
         EncoderWith3DWrapper(**dict(LDM_CFG, attn_resolutions=[32]))
+
+
+@pytest.mark.parametrize("name", ["sd3_t5_64", "vae3d_t5_64"])
+def test_fast_fp32_fp6_launch_plumbing(name, golden_dir, monkeypatch):
+    """fp32_mode = "fast": the convs behind a GroupNorm + SiLU prologue take the fp6-correction form (CVVAE_F32Q6) with a bound
+    derived from the norm's affine -- every such launch carries a bound, the seeded operands stay inside it, everything else stays
+    on the bf8 form (CVVAE_F32Q) or the three-MFMA one; CVVAE_F32_FP6=0 switches the fp6 form off"""
+    from cvvae_amd import _lib as L
+    family, over, shape, wseed, xseed = CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    for fp6 in ("1", "0"):
+        monkeypatch.setenv("CVVAE_F32_FP6", fp6)
+        m = build(family, over, wseed)
+        m.fp32_mode = "fast"
+        del emu_ops.Q6_CALLS[:]
+        with emu_ops.patched(whole_model=True), torch.no_grad():
+            post = m.encode(seeded_input(shape, xseed)).latent_dist
+            rec = m.decode(post.mode()).sample
+        assert np.abs(post.parameters.numpy() - gold["moments"]).max() <= TOL and np.abs(rec.numpy() - gold["recon"]).max() <= TOL
+        dts = {}
+        for sub in (m.encoder, m.decoder):
+            for tag, ent in sub._wc._c.items() if hasattr(sub, "_wc") else []:
+                if len(ent) >= 3 and hasattr(ent[1], "dt"):
+                    dts.setdefault(ent[1].dt, []).append(tag)
+        if fp6 == "1":
+            assert emu_ops.Q6_CALLS and all(0.0 < mx <= bound for mx, bound in emu_ops.Q6_CALLS), emu_ops.Q6_CALLS[:4]
+            if dts:
+                assert dts.get(L.F32Q6) and all(t.endswith("#q6") for t in dts[L.F32Q6])
+                assert all(".conv1" in t or ".conv2" in t for t in dts[L.F32Q6])  # resnet convs only
+        else:
+            assert not emu_ops.Q6_CALLS and L.F32Q6 not in dts

@@ -106,6 +106,76 @@ def test_fast_is_between_fp16_and_exact():
     assert errs["exact"] * 4 < errs["fast"] < errs["f16"] / 4, errs
 
 
+# ---- fp6 corrections (CVVAE_F32Q6, conv_kernel.h XP == 3): the GroupNorm + SiLU prologue instances
+@pytest.mark.parametrize("mode", [(REP, REP), (ZERO, ZERO), (REP, ZERO)])
+@pytest.mark.parametrize("Cio", [(256, 256), (128, 128), (128, 3)])
+def test_fp6_conv333_prologue(mode, Cio):
+    L = _ops()[1]
+    run_conv_case(F32, Cio[0], Cio[1], (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), mode[0], mode[1], (2, 4, 20, 36), prologue=1,
+                  out_mode=L.OUT_NCDHW if Cio[1] <= 32 else L.OUT_NDHWC, fast="fp6")
+
+
+@pytest.mark.parametrize("tpad", [(2, 0), (1, 1)])
+@pytest.mark.parametrize("T", [1, 2, 5])
+def test_fp6_conv333_time_folds(tpad, T):
+    run_conv_case(F32, 128, 256, (3, 3, 3), (1, 1, 1), (tpad, (1, 1), (1, 1)), REP, REP, (1, T, 16, 40), prologue=1,
+                  time_folds=True, tol=2 * 3 * FAST_ULP, fast="fp6")
+
+
+@pytest.mark.parametrize("Cout", [128, 256, 512])
+def test_fp6_conv133_prologue_residual(Cout):
+    run_conv_case(F32, Cout, Cout, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, (2, 3, 24, 40), prologue=1,
+                  residual=True, fast="fp6")
+
+
+def test_fp6_matches_bf8_and_degrades_gracefully_with_the_bound():
+    """same rung of the ladder as the bf8 form when the bound is right or 4x too loose; a bound far too TIGHT saturates the correction
+    terms of the large elements only -- the result falls back towards the fp16 model's error, never beyond it"""
+    args = (F32, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (1, 4, 20, 36))
+    e = {"bf8": run_conv_case(*args, prologue=1, fast=True, tol=1.0),
+         "fp6": run_conv_case(*args, prologue=1, fast="fp6", tol=1.0),
+         "fp6 loose": run_conv_case(*args, prologue=1, fast="fp6", tol=1.0, act_bound=4 * 9.0),
+         "fp6 tight": run_conv_case(*args, prologue=1, fast="fp6", tol=1.0, act_bound=0.05),
+         "f16": run_conv_case(torch.float16, *args[1:], prologue=1, tol=1.0)}
+    print("relative max error of one 256->256 3x3x3 conv with fused GN+SiLU:", e)
+    assert e["fp6"] <= 1.5 * e["bf8"] and e["fp6 loose"] <= 2.5 * e["bf8"], e
+    assert e["fp6 tight"] <= 1.2 * e["f16"], e
+
+
+def test_fp6_needs_prologue_and_bound():
+    ops, L = _ops()
+    w = rnd((128, 128, 3, 3, 3), F32, 1, 0.05).to(DEV)
+    pw = ops.pack_weight(w, None, (3, 3, 3), fast="fp6")
+    assert pw.dt == L.F32Q6
+    x = torch.zeros(1, 3, 8, 32, 128, device=DEV)
+    with pytest.raises(ValueError):
+        ops.conv(x, pw, pad=((1, 1), (1, 1), (1, 1)))
+    pw.act_bound = 8.0
+    with pytest.raises(ValueError):
+        ops.conv(x, pw, pad=((1, 1), (1, 1), (1, 1)))  # no GroupNorm + SiLU prologue: no bound to speak of
+
+
+@pytest.mark.parametrize("family", ["sd3", "vae3d"])
+def test_fp6_model_equals_bf8_model_within_the_rung(family, golden_dir, monkeypatch):
+    """whole model: fast mode with the fp6 form behind every GroupNorm + SiLU (the default) vs bf8 everywhere -- both inside
+    north_star's bound, within 2x of each other"""
+    import cvvae_amd
+    from oracle import parity as P
+    name = f"{family}_t5_64"
+    cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
+    r = {}
+    for fp6 in ("1", "0"):
+        monkeypatch.setenv("CVVAE_F32_FP6", fp6)
+        m = cls()
+        P.load_seeded(m, P.case_of(name)[3])
+        m = m.to(F32).cuda().eval()
+        m.fp32_mode = "fast"
+        r[fp6] = P.measure(m, name, golden_dir)
+        print("\n" + P.fmt("f32q fp6=" + fp6, r[fp6]))
+    assert r["1"]["latent_max_abs"] <= 1.0e-3 and r["1"]["recon_psnr_db"] >= 80.0, r["1"]
+    assert r["1"]["latent_max_abs"] <= 2.0 * r["0"]["latent_max_abs"] + 1e-5, r
+
+
 def test_fast_rejects_what_it_has_no_kernel_for():
     ops, L = _ops()
     w = rnd((128, 128, 1, 1, 1), F32, 1, 0.1).to(DEV)

@@ -45,8 +45,9 @@ def ref_pad(x, pad, mode_t, mode_hw):
 
 
 def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prologue=0, ups=False, out_mode=0,
-                  residual=False, seed=0, tol=None, time_folds=False, fast=False):
-    """fast (fp32 only): weights packed for the fast-fp32 kernels (CVVAE_F32Q: fp16 MFMA + bf8 correction MFMA)"""
+                  residual=False, seed=0, tol=None, time_folds=False, fast=False, act_bound=None):
+    """fast (fp32 only): weights packed for the fast-fp32 kernels (True: CVVAE_F32Q, fp16 MFMA + bf8 correction MFMA; "fp6":
+    CVVAE_F32Q6, e3m2 corrections, with act_bound -- default 8 max|gamma| + max|beta|, what engine.WeightCache derives)"""
     ops, L = _ops()
     if dtype == torch.float32 and ups is True:
         pytest.skip("the 27-tap gather form of the upsample conv (CVVAE_FOLD_UPSAMPLE=0 tuning path) has no split-precision instance")
@@ -94,6 +95,9 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         gn = ops.gn_stats(xd, g.to(DEV), bb.to(DEV), 1e-6)
     if ups == 2:
         pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), time_folds=time_folds, fast=fast)
+    if fast == "fp6":
+        assert pw.dt == L.F32Q6
+        pw.act_bound = float(8.0 * gamma.abs().max() + beta.abs().max()) if act_bound is None else act_bound
     out = ops.conv(xd, pw, stride=stride, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=prologue, gn=gn,
                    residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode)
     torch.cuda.synchronize()

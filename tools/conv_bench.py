@@ -1,6 +1,8 @@
 #!/usr/bin/env python
 """Micro-benchmark of single conv launches (tuning aid; also the command profiled for profiles/*pmc*).
-usage: python tools/conv_bench.py [case ...] [--iters N] [--dtype bf16|f16]
+usage: python tools/conv_bench.py [case ...] [--iters N] [--dtype bf16|f16|f32|f32q|f32q6|f32ab]
+(f32 = three fp16 MFMAs per product, f32q = fp16 + bf8 corrections, f32q6 = fp16 + fp6 corrections where an instance exists,
+f32ab = the last two interleaved: labels +q / +q6)
 cases are the cfg-3 layer shapes of SURVEY.md 2.3."""
 import argparse
 import os
@@ -76,15 +78,24 @@ def main():
     ap.add_argument("--tfolds", action="store_true", help="also time every 3x3x3 case with the time-fold weight slots (force label +tf)")
     a = ap.parse_args()
     forces = a.force or [""]
-    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float16
+    dt = torch.bfloat16 if a.dtype == "bf16" else (torch.float16 if a.dtype == "f16" else torch.float32)
+    fasts = {"f32": [("", False)], "f32q": [("", True)], "f32q6": [("", "fp6")], "f32ab": [("+q", True), ("+q6", "fp6")]}.get(a.dtype, [("", False)])
     for name in a.cases:
         cin, cout, k, T, H, W, pad, pro, ups = CASES[name]
         x = (torch.rand((1, T, H, W, cin), device="cuda") * 2 - 1).to(dt)
         w = (torch.rand((cout, cin) + k, device="cuda") * 2 - 1).to(dt) / (cin * k[0] * k[1] * k[2]) ** 0.5
-        if ups == 2:
-            pw = ops.pack_weight_upfold(w, torch.zeros(cout, device="cuda"))
-        else:
-            pw = ops.pack_weight(w.reshape(cout, cin, -1), torch.zeros(cout, device="cuda"), k)
+        def packed(fast, tf=False):
+            fast = True if (fast == "fp6" and not (pro == 1 and not ups and k in ((3, 3, 3), (1, 3, 3)) and not name.startswith("down"))) else fast
+            if ups == 2:
+                q = ops.pack_weight_upfold(w, torch.zeros(cout, device="cuda"), time_folds=tf, fast=fast)
+            elif tf:
+                q = ops.pack_weight_tfolds(w, torch.zeros(cout, device="cuda"), fast=fast)
+            else:
+                q = ops.pack_weight(w.reshape(cout, cin, -1), torch.zeros(cout, device="cuda"), k, fast=fast)
+            if q.dt == L.F32Q6:
+                q.act_bound = 8.0
+            return q
+        pw = packed(fasts[0][1])
         gn = None
         if pro:
             gn = ops.gn_stats(x, torch.ones(cin, device="cuda"), torch.zeros(cin, device="cuda"), 1e-6)
@@ -99,15 +110,14 @@ def main():
             kw["gn_out"] = 32
         npix = None
         best, kname = {}, {}
-        pws = {f: pw for f in forces}
+        pws = {f + lab: packed(fast) for f in forces for lab, fast in fasts}
         if a.tfolds and k[0] == 3:
-            pwt = ops.pack_weight_upfold(w, pw.bias[:cout], time_folds=True) if ups == 2 else ops.pack_weight_tfolds(w, pw.bias[:cout])
-            pws.update({f + "+tf": pwt for f in forces})
+            pws.update({f + lab + "+tf": packed(fast, True) for f in forces for lab, fast in fasts})
         forces_c = list(pws)
         for rnd in range(a.rounds):  # interleaved rounds: A/B deltas come from one process (guide rule 24)
             for f in forces_c:
                 pw = pws[f]
-                setenv(f.replace("+tf", ""))  # (labels: FORCE[@ORDER][!ENV=VAL,...][+tf])
+                setenv(f.replace("+tf", "").replace("+q6", "").replace("+q", ""))  # (labels: FORCE[@ORDER][!ENV=VAL,...][+q|+q6][+tf])
                 ops.PROFILE = lambda d, pw_, launch, f=f: (kname.__setitem__(f, ops.conv_kernel_name(d)), launch())
                 y = ops.conv(x, pw, **kw)
                 if isinstance(y, tuple):

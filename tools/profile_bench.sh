@@ -3,6 +3,7 @@
 # (3) separate --pmc passes for the SQ counters (MFMA busy, wait buckets).  Counters are never combined with the hip/hsa trace
 # domains.  Writes text summaries under gpurun_out/prof_<tag>/ ; copy the ones to keep into profiles/.
 #   usage (on the GPU box, from the repo root):  bash tools/profile_bench.sh <tag> [extra bench args]
+#   PROFILE_CMD="python $GRAFT_REPO_ROOT/tools/conv_bench.py ..." profiles that command instead of bench.py (PROFILE_STEPS=1)
 TAG=${1:-run}
 shift
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -10,8 +11,8 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # 1 warm-up + 3 timed steps + the 2 passes of the encode/decode split = 6 steps per run
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity $*"
-STEPS=6
+BENCH=${PROFILE_CMD:-"python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-parity $*"}
+STEPS=${PROFILE_STEPS:-6}
 rocprofv3 --kernel-trace --stats -d $O/trace -o bench -- $BENCH > $O/trace.log 2>&1
 DB=$(find $O/trace -name "*.db" | head -1)
 if [ -n "$DB" ]; then python $R/tools/rocpd_summary.py $DB > $O/kernel_stats.txt 2>&1; fi
