@@ -80,10 +80,14 @@ __device__ __forceinline__ f32x16 mfma_bf8_k64(f16x8 a_lo, f16x8 a_hi, f16x8 b_l
 // of the lane's first six dwords), same lane -> (row, k) map as above; each LANE carries one E8M0 scale byte (value 2^(byte-127),
 // byte 0 of the scale operand) for its 32 elements -- the hardware's block scale (tools/fp6_probe.hip, profiles/r3_fp6_probe.txt).
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
-__device__ __forceinline__ f32x16 mfma_bf6_k64(uint4 a03, uint4 a47, uint4 b03, uint2 b45, int scale_b, f32x16 c) {
-  const i32x8_t a = {(int)a03.x, (int)a03.y, (int)a03.z, (int)a03.w, (int)a47.x, (int)a47.y, 0, 0};
-  const i32x8_t b = {(int)b03.x, (int)b03.y, (int)b03.z, (int)b03.w, (int)b45.x, (int)b45.y, 0, 0};
-  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 3, 3, 0, (int)a47.z, 0, scale_b);  // cbsz = blgp = 3: bf6
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+typedef int i32x2_t __attribute__((ext_vector_type(2)));
+// (plain ext-vector types throughout: arrays of HIP's struct-based uint4 / uint2 inside the K loop's nested lambdas were not scalarised --
+//  the backend promoted them to LDS and the loop ran 2.4x slower)
+__device__ __forceinline__ f32x16 mfma_bf6_k64(i32x4_t a03, i32x4_t a47, i32x4_t b03, i32x2_t b45, int scale_b, f32x16 c) {
+  const i32x8_t a = {a03[0], a03[1], a03[2], a03[3], a47[0], a47[1], 0, 0};
+  const i32x8_t b = {b03[0], b03[1], b03[2], b03[3], b45[0], b45[1], 0, 0};
+  return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 3, 3, 0, a47[2], 0, scale_b);  // cbsz = blgp = 3: bf6
 }
 // 16 halves (8 dwords) -> 16 bf6 codes = 96 bits, code i at bits 6i: v_cvt_scalef32_pk32_bf6_f16 (code = round-to-nearest-even of
 // value / scale, saturating at +-28; only the exponent of `scale` is used) on a 32-half operand whose upper half is don't-care
@@ -313,6 +317,16 @@ __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_r
 // GroupNorm affine as ONE fused multiply-add wherever it is evaluated (conv prologue, cvvae_gn_silu_apply): the two forms
 // must round identically
 __device__ __forceinline__ float gn_affine(float x, float sc, float sh) { return __builtin_fmaf(x, sc, sh); }
+
+// compile-time loop: f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{})
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
 
 // out-of-range tap handling: replicate = clamp, zero = flag
 __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
@@ -662,7 +676,14 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                        : (size_t)(active ? nb : 0) * (size_t)p.nchunks * (STEPS * 512) + kgrp * (STEPS_W * 512)) + lane * 8;
   // XP == 2: the ring holds the FOUR records of one pair of taps -- [0] Whi of tap a, [1], [2] the halves of the pair's bf8
   // record, [3] Whi of tap b -- each refilled with the next pair's right after its last use
-  constexpr int NWF = XP >= 2 ? 4 : PF;
+  // (XQ_DEPTH pairs in flight: with four fragments per wave a pair lasts ~400-500 clocks -- less than an L2 round trip under load,
+  //  and the MFMA phase then runs at the latency of its weight stream: measured 60 ticks per MFMA, tools/conv_probe.hip CFG 11/12)
+#ifndef CVVAE_XQ_DEPTH
+#define CVVAE_XQ_DEPTH 2
+#endif
+  constexpr int XQD = CVVAE_XQ_DEPTH;
+  static_assert(XQD == 1 || XQD == 2, "fast-fp32 weight ring: one or two pairs of taps in flight");
+  constexpr int NWF = XP >= 2 ? 4 * XQD : PF;
   static_assert(XP < 2 || TFOLD || KT == 1, "fast-fp32 instances: 3-tap time kernels walk time groups, the others have KT = 1");
   const long long wq_ks = (long long)(TFOLD ? p.w_taps : NTAPS * 3) * 512, wq_cs = wq_ks * KSUB;  // (XP == 2)
   const T* wqx = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
@@ -677,6 +698,15 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     wf[0][1] = *reinterpret_cast<const v8*>(e + 512);
     wf[0][2] = *reinterpret_cast<const v8*>(e + 1024);
     wf[0][3] = *reinterpret_cast<const v8*>(e + (KH * KW > 1 ? 3 * 512 : 0));
+    if constexpr (XQD == 2) {  // ... and pair 1 (a group holds at least two pairs)
+      constexpr int R_ = KH * KW, PR_ = (R_ + 1) / 2;
+      static_assert(PR_ * KSUB >= 2, "two pairs per time group");
+      const T* e1 = e + (long long)(1 / PR_) * wq_ks + 2 * (1 % PR_) * (3 * 512);
+      wf[0][4] = *reinterpret_cast<const v8*>(e1);
+      wf[0][5] = *reinterpret_cast<const v8*>(e1 + 512);
+      wf[0][6] = *reinterpret_cast<const v8*>(e1 + 1024);
+      wf[0][7] = *reinterpret_cast<const v8*>(e1 + ((2 * (1 % PR_) + 1 < R_) ? 3 * 512 : 0));
+    }
   } else {
 #pragma unroll
     for (int n = 0; n < NB; ++n)
@@ -745,71 +775,84 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         v8 fa[MREP], fb[MREP], qa[MREP], qb[MREP];
         // XP == 3: ONE bf6 operand per fragment -- 24 bytes of the LANE's tap (lanes 0-31: tap a, lanes 32-63: tap b of the pair):
         // [lo * 2^11 | hi] codes of the pixel's 16 channels
-        uint4 q6a[XP == 3 ? MREP : 1];
-        uint2 q6b[XP == 3 ? MREP : 1];
+        i32x4_t q6a[XP == 3 ? MREP : 1];
+        i32x2_t q6b[XP == 3 ? MREP : 1];
         const unsigned aq6 = XP == 3 ? 32u - (unsigned)((lane >> 5) * 16) : 0u;  // (aoff[] carries the fp16 k split: undo it)
         const bool lhi = lane >= 32;
 #pragma unroll
         for (int r = 0; r < MREP; ++r) fa[r] = *reinterpret_cast<const v8*>(&smem[lb + (TFOLD ? tf_l0 : 0u) + aoff[r]]);
-        for (int g = 0; g < ngq; ++g) {
+        auto group_body = [&](int g) __attribute__((always_inline)) {
           const unsigned lbg = lb + (TFOLD ? (g == 0 ? tf_l0 : (g == 1 ? tf_l1 : tf_l2)) : 0u);
           const T* wg = wcb + (TFOLD ? (g == 0 ? tf_w0 : (g == 1 ? tf_w1 : tf_w2)) : 0);
           const bool lastg = g + 1 == ngq;
           const T* wn = lastg ? wnx + (TFOLD ? tf_w0 : 0) : wcb + (g == 0 ? tf_w1 : tf_w2);  // pair 0 of the next group / chunk
           const unsigned lbn = lb + (g == 0 ? tf_l1 : tf_l2);
-#pragma unroll
-          for (int q = 0; q < NPAIR; ++q) {
-            const int ks = q / PR, ta = 2 * (q % PR), tb = ta + 1;
-            const bool hasb = tb < R, lastq = q + 1 == NPAIR;
+          static_for<NPAIR>([&](auto q_tag) __attribute__((always_inline)) {
+            constexpr int q = decltype(q_tag)::value;
+            constexpr int ks = q / PR, ta = 2 * (q % PR), tb = ta + 1;
+            constexpr bool hasb = tb < R, lastq = q + 1 == NPAIR;
             const unsigned oa = (unsigned)(((ta / KW) * G::FW + (ta % KW)) * PIXB + ks * 64);
             const unsigned ob = (unsigned)(((tb / KW) * G::FW + (tb % KW)) * PIXB + ks * 64);
             const int nks = (q + 1) / PR, nta = 2 * ((q + 1) % PR);
-            const T* ne = lastq ? wn : wg + (long long)nks * wq_ks + nta * (3 * 512);  // record [0] of the next pair
-            const bool nhasb = lastq ? (R > 1) : (nta + 1 < R);
             const unsigned ona = (unsigned)(((nta / KW) * G::FW + (nta % KW)) * PIXB + nks * 64);
+            // The pair whose records refill this pair's ring slots: XQD pairs ahead, in this group or the next one.  Two pairs in
+            // flight: even pairs live in ring set 0, odd pairs in set 1.  A group with an ODD pair count ends on an even pair, and
+            // the next group starts on one: its last two pairs swap their refills (the second-to-last fetches the next group's
+            // pair 1, three pairs ahead; the last one the next group's pair 0, one pair ahead) -- the sets stay static.
+            constexpr int qf = q + XQD;
+            constexpr bool wrapf = qf >= NPAIR;
+            constexpr int qw = qf - NPAIR;
+            constexpr int qq = !wrapf ? qf : ((XQD == 2 && (NPAIR & 1)) ? 1 - qw : qw);
+            constexpr int fks = qq / PR, fta = 2 * (qq % PR);
+            const T* ne = (wrapf ? wn : wg) + (long long)fks * wq_ks + fta * (3 * 512);  // its record [0]
+            constexpr bool nhasb = fta + 1 < R;
+            constexpr int S = XQD == 2 ? 4 * (q & 1) : 0;  // this pair's ring set
             const unsigned oq6 = (hasb && lhi ? ob : oa) + aq6;  // XP == 3: my tap's pixel (an unpaired tap: both halves read tap a)
+            // (requesting the LDS fragments two sub-steps ahead instead of one -- correction operands during the tap-a products, the
+            //  next pair's tap a during tap b, its tap b during the corrections -- measured 3-6 % SLOWER: the loop does not wait on LDS)
             // Whi.hi of tap a
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
-              acc[r] = Tr<T>::mfma(wf[0][0], fa[r], acc[r]);
+              acc[r] = Tr<T>::mfma(wf[0][S + 0], fa[r], acc[r]);
               if (hasb) fb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob]);
               else if constexpr (XP == 3) {
-                q6a[r] = *reinterpret_cast<const uint4*>(&smem[lbg + aoff[r] + oq6]);
-                q6b[r] = *reinterpret_cast<const uint2*>(&smem[lbg + aoff[r] + oq6 + 16]);
+                q6a[r] = *reinterpret_cast<const i32x4_t*>(&smem[lbg + aoff[r] + oq6]);
+                q6b[r] = *reinterpret_cast<const i32x2_t*>(&smem[lbg + aoff[r] + oq6 + 16]);
               } else qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
             }
-            wf[0][0] = *reinterpret_cast<const v8*>(ne);
+            wf[0][S + 0] = *reinterpret_cast<const v8*>(ne);
             __builtin_amdgcn_sched_barrier(0);
             if (hasb) {  // Whi.hi of tap b
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
-                acc[r] = Tr<T>::mfma(wf[0][3], fb[r], acc[r]);
+                acc[r] = Tr<T>::mfma(wf[0][S + 3], fb[r], acc[r]);
                 if constexpr (XP == 3) {
-                  q6a[r] = *reinterpret_cast<const uint4*>(&smem[lbg + aoff[r] + oq6]);
-                  q6b[r] = *reinterpret_cast<const uint2*>(&smem[lbg + aoff[r] + oq6 + 16]);
+                  q6a[r] = *reinterpret_cast<const i32x4_t*>(&smem[lbg + aoff[r] + oq6]);
+                  q6b[r] = *reinterpret_cast<const i32x2_t*>(&smem[lbg + aoff[r] + oq6 + 16]);
                 } else {
                   qa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + oa + 32]);
                   qb[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ob + 32]);
                 }
               }
             }
-            wf[0][3] = *reinterpret_cast<const v8*>(ne + (nhasb ? 3 * 512 : 0));
+            wf[0][S + 3] = *reinterpret_cast<const v8*>(ne + (nhasb ? 3 * 512 : 0));
             __builtin_amdgcn_sched_barrier(0);
             // q(Whi).q(lo) + q(Wlo).q(hi) of both taps (bf8: K = 64 at twice the fp16 rate; bf6: four times)
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
               if constexpr (XP == 3)
-                acc[r] = mfma_bf6_k64(__builtin_bit_cast(uint4, wf[0][1]), __builtin_bit_cast(uint4, wf[0][2]), q6a[r], q6b[r], p.q6_eb, acc[r]);
+                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), q6a[r], q6b[r], p.q6_eb, acc[r]);
               else
-                acc[r] = mfma_bf8_k64(wf[0][1], wf[0][2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
+                acc[r] = mfma_bf8_k64(wf[0][S + 1], wf[0][S + 2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
               if (!lastq) fa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ona]);
               else if (!lastg) fa[r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
-            wf[0][1] = *reinterpret_cast<const v8*>(ne + 512);
-            wf[0][2] = *reinterpret_cast<const v8*>(ne + 1024);
+            wf[0][S + 1] = *reinterpret_cast<const v8*>(ne + 512);
+            wf[0][S + 2] = *reinterpret_cast<const v8*>(ne + 1024);
             __builtin_amdgcn_sched_barrier(0);
-          }
-        }
+          });
+        };
+        for (int g = 0; g < ngq; ++g) group_body(g);
       }
     } else if constexpr (TFOLD) {
       if (active) {

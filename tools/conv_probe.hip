@@ -27,6 +27,25 @@ static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #elif CFG == 3 // enc128 2-frame tile
 #define INST 3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0
 static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 10 // enc128 2-frame tile WITHOUT prologue: what the staging costs with no GroupNorm + SiLU arithmetic
+#define INST 3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 0,0
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 11 // enc128 fast fp32, bf8 corrections (XP = 2)
+#define INST 3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0
+#define XPV 2
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 12 // enc128 fast fp32, fp6 corrections (XP = 3)
+#define INST 3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0
+#define XPV 3
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 14 // enc128 fast fp32, bf8 corrections, WITHOUT prologue
+#define INST 3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 0,0
+#define XPV 2
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 13 // enc128 exact fp32 (XP = 1)
+#define INST 3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0
+#define XPV 1
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
 #elif CFG == 4 // c2d512
 #define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0
 static const int CIN = 512, COUT = 512, TT_ = 9, HH = 128, WW = 128, PT = 0;
@@ -47,18 +66,28 @@ static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #endif
 
+#ifndef XPV
+#define XPV 0
+#endif
+static const int ES = XPV ? 4 : 2, WREC = XPV ? 3 : 1;  // bytes per activation element; weight records per (k16, tap)
+
 template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int PRO, bool UPS>
 int run() {
   const int taps = KT * KH * KW;
   const size_t npix = (size_t)TT_ * HH * WW;
   void *in, *out, *w; float *bias, *gsc, *gsh; unsigned long long* dbg;
-  hipMalloc(&in, npix * CIN * 2); hipMalloc(&out, npix * COUT * 2);
-  const size_t wbytes = (size_t)((COUT + 31) / 32) * 32 * CIN * taps * 2 + WEIGHT_TAIL_BYTES;
+  hipMalloc(&in, npix * CIN * ES); hipMalloc(&out, npix * COUT * ES);
+  const size_t wbytes = (size_t)((COUT + 31) / 32) * 32 * CIN * taps * 2 * WREC + WEIGHT_TAIL_BYTES;
   hipMalloc(&w, wbytes); hipMalloc(&bias, 4 * ((COUT + 31) / 32) * 32); hipMalloc(&gsc, 4 * CIN); hipMalloc(&gsh, 4 * CIN);
   hipMalloc(&dbg, 8 * 128 * 8);
   std::vector<unsigned short> h(npix * CIN);
   srand(1);
   for (auto& v : h) v = (unsigned short)(0x3c00 + (rand() & 0x3ff)) | ((rand() & 1) << 15);  // bf16 in +-[0.0078, 0.0156): random bits
+  if (XPV) {
+    std::vector<float> hf(npix * CIN);
+    for (auto& v : hf) v = (float)((rand() & 0xffff) - 32768) / 32768.0f;
+    hipMemcpy(in, hf.data(), npix * CIN * 4, hipMemcpyHostToDevice);
+  } else
   hipMemcpy(in, h.data(), npix * CIN * 2, hipMemcpyHostToDevice);
   std::vector<unsigned short> hw(wbytes / 2);
   for (auto& v : hw) v = (unsigned short)(0x3a00 + (rand() & 0x3ff)) | ((rand() & 1) << 15);
@@ -74,7 +103,8 @@ int run() {
   a.pt = PT; a.ph = 1; a.pw = 1; a.mode_t = 1; a.mode_hw = KT == 3 ? 1 : 0;
   a.tiles_t = (TT_ + TT - 1) / TT; a.tiles_h = HH / TH; a.tiles_w = WW / TW; a.ntiles_n = (COUT + 32 * WN - 1) / (32 * WN);
   a.nchunks = CIN / (16 * KSUB); a.nblk32 = (COUT + 31) / 32; a.order = 1; a.gn_rpb = 1; a.alpha = 1.f;
-  a.w_taps = taps;  // plain packed layout (no time-fold slots)
+  a.w_taps = taps * WREC;  // plain packed layout (no time-fold slots)
+  a.q6_scale = 0.5f; a.q6_eb = 128;
   const int grid = a.tiles_t * a.tiles_h * a.tiles_w * a.ntiles_n;
   if (getenv("PROBE_RES") || getenv("PROBE_STATS")) {  // PROBE_RES: residual add + fused GroupNorm statistics in the epilogue
     if (getenv("PROBE_RES")) {                          // (what a ResnetBlock conv2 does); PROBE_STATS: statistics only (conv1)
@@ -91,7 +121,7 @@ int run() {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int it = 0; it < 3; ++it) {
     hipEventRecord(e0, 0);
-    launch_conv<__bf16, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS>(a, grid, 0);
+    launch_conv<std::conditional_t<XPV != 0, _Float16, __bf16>, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XPV>(a, grid, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double fl = 2.0 * npix * COUT * CIN * taps;
