@@ -45,7 +45,12 @@ class WeightCache:
         tag = norm_pre + "#bound"
         hit = self._c.get(tag)
         if hit is None or hit[0] != key:
-            hit = (key, max(float(sigmas * g.detach().abs().max() + b.detach().abs().max()), 1e-6))
+            # ONE power of two scales every channel of the operand: channels far below the largest one would land in e3m2's
+            # subnormals and lose their corrections, so a norm whose per-channel bounds spread over more than 3 binades (max > 8 x
+            # median) returns 0.0 = "no bound": its convs keep the bf8 form, which needs no scale
+            bc = (sigmas * g.detach().abs().float() + b.detach().abs().float()).flatten()
+            top, mid = float(bc.max()), float(bc.median())
+            hit = (key, max(top, 1e-6) if top <= 8.0 * max(mid, 1e-30) else 0.0)
             self._c[tag] = hit
         return hit[1]
 
@@ -62,7 +67,7 @@ class WeightCache:
         b = self.m.get_parameter(pre + ".bias")
         key = self._key(w, b)
         q6 = (self.fast and self.fast6 and act_norm is not None and w.dtype == torch.float32 and wscale is None
-              and tuple(k) in ((3, 3, 3), (1, 3, 3)))
+              and tuple(k) in ((3, 3, 3), (1, 3, 3)) and self.act_bound(act_norm) > 0.0)
         fast = "fp6" if q6 else self.fast
         tag = (pre + "#tf" if time_folds else (pre if wscale is None else f"{pre}#ws{wscale}")) + ("#q6" if q6 else self._q())
         hit = self._c.get(tag)

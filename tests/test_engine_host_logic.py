@@ -258,3 +258,22 @@ def test_fast_fp32_fp6_launch_plumbing(name, golden_dir, monkeypatch):
                 assert all(".conv1" in t or ".conv2" in t for t in dts[L.F32Q6])  # resnet convs only
         else:
             assert not emu_ops.Q6_CALLS and L.F32Q6 not in dts
+
+
+def test_fp6_form_is_refused_when_the_norm_affine_spreads_over_many_binades():
+    """one scale per launch cannot serve channels whose bounds differ by more than 8x: such a norm's convs keep the bf8 form"""
+    from cvvae_amd import _lib as L
+    family, over, shape, wseed, xseed = CASES["sd3_t5_64"]
+    m = build(family, over, wseed)
+    m.fp32_mode = "fast"
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        z = m.encode(seeded_input(shape, xseed)).latent_dist.mode()
+        wc = m.decoder._cache()
+        name = "mid_block.resnets.0"
+        assert wc.act_bound(name + ".norm1") > 0.0
+        assert wc.conv(name + ".conv1", (3, 3, 3), time_folds=True, act_norm=name + ".norm1").dt == L.F32Q6
+        with torch.no_grad():
+            m.decoder.get_parameter(name + ".norm1.weight")[3] *= 100.0  # one loud channel
+        assert wc.act_bound(name + ".norm1") == 0.0
+        assert wc.conv(name + ".conv1", (3, 3, 3), time_folds=True, act_norm=name + ".norm1").dt == L.F32Q
+        m.decode(z)  # and the whole decoder still runs (mixed forms)
