@@ -7,7 +7,8 @@ REFERENCE's fp32 latent).  The result -- how far the reference's own fp16 / bf16
 the yardstick the GPU tolerance bands are derived from (tests/test_gpu_baseline_shapes.py) and what bench.py prints next to
 `parity`.
 
-    python -m oracle.make_noise [case ...]        -> tests/golden/ref_self_noise.json   (entries are merged, not replaced)
+    python -m oracle.make_noise [case ...] [--dtypes bf16,f16]   -> tests/golden/ref_self_noise.json   (entries are merged, not replaced)
+(fp16 on the CPU is 3x slower than bf16 on the vae3d cases and did not finish in 3.5 h on cfg 3: --dtypes bf16 skips it)
 """
 import json
 import os
@@ -41,6 +42,11 @@ class _CpuModel:
 
 
 def main(only):
+    want = ("bf16", "f16")
+    for a in list(only):
+        if a.startswith("--dtypes"):
+            only.remove(a)
+            want = tuple(a.split("=", 1)[1].split(",")) if "=" in a else want
     ref = load_reference()
     torch.set_grad_enabled(False)
     table = {}
@@ -55,6 +61,8 @@ def main(only):
             continue
         cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
         for dtype in (torch.bfloat16, torch.float16):
+            if TAG[dtype] not in want:
+                continue
             model = cls(**over).eval()
             P.load_seeded(model, wseed)
             model = model.to(dtype)
