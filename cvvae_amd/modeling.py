@@ -759,6 +759,24 @@ class _CVVAEBase(nn.Module):
         return z
 
     @torch.no_grad()
+    def decode_latents(self, z: torch.Tensor, scale_factor: Optional[float] = None, n_samples_a_time: Optional[int] = None,
+                       flatten_frames: bool = True) -> torch.Tensor:
+        """The other half of the training / sampling engines' first-stage contract: `DiffusionEngine.decode_first_stage`
+        (/root/reference/lvdm/models/diffusion.py:139-157: `z / scale_factor`, rounds of `en_and_decode_n_samples_a_time` samples,
+        `first_stage_model.decode`, cat) with the adapters of `DiffusionEngineFor3DVAE.decode_first_stage` (:369-377: image latents
+        [B,z,h,w] run as one-frame clips; the frames come back as [(B T),3,H,W]).  `flatten_frames=False` keeps clips 5-D."""
+        if z.dim() == 4:
+            z = z.unsqueeze(2)
+        sf = scale_factor if scale_factor is not None else getattr(self.config, "scaling_factor", None)
+        if sf is not None and sf != 1.0:
+            z = (1.0 / sf) * z
+        n = z.shape[0] if n_samples_a_time is None else int(n_samples_a_time)
+        x = torch.cat([self.decode(z[a:a + n]).sample for a in range(0, z.shape[0], n)], dim=0)
+        if flatten_frames and x.dim() == 5:
+            x = x.permute(0, 2, 1, 3, 4).reshape(-1, x.shape[1], *x.shape[3:])
+        return x
+
+    @torch.no_grad()
     def decode_to_frames_u8(self, z: torch.Tensor, num_frames: Optional[int] = None) -> torch.Tensor:
         """`decode(z).sample` followed by the scripts' `(clamp(x,-1,1)+1)*127.5 -> uint8` ('t h w c',
         cvvae_inference_video.py:47-50) on the device.  One clip (B = 1)."""

@@ -79,6 +79,25 @@ def test_encode_latents_is_encode_first_stage(family):
     assert torch.equal(a, m.encode_latents(x, generator=torch.Generator().manual_seed(5)))
 
 
+@pytest.mark.parametrize("family", ["sd3", "vae3d"])
+def test_decode_latents_is_decode_first_stage(family):
+    """DiffusionEngineFor3DVAE.decode_first_stage (lvdm/models/diffusion.py:139-157, 369-377): z / scale_factor, rounds, decode, frames
+    folded into the batch; image latents run as one-frame clips"""
+    m = make(family)
+    g = torch.Generator().manual_seed(3)
+    zc = 16 if family == "sd3" else 4
+    z = torch.randn((3, zc, 2, 8, 8), generator=g)
+    sf = getattr(m.config, "scaling_factor", None) or 1.0
+    want = torch.cat([m.decode(z[i:i + 1] * (1.0 / sf)).sample for i in range(3)], dim=0)
+    x = m.decode_latents(z)
+    assert x.shape == (3 * want.shape[2], 3, 64, 64)
+    assert torch.equal(x, want.permute(0, 2, 1, 3, 4).reshape(-1, 3, 64, 64))
+    assert torch.equal(m.decode_latents(z, n_samples_a_time=2), x)
+    assert torch.equal(m.decode_latents(z, flatten_frames=False), want)
+    xi = m.decode_latents(z[:, :, 0], scale_factor=1.0)  # image latents [B,z,h,w]
+    assert xi.shape == (3, 3, 64, 64) and torch.equal(xi, m.decode(z[:, :, :1]).sample[:, :, 0])
+
+
 def test_from_pretrained_ignores_unknown_config_keys_and_extra_tensors(tmp_path):
     import cvvae_amd
     m = cvvae_amd.CVVAEModel()
