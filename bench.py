@@ -238,7 +238,18 @@ def torch_rocm_baseline(family, shape, dtype_tag, ms_per_step):
     hit = [r for r in runs if r["family"] == family and r["shape"] == list(shape) and r["dtype"] == dtype_tag]
     if not hit:
         return None
+    noise = None  # the same ops' own 16-bit noise on the GPU against the reference's fp32 fixtures (tools/torch_gpu_noise.py)
+    try:
+        allnoise = json.load(open(os.path.join(ROOT, "profiles", "r3_torch_gpu_noise.json")))
+        for case, e in allnoise.items():
+            if e.get(dtype_tag, {}).get("shape") == list(shape):
+                n = e[dtype_tag]
+                noise = {"latent_max_abs": n["latent_max_abs"], "latent_mean_abs": n["latent_mean_abs"], "recon_psnr_db": round(n["recon_psnr_db"], 2),
+                         "what": "PyTorch-ROCm's own run of these ops in this dtype vs the reference's fp32 CPU fixture (profiles/r3_torch_gpu_noise.json)"}
+    except (OSError, ValueError, KeyError):
+        pass
     return {"source": "profiles/r3_torch_gpu_baseline.json (tools/torch_gpu_baseline.py, round-3 gpurun box)", "measured_in_this_run": False,
+            "own_noise_same_dtype": noise,
             "runs": [{"kernels": "MIOpen" if "MIOpen conv" in r["what"] else "ATen vol2col + rocBLAS", "ms_per_clip": r["ms_per_clip"],
                       "frames_per_s": r["frames_per_s"], "this_run_speedup": round(r["ms_per_clip"] / ms_per_step, 1)} for r in hit]}
 
