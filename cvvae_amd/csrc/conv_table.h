@@ -41,10 +41,13 @@
   X(3,3,3, 1,1,1, 2,8,32, 8,1,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,1)
 // strided 3x3x3 (encoder downsamplers): 64-pixel tile, BN = 256
-// folded upsample convs (KH = KW = 2 taps per phase), BN = 256 (16-channel chunks measured 5 % faster than 32)
+// folded upsample convs (KH = KW = 2 taps per phase), BN = 256.  32-channel chunks first (the cost model ties; the first wins): a
+// 16-channel chunk is only 96 MFMAs per wave between two barriers.  Round 1 measured the 16-channel form 5 % faster; with the
+// weight-stationary tile windows of round 3 the 32-channel form wins: 256 -> 512 @9x256^2 6.18 -> 5.74 ms, 512 -> 512 2.89 -> 2.83 ms
+// (profiles/r3_ab_ups_chunk.log)
 #define CVVAE_CONV_G9(X) \
-  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2) \
-  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2)
+  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2) \
+  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2)
 // image mode (T = 1, time taps folded into the weights): strided per-frame conv and the 1x2x2 upsample phases
 #define CVVAE_CONV_G10(X) \
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
