@@ -7,9 +7,14 @@ HBM before the timed region.
 
 N > 1: one process per GPU over RCCL.  `python bench.py --gpus N` launches the N ranks itself (it re-executes under
 `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`); started by an external launcher
-(RANK / WORLD_SIZE in the environment) it simply is one of the ranks.  cfg 3 / 2 / 5: every rank codes its own clip(s)
-(the path partitions into independent 17-frame windows -- SURVEY.md 8e -- so there is no data-path collective; weak
-scaling); cfg 4: ONE clip, its temporal windows sharded over the ranks (cvvae_amd/dist.py; strong scaling).
+(RANK / WORLD_SIZE in the environment) it simply is one of the ranks.  The DEFAULT workload at N > 1 is north_star's temporal
+shard: ONE clip of 1 + 16 N frames at 512x512 whose frames arrive SHARDED ON TIME (rank r holds only its own 16 -- rank 0: 17 --
+frames), the causal halo frame exchanged point-to-point over RCCL (`batch_isend_irecv`), every rank coding its own 17-frame
+window, the latents all-gathered, the pixels left sharded (cvvae_amd/dist.py `codec_step_time_sharded`; weak scaling: the
+per-GPU work is cfg 3's window whatever N is, and at N = 1 the step IS cfg 3).  After the timed region every rank checks its
+slice bit for bit against the single-process wrapper run on the whole clip.  Annex `temporal_shard_cfg4` (N > 1): BASELINE cfg 4
+(T = 129, 720x1280) time-sharded the same way -- strong scaling, with the single-process time measured in the same invocation.
+`--workload cfg3_sd3_T17_512` (or cfg2 / cfg5) at N > 1 keeps the older independent-clips mode (no data-path collective).
 value = frames of all ranks / max-over-ranks time.
 
 Besides the contract line, the JSON carries
@@ -48,6 +53,8 @@ WORKLOADS = {
     "cfg4_sd3_T129_720x1280": ("sd3", 1, 129, 720, 1280),
     # cfg 5: batch-8 T=33 encode-only (training-side latent pre-compute); the batch is split over the ranks
     "cfg5_sd3_B8_T33_512_encode": ("sd3", 8, 33, 512, 512),
+    # the default at N > 1: ONE clip of 1 + 16 N frames, time-sharded input, halo frame over RCCL send/recv (T is set from N)
+    "temporal_shard_sd3_512": ("sd3", 1, None, 512, 512),
 }
 ENC_TFLOP = {"cfg3_sd3_T17_512": 22.842, "cfg2_vae3d_T17_256": 5.674, "cfg1_vae3d_T1_256": 0.533}  # encoder share of ALG_TFLOP
 # algorithmic FLOPs per unit of work (BASELINE.md section 3 / SURVEY 8d: 2*M*N*K of every conv/linear + attention)
@@ -65,20 +72,27 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg3_sd3_T17_512", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: cfg3_sd3_T17_512 on one GPU, temporal_shard_sd3_512 (the same window per GPU, ONE clip "
+                         "sharded on time, halo exchange over RCCL) on N > 1")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32", "f32q"],
                     help="model dtype; f32 = fp32 model in split precision (three fp16 MFMAs per product), f32q = fp32 model in fast "
                          "split precision (fp16 MFMA + bf8 / fp6 correction MFMA): the cheapest mode inside north_star's 1e-3 latent bound")
     ap.add_argument("--no-tolerance-mode", action="store_true",
                     help="skip the annex that times and checks the f32q model (the mode that meets |delta| <= 1e-3) beside the bench dtype")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-baseline-full", action="store_true",
-                    help="time the oracle on the FULL workload shape with all host cores (minutes) instead of the bounded sample")
+    ap.add_argument("--cpu-baseline-sample", action="store_true",
+                    help="time the CPU path on a bounded 17x192x192 sample (about 10 s, scaled by pixel count) instead of the default: "
+                         "the FULL workload shape on every host core, in a child process beside the untimed checker legs (minutes)")
     ap.add_argument("--hip-graphs", action="store_true",
                     help="replay each encoder/decoder pass as a captured hipGraph (vae.enable_hip_graphs(); for launch-bound inputs)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--no-check", action="store_true", help="cfg 4, N > 1: skip the sharded == single-process latent check")
+    ap.add_argument("--no-check", action="store_true", help="N > 1: skip the sharded == single-process bit-equality check")
+    ap.add_argument("--no-cfg4-annex", action="store_true", help="N > 1: skip the temporal_shard_cfg4 strong-scaling annex")
+    ap.add_argument("--cpu-baseline-wall", type=float, default=420.0,
+                    help="wall-time guard (s) of the in-run full-size CPU baseline; beyond it the kept measurement is reported")
+    ap.add_argument("--cpu-baseline-worker", nargs=4, metavar=("FAMILY", "T", "H", "W"), default=None, help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -117,6 +131,15 @@ def conv_flops_executed(d, pw):
     """MFMA FLOPs the launch really issues on useful rows/columns: the kernel's own taps (12 per phase pixel for the folded
     upsample, kH*kW for a single-frame fold) over the padded channel counts, minus the time groups the time folds skip."""
     sp = 4 if d.upsample2x == 2 else d.kH * d.kW  # spatial taps per output pixel as executed
+    # fp32 models: MFMA time UNITS per time group of `sp` taps (unit = one 32x32x16 fp16 MFMA): exact = three fp16 MFMAs per tap;
+    # fast = one fp16 MFMA per tap + one K = 64 correction MFMA per PAIR of taps, which lasts two units in bf8 and one in fp6
+    from cvvae_amd import _lib as L_
+    if d.dtype == L_.F32:
+        sp = 3 * sp
+    elif d.dtype == L_.F32Q:
+        sp = sp + 2 * ((sp + 1) // 2)
+    elif d.dtype == L_.F32Q6:
+        sp = sp + (sp + 1) // 2
     if d.kT == 3:
         rep = d.pad_mode_t == 1
         tg = sum(time_groups(to, d.sT, d.pad_t, d.Ti, rep, bool(d.w_time_folds)) for to in range(d.To))
@@ -161,65 +184,99 @@ def roofline_pass(step_fn):
     return agg
 
 
-def cpu_baseline(family, T=17, H=512, W=512, full=False):
-    """CPU oracle on a bounded sample: the same network on a 17-frame window at 192x192 (0.14 of the 512x512 frame
-    area; one temporal window, no spatial tiling -- like the workload), scaled by pixel count to the workload's frame size.
-    full=True: the workload's own shape, every host core, no extrapolation."""
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            return next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
+    except OSError:
+        return ""
+
+
+def cpu_baseline_measure(family, T=17, H=512, W=512, full=True):
+    """The CPU path timed on this host's cores.  full=True: the workload's OWN shape on every host core -- no extrapolation (minutes
+    of CPU time; bench.py runs it in a child process beside its untimed checker legs).  full=False: a bounded sample (the same
+    network on a 17-frame window at 192x192, scaled by pixel count; it flatters the CPU ~3x: oneDNN runs small frames more
+    efficiently).  With /root/reference mounted (the build container) the reference's OWN modules are timed (kind "reference");
+    on the GPU box, where it does not exist, the oracle restatement of them (kind "port")."""
     import torch
-    from oracle import cvvae_oracle as O
     from oracle.seeded import seeded_input, seeded_state_dict
     from oracle.shapes import state_dict_shapes
 
     # oneDNN conv at the sample size stops scaling (and regresses) beyond ~32 threads; the full shape takes every core
     cores = (os.cpu_count() or 1) if full else min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    sd = seeded_state_dict(state_dict_shapes(family), 0)
-    hh, ww = (H, W) if full else (min(H, 192), min(W, 192))  # sample: ~10 s of CPU work on the GPU box's host cores
+    hh, ww = (H, W) if full else (min(H, 192), min(W, 192))
     x = seeded_input((1, 3, T, hh, ww), 0)
+    kind, model = "port", None
+    if os.path.isdir("/root/reference/models"):
+        try:
+            from oracle.ref_loader import load_reference
+            ref = load_reference()
+            model = (ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel)().eval()
+            model.load_state_dict(seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, 0), strict=True)
+            kind = "reference"
+        except Exception:  # noqa: BLE001  (the port is the fallback wherever the reference cannot be imported)
+            model = None
     with torch.no_grad():
-        t0 = time.time()
-        mom = O.encode_moments(x, sd, {}, family)
-        t1 = time.time()
-        rec = O.decode_sample(O.posterior_mode(mom), sd, {}, family)
-        dt = time.time() - t0
+        if model is not None:
+            t0 = time.time()
+            post = model.encode(x).latent_dist
+            t1 = time.time()
+            rec = model.decode(post.mode()).sample
+            dt = time.time() - t0
+        else:
+            from oracle import cvvae_oracle as O
+            sd = seeded_state_dict(state_dict_shapes(family), 0)
+            t0 = time.time()
+            mom = O.encode_moments(x, sd, {}, family)
+            t1 = time.time()
+            rec = O.decode_sample(O.posterior_mode(mom), sd, {}, family)
+            dt = time.time() - t0
     assert rec.shape == x.shape
     area_scale = (H * W) / float(hh * ww)
-    cpu_model = ""
-    try:
-        with open("/proc/cpuinfo") as f:
-            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "")
-    except OSError:
-        pass
-    out = {
-        "value": round(T / (dt * area_scale), 5),
-        "unit": "frames/s",
-        "cores": cores,
-        "kind": "port",
-        "extrapolated": area_scale != 1.0,
-        "cpu_model": cpu_model,
+    who = "the reference's own modules (PyTorch-CPU fp32)" if kind == "reference" else "oracle (PyTorch-CPU fp32 restatement)"
+    return {
+        "value": round(T / (dt * area_scale), 5), "unit": "frames/s", "cores": cores, "kind": kind,
+        "extrapolated": area_scale != 1.0, "cpu_model": _cpu_model(),
         "encode_s": round(t1 - t0, 2), "decode_s": round(dt - (t1 - t0), 2),
-        "sample": (f"oracle (PyTorch-CPU fp32 restatement) encode+decode of the full 1x3x{T}x{hh}x{ww} workload in {dt:.1f}s"
-                   if area_scale == 1.0 else
-                   f"oracle (PyTorch-CPU fp32 restatement) encode+decode of 1x3x{T}x{hh}x{ww} in {dt:.1f}s; value = {T} frames "
-                   f"/ (t * {area_scale:.1f}) i.e. scaled by pixel count to the {H}x{W} workload"),
+        "sample": (f"{who} encode+decode of the full 1x3x{T}x{hh}x{ww} workload in {dt:.1f}s" if area_scale == 1.0 else
+                   f"{who} encode+decode of 1x3x{T}x{hh}x{ww} in {dt:.1f}s; value = {T} frames / (t * {area_scale:.1f}) "
+                   f"i.e. scaled by pixel count to the {H}x{W} workload"),
     }
-    # The bounded sample flatters the CPU (oneDNN runs the small frames ~2.5x more efficiently than the 512x512 ones), so the reported
-    # `value` is the FULL-size measurement whenever one is kept for this host CPU model (bench.py --cpu-baseline-full, minutes of CPU
-    # time, measured once per CPU model and committed as profiles/cpu_baseline_full.json); the in-run sample is the annex that shows
-    # the host is the same class of machine.  A host without a kept measurement is measured at full size in this run.
-    kept = os.path.join(ROOT, "profiles", "cpu_baseline_full.json")
-    if not full:
-        k = None
-        if os.path.isfile(kept):
-            with open(kept) as f:
-                k = json.load(f)
-        if k is not None and k.get("cpu_model") == cpu_model:
-            sample = dict(out)
-            out = dict(k, measured_in_this_run=False, in_run_sample=sample,
-                       sample_to_full_ratio=round(sample["value"] / k["value"], 2))
-        else:
-            out = cpu_baseline(family, T, H, W, full=True)
+
+
+def cpu_baseline_start(family, T, H, W):
+    """start the full-size CPU measurement in a child process (so that it runs BESIDE the untimed checker legs of this run, never
+    beside a timed region); returns the Popen"""
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", family, str(T), str(H), str(W)]
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")  # the child never touches the GPU
+    return subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True), time.time()
+
+
+def cpu_baseline_collect(handle, wall, family, T, H, W):
+    """the child's measurement if it arrives within `wall` seconds of its start; otherwise the KEPT full-size measurement of this
+    CPU model (profiles/cpu_baseline_full.json) marked measured_in_this_run = false, or -- no kept file -- the bounded sample"""
+    proc, t_start = handle
+    out, why = None, None
+    try:
+        so, _ = proc.communicate(timeout=max(1.0, wall - (time.time() - t_start)))
+        line = [ln for ln in so.splitlines() if ln.startswith("{")]
+        if proc.returncode == 0 and line:
+            out = json.loads(line[-1])
             out["measured_in_this_run"] = True
+            out["concurrent_with"] = "this run's untimed parity / roofline legs (one host thread + the GPU); never a timed region"
+        else:
+            why = f"worker exit code {proc.returncode}"
+    except subprocess.TimeoutExpired:
+        proc.kill()
+        why = f"not finished within the {wall:.0f} s wall guard (--cpu-baseline-wall)"
+    if out is None:
+        kept = os.path.join(ROOT, "profiles", "cpu_baseline_full.json")
+        k = json.load(open(kept)) if os.path.isfile(kept) else None
+        if k is not None and k.get("cpu_model") == _cpu_model():
+            out = dict(k, measured_in_this_run=False, why_not=why)
+        else:
+            out = dict(cpu_baseline_measure(family, T, H, W, full=False), measured_in_this_run=True, why_not_full=why)
     return out
 
 
@@ -229,6 +286,86 @@ def _rccl_version(torch):
         return ".".join(str(x) for x in v) if isinstance(v, (tuple, list)) else str(v)
     except Exception as e:  # noqa: BLE001
         return f"unavailable ({type(e).__name__})"
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the temporal shard (N > 1 default): module-level so that tests/test_dist_gloo.py drives EXACTLY the step bench.py times
+# ------------------------------------------------------------------------------------------------------------------------
+def temporal_shard_T(world: int, stride: int = 16) -> int:
+    """frames of the sharded clip: one `stride`-frame window per rank + the clip's first frame (N = 1: cfg 3's 17)"""
+    return 1 + stride * world
+
+
+def temporal_shard_input(T_total, H, W, world, rank, dtype, device, seed=1000, stride=16, keep_full=True):
+    """-> (x_full on the CPU or None, x_local on `device`): the SAME seeded clip on every rank, of which the rank keeps only
+    its `owned_frames` on the device (time-sharded input); the full clip stays on the host for the post-run check"""
+    import torch
+    from cvvae_amd import dist as D
+    g = torch.Generator().manual_seed(seed)
+    x_full = (torch.rand((1, 3, T_total, H, W), generator=g) * 2 - 1).to(dtype)
+    a, b = D.owned_frames(T_total, stride, world, rank)
+    x_local = x_full[:, :, a:b].contiguous().to(device)
+    return (x_full if keep_full else None), x_local
+
+
+def temporal_shard_step(vae, x_local, T_total, group=None):
+    """one timed step at N > 1: halo exchange (send/recv) -> encode own windows -> all_gather moments -> decode own windows"""
+    from cvvae_amd import dist as D
+    return D.codec_step_time_sharded(vae, x_local, T_total, group=group)
+
+
+def temporal_shard_check(vae, x_full, mom, y_local, world, rank, device):
+    """every rank: the single-process wrapper on the WHOLE clip must reproduce the gathered moments and this rank's frames
+    bit for bit (windows are independent network calls; the halo frame is the neighbour's own data)"""
+    import torch
+    from cvvae_amd import dist as D
+    x = x_full.to(device)
+    ref_mom = vae.encode(x).latent_dist.parameters
+    zc = ref_mom.shape[1] // 2
+    ok = bool(torch.equal(mom, ref_mom))
+    a, b = D.decoded_frames_of_rank(vae, ref_mom.shape[2], world, rank)
+    if b > a:
+        ref_y = vae.decode(ref_mom[:, :zc]).sample[:, :, a:b]
+        ok = ok and y_local is not None and tuple(y_local.shape) == tuple(ref_y.shape) and bool(torch.equal(y_local, ref_y))
+    else:
+        ok = ok and y_local is None
+    return ok
+
+
+def init_rccl(torch, world, rank, local_rank, seconds=180):
+    """process group on RCCL with a bounded first contact: init + one all_reduce under `seconds`, and a ONE-LINE diagnosis on
+    stderr if it does not come back (the RCCL path of this project first ran on the driver's multi-GPU tier)."""
+    import datetime
+    import threading
+
+    import torch.distributed as dist
+
+    what = {"at": "init_process_group"}
+
+    def watchdog():
+        print(f"bench.py: rank {rank}/{world} (cuda:{local_rank}, {torch.cuda.device_count()} devices visible) still inside "
+              f"{what['at']} after {seconds} s -- RCCL first contact hangs: check HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC), "
+              f"MASTER_ADDR=127.0.0.1, one rank per GPU, NCCL_DEBUG=INFO for the transport it picked", file=sys.stderr, flush=True)
+
+    tmr = threading.Timer(seconds, watchdog)
+    tmr.daemon = True
+    tmr.start()
+    try:
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=max(seconds * 2, 600)))
+        what["at"] = "the first all_reduce"
+        t = torch.ones(1, device="cuda")
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        if int(t.item()) != world:
+            raise RuntimeError(f"first all_reduce over {world} ranks returned {t.item()}")
+    except Exception as e:  # noqa: BLE001
+        print(f"bench.py: rank {rank}/{world}: RCCL first contact failed in {what['at']}: {type(e).__name__}: {e}", file=sys.stderr,
+              flush=True)
+        raise
+    finally:
+        tmr.cancel()
+    return dist
 
 
 def torch_rocm_baseline(family, shape, dtype_tag, ms_per_step):
@@ -271,8 +408,74 @@ def profile_json(name):
     return None
 
 
+def roofline_report(agg, args, sec_per_step, profiled, brief=False):
+    """-> {"roofline": ..., "mfma_busy": ..., "kernels": ...} from a roofline_pass() aggregate.  `achieved` = ALGORITHMIC FLOPs
+    (2 M N K of the reference op) / HIP-event time of the dominant conv instance; `executed` = the MFMA work really issued, in
+    units of the fp16 32x32x16 MFMA (16-bit models: one per product and executed tap; fp32 models: three -- exact -- or 1 + 1 (bf8)
+    / 1 + 1/2 (fp6) per product -- fast: conv_flops_executed).  Counter-derived fields come from the committed PMC passes of the
+    cfg 3 bf16 command (`profiled`), stamped with the fingerprint of the kernel sources they were measured on."""
+    out = {}
+    name, (fl, sec, n, fx, fl_main) = max(agg.items(), key=lambda kv: kv[1][1])
+    ach = fl / sec / 1e12
+    traffic = None
+    short = name.split("_", 3)[3] if name.count("_") >= 3 else name
+    tj = profile_json("pmc_traffic.json") if profiled else None
+    from cvvae_amd import _lib as _L
+    fp_now = _L.source_fingerprint()
+
+    def stale(doc):  # the committed counters were measured on other kernel sources than the ones running now
+        return doc.get("library_source_fingerprint") != fp_now
+    hbm_extra = {}
+    if tj:
+        k = tj.get("kernels", {}).get(short)
+        if k:
+            traffic = k["fetch_bytes"] + k["write_bytes"]
+        if "step_total_bytes" in tj:
+            hbm_extra = {"pmc_bytes_per_step": tj["step_total_bytes"], "pmc_gbps": round(tj["step_total_bytes"] / sec_per_step / 1e9, 1)}
+    out["roofline"] = {
+        "bound": "mfma", "kernel": name, "launches_per_step": n,
+        "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
+        "executed": round(fx / sec / 1e12, 1),
+        "executed_note": "MFMA time units issued x 2*32*32*16 FLOP / time (fp32 models: 3 units per product exact; fast: 2 with bf8, 1.5 "
+                         "with fp6 corrections) -- the matrix-pipe occupancy as a rate; `achieved` counts the reference op's FLOPs once",
+        "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": traffic,
+        "traffic_unit": "bytes/launch (PMC, profiles/pmc_traffic.json)",
+        "traffic_source": None if not tj else {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
+                                               "library_source_fingerprint": tj.get("library_source_fingerprint"),
+                                               "running_source_fingerprint": fp_now, "stale": stale(tj)},
+    }
+    if fl_main < fl:  # launches of this instance are split in two dispatches (odd frame count under a two-frame tile)
+        out["roofline"]["dispatches_per_launch"] = 2
+        out["roofline"]["main_dispatch_alg_gflop"] = round(fl_main / n / 1e9, 2)
+        out["roofline"]["launch_note"] = (
+            "avg_launch_ms spans BOTH dispatches of a cvvae_conv_fwd call (HIP events around the call): the two-frame-tile kernel "
+            "over all but the last frame + its one-frame-tile twin on the last frame.  A rocprofv3 trace lists them as two kernels "
+            "whose average durations add up to it; against the main kernel's rocprofv3 duration use main_dispatch_alg_gflop")
+    pk = profile_json("peak_probe.json")
+    if pk and not brief:  # what dense bf16 matrix code sustains on this pool's MI355X (vendor GEMM, register-only MFMA stream)
+        out["roofline"]["on_box_denominators"] = pk
+        out["roofline"]["executed_frac_of_hipblaslt_gemm"] = round(fx / sec / 1e12 / max(pk["hipblaslt_bf16_gemm_tflops"]), 3)
+    sq = profile_json("pmc_sq.json") if profiled else None
+    if sq and short in sq.get("kernels", {}):
+        out["mfma_busy"] = dict(sq["kernels"][short], source="profiles/pmc_sq.json (SQ counters, separate --pmc passes)",
+                                measured_in_this_run=False, stale=stale(sq))
+    tot_fl, tot_fx, tot_sec = sum(v[0] for v in agg.values()), sum(v[3] for v in agg.values()), sum(v[1] for v in agg.values())
+    out["executed_tflops_conv_kernels"] = round(tot_fx / tot_sec / 1e12, 1)
+    out["algorithmic_tflops_conv_kernels"] = round(tot_fl / tot_sec / 1e12, 1)
+    out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "executed_tflops": round(v[3] / v[1] / 1e12, 1),
+                          "ms": round(v[1] * 1e3, 3), "launches": v[2]}
+                      for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+    if hbm_extra:
+        out["hbm_pmc"] = hbm_extra
+    return out
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_worker is not None:  # child of cpu_baseline_start(): CPU only, one JSON line
+        fam, T_, H_, W_ = args.cpu_baseline_worker
+        print(json.dumps(cpu_baseline_measure(fam, int(T_), int(H_), int(W_), full=True)), flush=True)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     import torch
@@ -285,17 +488,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU path)")
     torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-
-        dist = dist_
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dist = init_rccl(torch, world, rank, local_rank) if world > 1 else None
 
     import cvvae_amd
+    from cvvae_amd import dist as D
     from oracle import parity as P  # checker only: seeded weights + the fixture comparison (never inside the timed region)
 
+    if args.workload is None:
+        args.workload = "cfg3_sd3_T17_512" if world == 1 else "temporal_shard_sd3_512"
+    tshard = args.workload.startswith("temporal_shard")
+    if tshard and world == 1:
+        args.workload, tshard = "cfg3_sd3_T17_512", False  # one rank: the shard IS cfg 3 (T = 1 + 16)
     family, B, T, H, W = WORKLOADS[args.workload]
+    if tshard:
+        T = temporal_shard_T(world)
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32, "f32q": torch.float32}[args.dtype]
     cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
     vae = cls()
@@ -311,13 +517,19 @@ def main():
         if B % world:
             raise SystemExit(f"cfg5 splits its batch of {B} over the ranks: --gpus must divide {B}")
         B = B // world
-    # cfg 3 / 2: every rank codes its own clip (weak scaling).  cfg 4: every rank holds the same clip (seed without rank)
-    g = torch.Generator().manual_seed(1000 + (0 if cfg4 else rank))
-    x = (torch.rand((B, 3, T, H, W), generator=g) * 2 - 1).to(dtype).cuda()
+    x_full = None
+    if tshard:
+        # ONE clip, the same on every rank (same seed); the rank keeps only ITS frames on the device
+        x_full, x = temporal_shard_input(T, H, W, world, rank, dtype, "cuda", keep_full=not args.no_check)
+    else:
+        # cfg 3 / 2: every rank codes its own clip (weak scaling).  cfg 4: every rank holds the same clip (seed without rank)
+        g = torch.Generator().manual_seed(1000 + (0 if cfg4 else rank))
+        x = (torch.rand((B, 3, T, H, W), generator=g) * 2 - 1).to(dtype).cuda()
 
-    if cfg4 and dist is not None:
-        from cvvae_amd import dist as D
-
+    if tshard:
+        def step():
+            return temporal_shard_step(vae, x, T)
+    elif cfg4 and dist is not None:
         def step():
             # (window x spatial tile) network calls split over the ranks (8 x 6 = 48 units at cfg 4: one window per rank on 8 GPUs,
             # no tile traffic; fewer windows than ranks -> the tiles of a window spread out, raw tiles go point-to-point to the
@@ -336,6 +548,7 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+    D.TRAFFIC.update(sent=0, recv=0)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -347,21 +560,35 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    assert cfg5 or (cfg4 and dist is not None) or y.shape == x.shape
+    assert tshard or cfg5 or (cfg4 and dist is not None) or y.shape == x.shape
     rank_times = None
+    traffic = None
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed, float(D.TRAFFIC["sent"]), float(D.TRAFFIC["recv"])], device="cuda", dtype=torch.float64)
         ts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(ts, t)                      # per-rank clocks (diagnostic); the reported time is their MAX
-        rank_times = [round(float(v.item()) / args.steps * 1e3, 3) for v in ts]
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_gather(ts, t)                      # per-rank clocks and wire bytes (diagnostic); the reported time is their MAX
+        rank_times = [round(float(v[0].item()) / args.steps * 1e3, 3) for v in ts]
+        traffic = {"bytes_sent_per_step_by_rank": [int(v[1].item()) // max(args.steps, 1) for v in ts],
+                   "bytes_recv_per_step_by_rank": [int(v[2].item()) // max(args.steps, 1) for v in ts]}
+        elapsed = max(float(v[0].item()) for v in ts)
 
     strong = cfg4                                 # one fixed clip split over the ranks; everything else: per-rank work fixed
-    frames = (1 if strong else world) * B * T * args.steps
-    units = (1 if strong else world) * (B if cfg5 else 1) * args.steps / (8 if cfg5 else 1)  # ALG_TFLOP units done
+    if tshard:
+        frames = T * args.steps                   # ONE clip of 1 + 16 N frames per step, over all ranks
+        units = world * args.steps                # every rank codes one cfg-3 window (rank r > 0 re-codes its halo frame)
+    else:
+        frames = (1 if strong else world) * B * T * args.steps
+        units = (1 if strong else world) * (B if cfg5 else 1) * args.steps / (8 if cfg5 else 1)  # ALG_TFLOP units done
+    alg_key = "cfg3_sd3_T17_512" if tshard else args.workload
+    if tshard:
+        par = (f"ONE clip of {T} = 1 + 16 x {world} frames sharded on time over {world} ranks: halo frame by RCCL send/recv "
+               f"(batch_isend_irecv), one 17-frame window per rank, moments all-gathered, pixels left sharded")
+    elif strong:
+        par = f"(temporal window x spatial tile) network calls sharded x{world}, latents all-gathered"
+    else:
+        par = f"independent clips x{world} (no collective)"
     out = {
-        "metric": "encode+decode frames/sec (T=17, 512x512)" if args.workload.startswith("cfg3") else
+        "metric": "encode+decode frames/sec (T=17, 512x512)" if (args.workload.startswith("cfg3") or tshard) else
                   ("encode-only frames/sec" if cfg5 else "encode+decode frames/sec"),
         "value": round(frames / elapsed, 3),
         "unit": "frames/s",
@@ -374,38 +601,87 @@ def main():
         "vs_baseline": None,
         "dtype": args.dtype,
         "data": "synthetic uniform[-1,1) clip, seeded random weights with default-init statistics of the named architecture",
-        "config": {"workload": f"{args.workload}: {family} " + ("encode(x).mode()" if cfg5 else "encode(x).mode() + decode(z)") +
-                               f", x=[{B},3,{T},{H},{W}] per GPU",
-                   "clips_per_gpu": B, "hip_graphs": bool(args.hip_graphs),
-                   "parallelism": (f"(temporal window x spatial tile) network calls sharded x{world}, latents all-gathered" if strong else
-                                   f"independent clips x{world} (no collective)")},
-        "multi_gpu": None if dist is None else {
+        "config": {"workload": (f"{args.workload}: {family} encode(x).mode() + decode(z) of ONE [1,3,{T},{H},{W}] clip, rank r holding "
+                                f"frames owned_frames({T}, 16, {world}, r) -- a 17-frame window (cfg 3's) per GPU" if tshard else
+                                f"{args.workload}: {family} " + ("encode(x).mode()" if cfg5 else "encode(x).mode() + decode(z)") +
+                                f", x=[{B},3,{T},{H},{W}] per GPU"),
+                   "clips_per_gpu": (round(1.0 / world, 4) if tshard else B), "hip_graphs": bool(args.hip_graphs), "parallelism": par},
+        "multi_gpu": None if dist is None else dict({
             "n_ranks_seen": dist.get_world_size(), "backend": dist.get_backend(),
             "rccl_version": _rccl_version(torch),
             "ms_per_step_by_rank": rank_times, "devices": torch.cuda.device_count(),
             "device_name": torch.cuda.get_device_name(local_rank),
-            "data_path_collectives": ("all_gather of the latents (15 MB) once per step; tile results point-to-point only when a "
-                                      "window's tiles span ranks") if strong else "none (independent clips)",
-            "note": "value = work of all ranks / MAX over ranks of the barrier-bracketed time"},
-        "achieved_tflops_whole_path": round(ALG_TFLOP[args.workload] * units / elapsed, 1),
-        "hbm": {"algorithmic_gbps": round(ALG_GB[args.workload] * units / elapsed, 1), "peak_gbps": HBM_PEAK_GBPS,
+            "data_path_collectives": (
+                "per step: 1 batched send/recv of the boundary pixel frame to the right neighbour (1.5 MB in bf16 at 512x512) + 1 "
+                "all_gather of the posterior moments on time (padded to the largest rank's 5 latent frames)" if tshard else
+                ("all_gather of the latents (15 MB) once per step; tile results point-to-point only when a window's tiles span "
+                 "ranks") if strong else "none (independent clips)"),
+            "note": "value = work of all ranks / MAX over ranks of the barrier-bracketed time"}, **(traffic or {})),
+        "achieved_tflops_whole_path": round(ALG_TFLOP[alg_key] * units / elapsed, 1),
+        "hbm": {"algorithmic_gbps": round(ALG_GB[alg_key] * units / elapsed, 1), "peak_gbps": HBM_PEAK_GBPS,
                 "note": "algorithmic bytes (BASELINE.md section 3) / step time; the path is MFMA-bound (AI ~1900 FLOP/B)"},
     }
 
-    if cfg4 and dist is not None and not args.no_check:
+    if dist is not None and not args.no_check and (tshard or cfg4):
         # the sharded run must reproduce the single-process wrapper bit for bit (windows are independent network calls)
-        from cvvae_amd import dist as D
-        mom = D.encode_units_sharded(vae, x)
-        ok = True
-        if rank == 0:
-            ref = vae.encode(x).latent_dist.parameters
-            ok = bool(torch.equal(mom, ref))
-            out["sharded_equals_single_process"] = ok
+        if tshard:
+            mom, y_loc = step()
+            ok = temporal_shard_check(vae, x_full, mom, y_loc, world, rank, "cuda")
+            del mom, y_loc
+        else:
+            mom = D.encode_units_sharded(vae, x)
+            ok = bool(torch.equal(mom, vae.encode(x).latent_dist.parameters)) if rank == 0 else True
         okt = torch.tensor([1 if ok else 0], device="cuda")
-        dist.broadcast(okt, 0)
-        assert int(okt.item()) == 1, "cfg 4: window-sharded latents differ from the single-process result"
+        oks = [torch.empty_like(okt) for _ in range(world)]
+        dist.all_gather(oks, okt)
+        out["sharded_equals_single_process"] = all(int(v.item()) == 1 for v in oks)
+        out["sharded_check"] = ("every rank: gathered moments and its own decoded frames == the single-process wrapper on the whole "
+                                "clip, bit for bit" if tshard else "rank 0: gathered moments == the single-process wrapper, bit for bit")
+        assert out["sharded_equals_single_process"], f"sharded results differ from the single-process run: {[int(v.item()) for v in oks]}"
+    x_full = None
 
-    if rank == 0 and not (cfg5 or (cfg4 and dist is not None)):
+    if dist is not None and tshard and not args.no_cfg4_annex:
+        # BASELINE cfg 4 through the same time-sharded step: ONE fixed clip (T = 129, 720x1280: 8 windows x 6 blended spatial
+        # tiles), strong scaling, with the single-process time of the same clip measured HERE on rank 0
+        fam4, _, T4, H4, W4 = WORKLOADS["cfg4_sd3_T129_720x1280"]
+        x4_full, x4 = temporal_shard_input(T4, H4, W4, world, rank, dtype, "cuda", seed=1004, keep_full=(rank == 0))
+        temporal_shard_step(vae, x4, T4)             # warmup
+        torch.cuda.synchronize()
+        dist.barrier()
+        t4 = time.perf_counter()
+        n4 = 2
+        for _ in range(n4):
+            temporal_shard_step(vae, x4, T4)
+        torch.cuda.synchronize()
+        mine4 = (time.perf_counter() - t4) / n4
+        dist.barrier()
+        tt = torch.tensor([mine4], device="cuda", dtype=torch.float64)
+        t4s = [torch.empty_like(tt) for _ in range(world)]
+        dist.all_gather(t4s, tt)
+        t4max = max(float(v.item()) for v in t4s)
+        single = None
+        if rank == 0:
+            xg = x4_full.cuda()
+            vae.decode(vae.encode(xg).latent_dist.mode())   # warmup of the single-process shapes
+            torch.cuda.synchronize()
+            ts1 = time.perf_counter()
+            vae.decode(vae.encode(xg).latent_dist.mode())
+            torch.cuda.synchronize()
+            single = time.perf_counter() - ts1
+            del xg
+        dist.barrier()
+        out["temporal_shard_cfg4"] = {
+            "workload": f"cfg4_sd3_T129_720x1280: ONE [1,3,{T4},{H4},{W4}] clip, time-sharded over {world} ranks (8 windows; 6 blended "
+                        f"spatial tiles per window on the owning rank), encode + decode, moments all-gathered",
+            "scaling": "strong", "steps": n4, "ms_per_step": round(t4max * 1e3, 2), "value": round(T4 / t4max, 2), "unit": "frames/s",
+            "ms_per_step_by_rank": [round(float(v.item()) * 1e3, 2) for v in t4s],
+            "single_process_ms_same_invocation": None if single is None else round(single * 1e3, 2),
+            "speedup_vs_single_process": None if single is None else round(single / t4max, 3),
+        }
+        del x4, x4_full
+        torch.cuda.empty_cache()
+
+    if rank == 0 and not (tshard or cfg5 or (cfg4 and dist is not None)):
         # encode / decode split of one step (separate, untimed pass; events on the launch stream)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         for _ in range(2):
@@ -422,101 +698,89 @@ def main():
             out["encode_tflops"] = round(et / enc_ms * 1e3, 1)
             out["decode_tflops"] = round((ALG_TFLOP[args.workload] - et) / dec_ms * 1e3, 1)
             out["encode_frac_of_mfma_peak"] = round(et / enc_ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
-    if rank == 0 and not args.no_roofline and not args.dtype.startswith("f32"):
+    if rank == 0 and not args.no_roofline:
         vae.enable_hip_graphs(False)  # per-launch timing needs the eager launches
-        agg = roofline_pass(step)
-        name, (fl, sec, n, fx, fl_main) = max(agg.items(), key=lambda kv: kv[1][1])
-        ach = fl / sec / 1e12
-        # HBM traffic per launch of that kernel: from the committed PMC passes of this same command (profiles/)
-        traffic = None
-        short = name.split("_", 3)[3] if name.count("_") >= 3 else name
-        profiled = args.workload.startswith("cfg3") and args.dtype == "bf16"  # the committed PMC passes are of THIS command
-        tj = profile_json("pmc_traffic.json") if profiled else None
-        from cvvae_amd import _lib as _L
-        fp_now = _L.source_fingerprint()
-
-        def stale(doc):  # the committed counters were measured on other kernel sources than the ones running now
-            return doc.get("library_source_fingerprint") != fp_now
-        if tj:
-            k = tj.get("kernels", {}).get(short)
-            if k:
-                traffic = k["fetch_bytes"] + k["write_bytes"]
-            if "step_total_bytes" in tj:
-                out["hbm"]["pmc_bytes_per_step"] = tj["step_total_bytes"]
-                out["hbm"]["pmc_gbps"] = round(tj["step_total_bytes"] / (elapsed / args.steps) / 1e9, 1)
-        out["roofline"] = {
-            "bound": "mfma", "kernel": name, "launches_per_step": n,
-            "achieved": round(ach, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_PEAK_TFLOPS, 4),
-            "executed": round(fx / sec / 1e12, 1),
-            "avg_launch_ms": round(sec / n * 1e3, 4), "alg_gflop_per_launch": round(fl / n / 1e9, 2), "traffic": traffic,
-            "traffic_unit": "bytes/launch (PMC, profiles/pmc_traffic.json)",
-            "traffic_source": None if not tj else {"file": "profiles/pmc_traffic.json", "measured_in_this_run": False,
-                                                   "library_source_fingerprint": tj.get("library_source_fingerprint"),
-                                                   "running_source_fingerprint": fp_now, "stale": stale(tj)},
-        }
-        if fl_main < fl:  # launches of this instance are split in two dispatches (odd frame count under a two-frame tile)
-            out["roofline"]["dispatches_per_launch"] = 2
-            out["roofline"]["main_dispatch_alg_gflop"] = round(fl_main / n / 1e9, 2)
-            out["roofline"]["launch_note"] = (
-                "avg_launch_ms spans BOTH dispatches of a cvvae_conv_fwd call (HIP events around the call): the two-frame-tile kernel "
-                "over all but the last frame + its one-frame-tile twin on the last frame.  A rocprofv3 trace lists them as two kernels "
-                "whose average durations add up to it; against the main kernel's rocprofv3 duration use main_dispatch_alg_gflop")
-        pk = profile_json("peak_probe.json")
-        if pk:  # what dense bf16 matrix code sustains on this pool's MI355X (vendor GEMM, register-only MFMA stream)
-            out["roofline"]["on_box_denominators"] = pk
-            out["roofline"]["executed_frac_of_hipblaslt_gemm"] = round(fx / sec / 1e12 / max(pk["hipblaslt_bf16_gemm_tflops"]), 3)
-        sq = profile_json("pmc_sq.json") if profiled else None
-        if sq and short in sq.get("kernels", {}):
-            out["mfma_busy"] = dict(sq["kernels"][short], source="profiles/pmc_sq.json (SQ counters, separate --pmc passes)",
-                                    measured_in_this_run=False, stale=stale(sq))
-        tot_fx, tot_sec = sum(v[3] for v in agg.values()), sum(v[1] for v in agg.values())
-        out["executed_tflops_conv_kernels"] = round(tot_fx / tot_sec / 1e12, 1)
-        out["kernels"] = {k: {"tflops": round(v[0] / v[1] / 1e12, 1), "executed_tflops": round(v[3] / v[1] / 1e12, 1),
-                              "ms": round(v[1] * 1e3, 3), "launches": v[2]}
-                          for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])}
-    if rank == 0 and not args.no_parity and args.workload in GOLDEN_OF and \
-            os.path.isfile(os.path.join(P.GOLDEN_DIR, GOLDEN_OF[args.workload] + ".npz")):
-        vae.enable_hip_graphs(False)
-        r = P.measure(vae, GOLDEN_OF[args.workload])
-        out["parity"] = {
-            "against": f"tests/golden/{GOLDEN_OF[args.workload]}.npz = the reference's own modules, CPU fp32, same seeded weights/input",
-            "latent_max_abs": float(f"{r['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{r['latent_mean_abs']:.3e}"),
-            "recon_psnr_db": round(r["recon_psnr_db"], 2), "recon_max_abs": float(f"{r['recon_max_abs']:.3e}"),
-            "reference_own_noise_same_dtype": reference_noise(GOLDEN_OF[args.workload], args.dtype),
-            "north_star_tolerance": "|delta| <= 1e-3 on latents",
-            "meets_north_star_tolerance": bool(r["latent_max_abs"] <= 1e-3),
-        }
-    if rank == 0 and world == 1 and not args.no_tolerance_mode and not args.no_parity and not args.dtype.startswith("f32") and \
-            not cfg5 and args.workload in GOLDEN_OF and os.path.isfile(os.path.join(P.GOLDEN_DIR, GOLDEN_OF[args.workload] + ".npz")):
-        # the SAME workload on the cheapest mode that meets the latent bound as a maximum: throughput and tolerance of one mode,
-        # measured in this run next to the bench dtype (the precision ladder)
-        del vae
-        torch.cuda.empty_cache()
+        out.update(roofline_report(roofline_pass(step), args, elapsed / args.steps,
+                                   profiled=args.workload.startswith("cfg3") and args.dtype == "bf16"))
+        out["hbm"].update(out.pop("hbm_pmc", {}))
+    golden = GOLDEN_OF.get(args.workload)
+    have_golden = golden is not None and os.path.isfile(os.path.join(P.GOLDEN_DIR, golden + ".npz"))
+    tol_mode = (rank == 0 and world == 1 and not args.no_tolerance_mode and not args.no_parity and not args.dtype.startswith("f32")
+                and not cfg5 and have_golden)
+    vq = None
+    if tol_mode:
+        # the SAME workload on the cheapest mode that meets the latent bound as a maximum: throughput, roofline and tolerance of one
+        # mode, measured in this run next to the bench dtype (the precision ladder).  Timed BEFORE the CPU
+        # baseline child starts.
         vq = cls()
         P.load_seeded(vq, 0)
         vq = vq.float().cuda().eval()
         vq.fp32_mode = "fast"
         xq = x.float()
+
+        def qstep():
+            return vq.decode(vq.encode(xq).latent_dist.mode()).sample
         for _ in range(2):
-            vq.decode(vq.encode(xq).latent_dist.mode())
+            qstep()
         torch.cuda.synchronize()
         tq = time.perf_counter()
         nq = max(2, min(args.steps, 5))
         for _ in range(nq):
-            vq.decode(vq.encode(xq).latent_dist.mode())
+            qstep()
         torch.cuda.synchronize()
         tq = (time.perf_counter() - tq) / nq
-        rq = P.measure(vq, GOLDEN_OF[args.workload])
         out["tolerance_mode"] = {
             "dtype": "f32q", "what": "fp32 model, every product = fp16 MFMA + bf8 / fp6 correction MFMA (fp32_mode='fast'); bench.py --dtype f32q",
             "value": round(B * T / tq, 3), "unit": "frames/s", "ms_per_step": round(tq * 1e3, 3),
-            "latent_max_abs": float(f"{rq['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{rq['latent_mean_abs']:.3e}"),
-            "recon_psnr_db": round(rq["recon_psnr_db"], 2), "meets_north_star_tolerance": bool(rq["latent_max_abs"] <= 1e-3),
             "ratio_to_bench_dtype": round((B * T / tq) / out["value"], 3),
         }
+        if not args.no_roofline:
+            qargs = argparse.Namespace(**dict(vars(args), dtype="f32q"))
+            rq_ = roofline_report(roofline_pass(qstep), qargs, tq, profiled=False, brief=True)
+            rq_.pop("hbm_pmc", None)
+            out["tolerance_mode"].update(rq_)
+        del xq
+    cpu_handle = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_baseline_sample:
+        out["cpu_baseline"] = dict(cpu_baseline_measure(family, T, H, W, full=False), measured_in_this_run=True)
+    elif rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # every timed region of this run is over: the full-size CPU measurement runs beside the parity legs below
+        cpu_handle = cpu_baseline_start(family, T, H, W)
+    if rank == 0 and not args.no_parity and have_golden:
+        vae.enable_hip_graphs(False)
+        r = P.measure(vae, golden)
+        out["parity"] = {
+            "against": f"tests/golden/{golden}.npz = the reference's own modules, CPU fp32, same seeded weights/input",
+            "weights": "seeded random weights with PyTorch default-init statistics (GroupNorm gamma = 1, beta = 0): no checkpoint access",
+            "latent_max_abs": float(f"{r['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{r['latent_mean_abs']:.3e}"),
+            "recon_psnr_db": round(r["recon_psnr_db"], 2), "recon_max_abs": float(f"{r['recon_max_abs']:.3e}"),
+            "reference_own_noise_same_dtype": reference_noise(golden, args.dtype),
+            "north_star_tolerance": "|delta| <= 1e-3 on latents",
+            "meets_north_star_tolerance": bool(r["latent_max_abs"] <= 1e-3),
+        }
+    if rank == 0 and cfg5 and not args.no_parity and os.path.isfile(os.path.join(P.GOLDEN_DIR, "cfg5slice_sd3_b2_t33_512_enc.npz")):
+        # cfg 5's own fixture: a B = 2 slice of the batch of 8, both 17-frame windows of every clip, from the reference's modules
+        vae.enable_hip_graphs(False)
+        r = P.measure_encode(vae, "cfg5slice_sd3_b2_t33_512_enc", latents=lambda xx: vae.encode_latents(xx, sample=False))
+        out["parity"] = {
+            "against": "tests/golden/cfg5slice_sd3_b2_t33_512_enc.npz = the reference's own modules, CPU fp32: a B = 2 slice "
+                       "[2,3,33,512,512] of the workload's batch, through the timed entry point (encode_latents, posterior mode)",
+            "latent_max_abs": float(f"{r['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{r['latent_mean_abs']:.3e}"),
+            "latent_max_abs_per_batch_item": [float(f"{v:.3e}") for v in r["latent_max_abs_per_batch_item"]],
+            "north_star_tolerance": "|delta| <= 1e-3 on latents", "meets_north_star_tolerance": bool(r["latent_max_abs"] <= 1e-3),
+        }
+    if vq is not None:
+        del vae
+        torch.cuda.empty_cache()
+        rq = P.measure(vq, golden)
+        out["tolerance_mode"].update({
+            "weights": "seeded random weights (GroupNorm gamma = 1, beta = 0); the fp6 correction form is taken only where the norm's "
+                       "bound 8 max|gamma| + max|beta| <= 16 (cvvae_amd/engine.py act_bound), bf8 corrections elsewhere",
+            "latent_max_abs": float(f"{rq['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{rq['latent_mean_abs']:.3e}"),
+            "recon_psnr_db": round(rq["recon_psnr_db"], 2), "meets_north_star_tolerance": bool(rq["latent_max_abs"] <= 1e-3)})
         del vq
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(family, T, H, W, full=args.cpu_baseline_full)
+    if cpu_handle is not None:
+        out["cpu_baseline"] = cpu_baseline_collect(cpu_handle, args.cpu_baseline_wall, family, T, H, W)
     if rank == 0 and world == 1:
         out["reference_ops_on_this_gpu_model"] = torch_rocm_baseline(family, [B, 3, T, H, W], args.dtype, out["ms_per_step"])
     if dist is not None:

@@ -26,7 +26,7 @@
 //   * logical tile order: N-tile (and phase) fastest, then time, x, y, batch; XCD-aware bijective block remap.
 //
 // Reference semantics implemented here (file:line in /root/reference): see include/cvvae.h.  Design notes and
-// measurements: DESIGN.md section 3.1.  -DCVVAE_CONV_PROBE adds s_memtime stamps (tools/conv_probe.hip).
+// measurements: DESIGN.md section 3.1.  -DCVVAE_CONV_PROBE adds s_memtime stamps (tools/probes/conv_probe.hip).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -78,7 +78,7 @@ __device__ __forceinline__ f32x16 mfma_bf8_k64(f16x8 a_lo, f16x8 a_hi, f16x8 b_l
 // v_mfma_scale_f32_32x32x64_f8f6f4 with both operands "bf6" (OCP MX e3m2: 6 bits, normals 0.25 .. 28, subnormal quantum 1/16):
 // K = 64 at FOUR times the fp16 rate per K element.  An operand is 32 six-bit codes per lane (24 bytes, element i at bits 6i..6i+5
 // of the lane's first six dwords), same lane -> (row, k) map as above; each LANE carries one E8M0 scale byte (value 2^(byte-127),
-// byte 0 of the scale operand) for its 32 elements -- the hardware's block scale (tools/fp6_probe.hip, profiles/r3_fp6_probe.txt).
+// byte 0 of the scale operand) for its 32 elements -- the hardware's block scale (tools/probes/fp6_probe.hip, profiles/r3_fp6_probe.txt).
 typedef int i32x8_t __attribute__((ext_vector_type(8)));
 typedef int i32x4_t __attribute__((ext_vector_type(4)));
 typedef int i32x2_t __attribute__((ext_vector_type(2)));
@@ -155,7 +155,7 @@ struct ConvArgs {
   int gn_slabs;      // records per batch row and group = pixel tiles * WM * KG * (4-channel slots per group)
   int gn_G;          // groups of the stored tensor
   int gn_sh;         // log2(channels per group), >= 2
-  // tuning probe (tools/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
+  // tuning probe (tools/probes/conv_probe.hip, built with -DCVVAE_CONV_PROBE): s_memtime stamps of workgroup dbg_block
   unsigned long long* dbg;
   int dbg_block;
   int t_short_lo, t_short_hi;  // leading / trailing time tiles that are short (time folds): scheduled after the long ones
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   // XP == 2: the ring holds the FOUR records of one pair of taps -- [0] Whi of tap a, [1], [2] the halves of the pair's bf8
   // record, [3] Whi of tap b -- each refilled with the next pair's right after its last use
   // (XQ_DEPTH pairs in flight: with four fragments per wave a pair lasts ~400-500 clocks -- less than an L2 round trip under load,
-  //  and the MFMA phase then runs at the latency of its weight stream: measured 60 ticks per MFMA, tools/conv_probe.hip CFG 11/12)
+  //  and the MFMA phase then runs at the latency of its weight stream: measured 60 ticks per MFMA, tools/probes/conv_probe.hip CFG 11/12)
 #ifndef CVVAE_XQ_DEPTH
 #define CVVAE_XQ_DEPTH 2
 #endif

@@ -30,6 +30,16 @@ CVVAE_CONV_XQ6(CVVAE_EXTERN_XQ6)
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_NB2(CVVAE_EXTERN_NB2)
 
+// Per-frame GroupNorm tables are merged from the statistics records of a kT == 1 conv (cvvae_gn_finalize_frames, ops.GNPartials.frames):
+// that assumes ONE-FRAME tiles written in frame-major record order, i.e. TT == 1 for every kT == 1 instance of every list
+#define CVVAE_CHECK_FRAME_TILES(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  static_assert(KT != 1 || TT == 1, "kT == 1 instances must have one-frame tiles: per-frame statistics are merged from their records");
+CVVAE_CONV_ALL(CVVAE_CHECK_FRAME_TILES)
+CVVAE_CONV_NB2(CVVAE_CHECK_FRAME_TILES)
+CVVAE_CONV_XP(CVVAE_CHECK_FRAME_TILES)
+CVVAE_CONV_XQ(CVVAE_CHECK_FRAME_TILES)
+CVVAE_CONV_XQ6(CVVAE_CHECK_FRAME_TILES)
+
 typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 
 struct Instance {

@@ -103,7 +103,7 @@ __device__ __forceinline__ uint4 xq_half(int kh, const float (&w)[16]) {
   return make_uint4(lo.x, lo.y, hi.x, hi.y);
 }
 // e3m2 ("bf6": sign, 3 exponent bits of bias 3, 2 mantissa bits; normals 0.25 .. 28, subnormals k/16), round to nearest even,
-// saturating -- the rounding of v_cvt_scalef32_pk32_bf6_f16 (tools/fp6_probe.hip)
+// saturating -- the rounding of v_cvt_scalef32_pk32_bf6_f16 (tools/probes/fp6_probe.hip)
 __device__ __forceinline__ unsigned enc_e3m2(float v) {
   const unsigned sgn = (__float_as_uint(v) >> 31) << 5;
   const float a = fminf(fabsf(v), 28.0f);

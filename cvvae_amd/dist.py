@@ -58,24 +58,46 @@ def _gather_time(local: torch.Tensor, counts: List[int], group=None) -> torch.Te
         pad[:, :, :local.shape[2]] = local
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad.contiguous(), group=group)
+    TRAFFIC["sent"] += _nbytes(pad) * (world - 1)
+    TRAFFIC["recv"] += _nbytes(pad) * (world - 1)
     return torch.cat([b[:, :, :c] for b, c in zip(bufs, counts) if c], dim=2)
 
 
+def _peer(group, r: int) -> int:
+    """P2POp / isend / irecv take GLOBAL ranks whatever `group` is: translate a group-relative rank."""
+    return r if group is None else dist.get_global_rank(group, r)
+
+
+# bytes this process has put on / taken off the wire through the point-to-point and gather calls of this module (diagnostic:
+# bench.py prints them per step; reset with TRAFFIC.update(sent=0, recv=0))
+TRAFFIC = {"sent": 0, "recv": 0}
+
+
+def _nbytes(t: torch.Tensor) -> int:
+    return t.numel() * t.element_size()
+
+
 def _exchange_boundary(x_local: torch.Tensor, have: List[bool], group=None) -> Optional[torch.Tensor]:
-    """every rank with frames sends its LAST frame to the next rank that has frames; returns the received frame."""
+    """every rank with frames sends its LAST frame to the next rank that has frames; returns the received frame.
+    Send and receive are posted as ONE batch (`batch_isend_irecv`: on RCCL a single group call, so the N-1 transfers of a
+    clip run concurrently instead of serialising into a chain of blocking pairs)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     active = [r for r in range(world) if have[r]]
     if rank not in active:
         return None
     i = active.index(rank)
-    reqs, recv = [], None
+    p2p, recv = [], None
     if i + 1 < len(active):
-        reqs.append(dist.isend(x_local[:, :, -1:].contiguous(), dst=active[i + 1], group=group))
+        last = x_local[:, :, -1:].contiguous()
+        p2p.append(dist.P2POp(dist.isend, last, _peer(group, active[i + 1]), group))
+        TRAFFIC["sent"] += _nbytes(last)
     if i > 0:
         recv = torch.empty_like(x_local[:, :, :1]).contiguous()
-        reqs.append(dist.irecv(recv, src=active[i - 1], group=group))
-    for q in reqs:
-        q.wait()
+        p2p.append(dist.P2POp(dist.irecv, recv, _peer(group, active[i - 1]), group))
+        TRAFFIC["recv"] += _nbytes(recv)
+    if p2p:
+        for q in dist.batch_isend_irecv(p2p):
+            q.wait()
     return recv
 
 
@@ -119,16 +141,15 @@ def _sharded(model, x: torch.Tensor, T_total: int, encode: bool, time_sharded: b
         else:
             span = rb - ra + (1 if ra > 0 else 0)          # frames seen incl. the halo
             counts.append(f(span) - (1 if ra > 0 else 0))  # minus the dropped first output frame
-    if out is None:
-        ref_shape = [0] * 5
-        shp = torch.tensor(ref_shape, device=x.device)
-    else:
-        shp = torch.tensor(list(out.shape), device=x.device)
-    shapes = [torch.empty_like(shp) for _ in range(world)]
-    dist.all_gather(shapes, shp, group=group)
-    proto = next(s for s in shapes if int(s[2]) > 0).tolist()
-    if out is None:
-        out = x.new_zeros((proto[0], proto[1], 0, proto[3], proto[4]))
+    if any(rb <= ra for ra, rb in ranges):
+        # a rank without a window has to learn the result's geometry from one that has (a host sync; only when the clip has fewer
+        # windows than there are ranks -- otherwise nothing here waits for the device)
+        shp = torch.tensor([0] * 5 if out is None else list(out.shape), device=x.device)
+        shapes = [torch.empty_like(shp) for _ in range(world)]
+        dist.all_gather(shapes, shp, group=group)
+        proto = next(s for s in shapes if int(s[2]) > 0).tolist()
+        if out is None:
+            out = x.new_zeros((proto[0], proto[1], 0, proto[3], proto[4]))
     return _gather_time(out, counts, group)
 
 
@@ -142,6 +163,33 @@ def encode_windows_sharded(model, x: torch.Tensor, T_total: Optional[int] = None
 def decode_windows_sharded(model, z: torch.Tensor, T_total: Optional[int] = None, time_sharded: bool = False,
                            gather: bool = True, group=None):
     return _sharded(model, z, z.shape[2] if T_total is None else T_total, False, time_sharded, gather, group)
+
+
+def codec_step_time_sharded(model, x_local: torch.Tensor, T_total: int, group=None):
+    """encode + decode of ONE clip whose frames arrive sharded on time (rank r holds `owned_frames(T_total, 16, world, r)`):
+    the step `bench.py --gpus N` times and the gloo / RCCL tests check.
+
+      1. causal halo exchange: the last pixel frame of every rank goes to its right neighbour (one batched send/recv);
+      2. every rank encodes its own windows (modeling_vae.py:519-536) -- no collective inside the network;
+      3. the posterior moments are all-gathered on time (the clip's latent: what a caller of `encode` gets back; 15 MB at cfg 4);
+      4. every rank decodes its own run of the 5-latent-frame windows (modeling_vae.py:605-622) out of the gathered latent -- the
+         boundary latent frame is already there, nothing else travels; the pixels stay sharded on time.
+
+    -> (moments of the whole clip [every rank], this rank's reconstructed frames or None).  Concatenated over the ranks the
+    frames equal `model.decode(model.encode(x).latent_dist.mode()).sample` bit for bit."""
+    mom = encode_windows_sharded(model, x_local, T_total=T_total, time_sharded=True, gather=True, group=group)
+    z = mom[:, :mom.shape[1] // 2]
+    y_local = decode_windows_sharded(model, z, time_sharded=False, gather=False, group=group)
+    return mom, y_local
+
+
+def decoded_frames_of_rank(model, T_latent: int, world: int, rank: int) -> Tuple[int, int]:
+    """pixel-frame range [a, b) of the clip that `rank` holds after `codec_step_time_sharded`"""
+    a, b = owned_frames(T_latent, model.decode_n_frames_a_time, world, rank)
+    if b <= a:
+        return 0, 0
+    tnc = model.config.time_n_compress
+    return (0 if a == 0 else (a - 1) * tnc + 1), (b - 1) * tnc + 1
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -237,10 +285,12 @@ def _units_sharded(model, x: torch.Tensor, encode: bool, gather: bool, group=Non
         if src == dst:
             continue
         if rank == src:
-            ops_p2p.append(dist.P2POp(dist.isend, outs[u].contiguous(), dst, group, tag=u))
+            ops_p2p.append(dist.P2POp(dist.isend, outs[u].contiguous(), _peer(group, dst), group, tag=u))
+            TRAFFIC["sent"] += _nbytes(outs[u])
         elif rank == dst:
             outs[u] = torch.empty(out_shape(u), dtype=x.dtype, device=x.device)
-            ops_p2p.append(dist.P2POp(dist.irecv, outs[u], src, group, tag=u))
+            ops_p2p.append(dist.P2POp(dist.irecv, outs[u], _peer(group, src), group, tag=u))
+            TRAFFIC["recv"] += _nbytes(outs[u])
     if ops_p2p:
         for q in dist.batch_isend_irecv(ops_p2p):
             q.wait()

@@ -32,6 +32,12 @@ class WeightCache:
         # ... and, behind a GroupNorm + SiLU, with e3m2 ("fp6") corrections (CVVAE_F32Q6: 1.5x instead of 2x the MFMA time of a 16-bit
         # model); CVVAE_F32_FP6=0 keeps the bf8 form everywhere (A/B aid)
         self.fast6 = os.environ.get("CVVAE_F32_FP6", "1") != "0"
+        # e3m2 spans ~9 binades under ONE power-of-two scale per launch: with a bound b the codes' normal range starts at about b / 112,
+        # and post-SiLU negatives never exceed 0.278 -- a bound above ~16 would put that whole branch (and the small positives) into
+        # e3m2's subnormals, where the correction terms degrade towards the fp16 model's error.  The form is MEASURED at the bound of
+        # default-initialised norms (8) and on spread affines up to ~14 (tests/test_gpu_fast_fp32.py); norms whose bound exceeds this
+        # cap keep the bf8 form, which needs no scale.  (No real checkpoint can be measured here: DESIGN.md section 4.)
+        self.fp6_bound_cap = float(os.environ.get("CVVAE_F32_FP6_CAP", "16"))
 
     def _q(self) -> str:
         return "#q" if self.fast else ""
@@ -50,7 +56,7 @@ class WeightCache:
             # median) returns 0.0 = "no bound": its convs keep the bf8 form, which needs no scale
             bc = (sigmas * g.detach().abs().float() + b.detach().abs().float()).flatten()
             top, mid = float(bc.max()), float(bc.median())
-            hit = (key, max(top, 1e-6) if top <= 8.0 * max(mid, 1e-30) else 0.0)
+            hit = (key, max(top, 1e-6) if (top <= 8.0 * max(mid, 1e-30) and top <= self.fp6_bound_cap) else 0.0)
             self._c[tag] = hit
         return hit[1]
 
@@ -258,6 +264,14 @@ class WeightCache:
             return False
 
 
+def switches_key(wc=None) -> tuple:
+    """every execution switch that changes the launch sequence of a pass: part of the hipGraph cache key (modeling._forward_graphed),
+    so that flipping one in a live process re-captures instead of replaying the other setting's graph"""
+    return (fold_upsample(), fold_t1(), fuse_shortcut(), fold_time(), rowpack_conv_in(), tapsn_conv_out(), fused_attention(),
+            per_frame_stats_from_records(), os.environ.get("CVVAE_PREPASS", "auto"), os.environ.get("CVVAE_CONV_FORCE", ""),
+            None if wc is None else (wc.fast, wc.fast6, wc.fp6_bound_cap))
+
+
 def fold_upsample() -> bool:
     """Upsample3D = nearest x(1,2,2) + 3x3x3 conv.  Default: run it as four 3x2x2 phase convolutions over the stored input
     with folded weights (2.25x fewer MFMAs; differs from the 27-tap form only by one rounding of each folded weight).
@@ -311,15 +325,22 @@ def _shortcut_scale_fits(wc: WeightCache, sc_name: str, pw2, dtype) -> bool:
     return hit[1] * pw2.wscale < 32768.0
 
 
-def _fused_prologue() -> bool:
-    return os.environ.get("CVVAE_PREPASS", "auto") in ("auto", "0")
+def _fused_prologue(x: torch.Tensor, k: Tuple[int, int, int], cout: int) -> bool:
+    """does THIS launch keep its GroupNorm + SiLU in the conv's staging?  The one decision (prepass) both the weight form (fp6
+    corrections need the fused prologue: WeightCache.conv act_norm) and the launch follow."""
+    return not prepass(x, k, cout)
+
+
+def _cout(wc: "WeightCache", pre: str) -> int:
+    return int(wc.m.get_parameter(pre + ".weight").shape[0])
 
 
 def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
     """conv2 (per-frame 3x3 over GN+SiLU(h), zero pad) + shortcut(x) + add -- vae_blocks3d_sd3.py:559-567, vae_models.py:404-410."""
-    pw2 = wc.conv(pre + ".conv2", (1, 3, 3), act_norm=pre + ".norm2" if _fused_prologue() else None)
+    fused = _fused_prologue(h, (1, 3, 3), _cout(wc, pre + ".conv2"))
+    pw2 = wc.conv(pre + ".conv2", (1, 3, 3), act_norm=pre + ".norm2" if fused else None)
     kw = dict(pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2, gn_out=G32 if want_stats else 0)
-    if prepass(h, (1, 3, 3), pw2.cout):
+    if not fused:
         h = ops.gn_silu_apply(h, g2)
         kw.update(prologue=L.PRO_NONE, gn=None)
     if not wc.has(sc_name + ".weight"):
@@ -356,7 +377,8 @@ def conv3(wc: WeightCache, x: torch.Tensor, pre: str, *, pad, pad_mode_t, pad_mo
     """One 3x3x3 convolution of the path (CausalConv3d / Conv3d / nn.Conv3d / Downsample3D).  On a single-frame input whose
     time padding makes the three taps coincide it runs as the temporally folded 1x3x3 conv (fold_t1).
     act_norm: name of the GroupNorm behind the GN+SiLU prologue (WeightCache.conv)."""
-    if not (kw.get("prologue") == L.PRO_GN_SILU and tuple(stride) == (1, 1, 1) and _fused_prologue()):
+    if not (kw.get("prologue") == L.PRO_GN_SILU and tuple(stride) == (1, 1, 1) and not kw.get("gn_per_frame")
+            and _fused_prologue(x, (3, 3, 3), _cout(wc, pre))):
         act_norm = None
     if x.shape[1] == 1 and fold_t1() and pad[0][0] + pad[0][1] == 2:
         pw = wc.conv_t1(pre, "sum" if pad_mode_t == REP else "center", cin_pad=cin_pad)
@@ -600,7 +622,8 @@ def c2d_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, want_stats: bool 
     """ResnetBlock2D.forward, lvdm/modules/diffusionmodules/vae_blocks_sd3.py:368-421, on [frames,1,H,W,C]: GN(eps 1e-6)+SiLU
     fused into conv1 and conv2 (per-frame 3x3, zero pad), 1x1 shortcut and residual add in conv2's launch."""
     g1 = _norm(wc, x, xp, pre + ".norm1", 1e-6)
-    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (1, 3, 3), act_norm=pre + ".norm1" if _fused_prologue() else None), pad=P2D,
+    # (this launch always keeps its prologue fused: no prepass decision in front of it)
+    h, hp = ops.conv(x, wc.conv(pre + ".conv1", (1, 3, 3), act_norm=pre + ".norm1"), pad=P2D,
                      pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32)
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     if tape is not None:

@@ -112,7 +112,7 @@ class _Net(nn.Module):
 
     def _forward_graphed(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         sig = tuple((p.data_ptr(), p._version) for p in self.parameters())
-        key = (tuple(x.shape), x.dtype, x.device.index, tuple(sorted(kwargs.items())), engine.fold_upsample(), engine.fold_t1(), engine.fuse_shortcut(), engine.fold_time(), self._fp32_fast)
+        key = (tuple(x.shape), x.dtype, x.device.index, tuple(sorted(kwargs.items())), engine.switches_key(self._cache()), self._fp32_fast)
         ent = self._graphs.get(key)
         if ent is not None and ent[0] != sig:  # weights were replaced / moved / modified: the captured pointers are stale
             del self._graphs[key]

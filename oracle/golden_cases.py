@@ -46,6 +46,14 @@ BIG_CASES = {
     "cfg4win_sd3_t17_720x1280": ("sd3", {}, (1, 3, 17, 720, 1280), 0, 24, 8),
 }
 
+# ENCODE-ONLY fixtures at full size (the training-side latent pre-compute of BASELINE cfg 5: batch-8 T=33 512x512 encode; the
+# fixture is a B = 2 slice of the 8 -- batch items are independent network calls, two of them pin the batch indexing -- with both
+# 17-frame windows of every clip): the posterior mean in full, the log-variance at stride 2 over H and W
+# name -> (family, config overrides, input shape, weight seed, input seed)
+ENC_CASES = {
+    "cfg5slice_sd3_b2_t33_512_enc": ("sd3", {}, (2, 3, 33, 512, 512), 0, 25),
+}
+
 
 def recon_subsample(recon, s: int):
     """recon [B,C,T,H,W] (numpy or torch) -> [B,C,T,H/s,W/s]: frame t sampled at rows (t % s)::s, columns (3t % s)::s"""

@@ -133,8 +133,44 @@ def main_big(only=None):
               f"reference CPU fp32 encode {t1 - t0:.1f}s decode {t2 - t1:.1f}s ({torch.get_num_threads()} threads)", flush=True)
 
 
+def main_enc(only=None):
+    """encode-only fixtures at full size (BASELINE cfg 5's batch slice) from the reference's own modules"""
+    import time
+
+    from oracle.golden_cases import ENC_CASES
+
+    ref = load_reference()
+    torch.set_grad_enabled(False)
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, (family, over, shape, wseed, xseed) in ENC_CASES.items():
+        if only and name not in only:
+            continue
+        cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
+        model = cls(**over).eval()
+        sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+        model.load_state_dict(sd, strict=True)
+        x = seeded_input(shape, xseed)
+        t0 = time.time()
+        mnp = model.encode(x).latent_dist.parameters.numpy().astype(np.float32)
+        t1 = time.time()
+        zc = mnp.shape[1] // 2
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        np.savez_compressed(
+            os.path.join(out_dir, name + ".npz"),
+            moments_mean=mnp[:, :zc].copy(), moments_logvar_sub=mnp[:, zc:, :, ::2, ::2].copy(),
+            moments_shape=np.asarray(mnp.shape, dtype=np.int64),
+            moments_mean_f64=np.float64(mnp.astype(np.float64).mean()),
+            weight_abs_sum=np.float64(wsum), n_tensors=np.int64(len(sd)),
+            ref_cpu_seconds=np.asarray([t1 - t0]), ref_cpu_threads=np.int64(torch.get_num_threads()),
+        )
+        print(f"{name}: moments {tuple(mnp.shape)} wsum {wsum:.6f} reference CPU fp32 encode {t1 - t0:.1f}s "
+              f"({torch.get_num_threads()} threads)", flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "constraint":
+    if len(sys.argv) > 1 and sys.argv[1] == "enc":
+        main_enc(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "constraint":
         main_constraint()
     elif len(sys.argv) > 1 and sys.argv[1] == "ldm":
         main_ldm()

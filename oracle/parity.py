@@ -8,7 +8,7 @@ import os
 import numpy as np
 import torch
 
-from .golden_cases import BIG_CASES, CASES, recon_subsample
+from .golden_cases import BIG_CASES, CASES, ENC_CASES, recon_subsample
 from .seeded import seeded_input, seeded_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -89,6 +89,33 @@ def measure(model, name: str, golden_dir: str = GOLDEN_DIR) -> dict:
         "recon_max_abs": float(np.abs(r - g).max()), "recon_psnr_db": float(10 * np.log10(4.0 / max(mse, 1e-30))),
     }
     out.update(extra)
+    return out
+
+
+@torch.no_grad()
+def measure_encode(model, name: str, golden_dir: str = GOLDEN_DIR, latents=None) -> dict:
+    """encode-only fixtures (golden_cases.ENC_CASES: BASELINE cfg 5's batch slice) against the reference's `moments`:
+    `model.encode(x).latent_dist.parameters` (mean and log-variance), or -- `latents` given: the latent pre-compute entry point
+    bench.py times, x -> posterior MODE -- the posterior mean alone."""
+    family, over, shape, wseed, xseed = ENC_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    x = seeded_input(shape, xseed).to(model.dtype).to(model.device)
+    mshape = tuple(int(v) for v in gold["moments_shape"])
+    zc = mshape[1] // 2
+    if latents is not None:
+        mean = latents(x).float().cpu().numpy()
+        assert tuple(mean.shape) == (mshape[0], zc) + mshape[2:], (mean.shape, mshape)
+        dl = None
+    else:
+        mom = model.encode(x).latent_dist.parameters.float().cpu().numpy()
+        assert tuple(mom.shape) == mshape, (mom.shape, mshape)
+        mean = mom[:, :zc]
+        dl = np.abs(mom[:, zc:, :, ::2, ::2] - gold["moments_logvar_sub"])
+    dm = np.abs(mean - gold["moments_mean"])
+    out = {"case": name, "shape": list(shape), "latent_max_abs": float(dm.max()), "latent_mean_abs": float(dm.mean()),
+           "latent_max_abs_per_batch_item": [float(dm[b].max()) for b in range(dm.shape[0])]}
+    if dl is not None:
+        out["moments_max_abs"] = float(max(dm.max(), dl.max()))
     return out
 
 

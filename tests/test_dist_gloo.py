@@ -180,3 +180,93 @@ def test_unit_plan_cfg4_and_short_clips():
     # decode side: latent tiles of 72 with stride 56
     wins, grid, units, owner, _ = D.unit_plan(m, (1, 16, 33, 90, 160), False, 8)
     assert len(wins) == 8 and [len(r) for r in grid] == [3, 3] and [owner.count(r) for r in range(8)] == [6] * 8
+
+
+def _worker_bench_step(rank, world, port, q):
+    """bench.py's own N > 1 functions -- temporal_shard_input / temporal_shard_step / temporal_shard_check -- on the REAL
+    CVVAESD3Model over gloo (kernels emulated on the CPU): one clip of 1 + 16 N frames, time-sharded input, halo by batched
+    send/recv, moments all-gathered, every rank checking its own slice against the single-process wrapper"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import bench
+        import cvvae_amd
+        from cvvae_amd import dist as D
+        from oracle.seeded import seeded_state_dict
+        from tests import emu_ops
+        torch.set_num_threads(4)
+        m = cvvae_amd.CVVAESD3Model()
+        m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 0), strict=True)
+        m = m.eval()
+        T = bench.temporal_shard_T(world)
+        x_full, x_local = bench.temporal_shard_input(T, 32, 32, world, rank, torch.float32, "cpu")
+        a, b = D.owned_frames(T, 16, world, rank)
+        assert x_local.shape[2] == b - a == (17 if rank == 0 else 16)
+        with emu_ops.patched(whole_model=True), torch.no_grad():
+            D.TRAFFIC.update(sent=0, recv=0)
+            mom, y_local = bench.temporal_shard_step(m, x_local, T)
+            sent, recv = D.TRAFFIC["sent"], D.TRAFFIC["recv"]
+            ok = bench.temporal_shard_check(m, x_full, mom, y_local, world, rank, "cpu")
+        frame = x_local[:, :, :1].numel() * 4
+        gathered = 2 * (mom.numel() // mom.shape[2]) * 5 * 4 * (world - 1) // 2  # padded all_gather: 5 latent frames per rank
+        q.put((rank, ok, tuple(mom.shape), tuple(y_local.shape), sent, recv, frame, gathered))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_temporal_shard_step_over_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    world = 2
+    procs = [ctx.Process(target=_worker_bench_step, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=900) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok, ms, ys, sent, recv, frame, gathered in res:
+        assert ok, (rank, ms, ys)
+        assert ms[2] == 9 and ys[2] == (17 if rank == 0 else 16)
+        # wire accounting: the halo frame goes 0 -> 1 (one pixel frame), the gather moves every other rank's padded moments
+        assert sent == (frame if rank == 0 else 0) + gathered and recv == (frame if rank == 1 else 0) + gathered, (rank, sent, recv)
+
+
+def _worker_subgroup(rank, world, port, q):
+    """the sharding entry points on a SUBGROUP (ranks 1..3 of 4): P2POp peers are global ranks whatever the group is"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tests.test_host_logic import make
+        from cvvae_amd import dist as D
+        grp = dist.new_group([1, 2, 3])
+        if rank == 0:
+            q.put((rank, True, True))
+            return
+        gr, gw = dist.get_rank(grp), dist.get_world_size(grp)
+        m = make("sd3", tile_spatial_size=144)
+        g = torch.Generator().manual_seed(0)
+        x = torch.rand((1, 3, 49, 160, 200), generator=g) * 2 - 1
+        full = m.encode(x).latent_dist.parameters
+        a, b = D.owned_frames(49, 16, gw, gr)
+        got = D.encode_windows_sharded(m, x[:, :, a:b].contiguous(), T_total=49, time_sharded=True, group=grp)
+        x1 = x[:, :, :17].contiguous()  # one window, 2x2 tiles over three ranks: raw tiles point-to-point inside the subgroup
+        got_u = D.encode_units_sharded(m, x1, group=grp)
+        q.put((rank, torch.equal(got, full), torch.equal(got_u, m.encode(x1).latent_dist.parameters)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharding_on_a_subgroup():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_subgroup, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(4)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(a and b for _, a, b in res), res

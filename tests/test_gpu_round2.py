@@ -251,6 +251,12 @@ def _nccl_worker(rank, world, port, q):
         ok_e = ok_e and torch.equal(D.encode_units_sharded(m, x1), m.encode(x1).latent_dist.parameters)
         z1 = z[:, :, :5].contiguous()
         ok_d = ok_d and torch.equal(D.decode_units_sharded(m, z1), m.decode(z1).sample)
+        # ... and bench.py's own N > 1 step (what `bench.py --gpus 2` times): one clip of 33 frames, time-sharded, checked per rank
+        import bench
+        Tb = bench.temporal_shard_T(world)
+        xf, xl = bench.temporal_shard_input(Tb, 96, 128, world, rank, dtype, f"cuda:{rank}")
+        mom, yl = bench.temporal_shard_step(m, xl, Tb)
+        ok_e = ok_e and bench.temporal_shard_check(m, xf, mom, yl, world, rank, f"cuda:{rank}")
         q.put((rank, ok_e, ok_d))
     finally:
         dist.destroy_process_group()

@@ -1,5 +1,5 @@
 """On-box denominators: what dense bf16 matrix throughput does THIS MI355X sustain under its power cap?
- (1) hipBLASLt through torch.matmul (8192^3 and 16384x8192x8192, bf16), (2) tools/valu_mfma_probe (register-only MFMA stream)."""
+ (1) hipBLASLt through torch.matmul (8192^3 and 16384x8192x8192, bf16), (2) tools/probes/valu_mfma_probe (register-only MFMA stream)."""
 import subprocess, sys, os, time
 import torch
 for (m, n, k) in ((8192, 8192, 8192), (16384, 8192, 8192), (4096, 4096, 16384)):

@@ -1,6 +1,6 @@
 // conv_probe.hip -- tuning probe: launches ONE conv_fwd_kernel instantiation on synthetic data with s_memtime stamps in
 // the pipeline (kernel built with -DCVVAE_CONV_PROBE) and prints the per-wave timeline of one workgroup.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCVVAE_CONV_PROBE -DCFG=<n> -Icvvae_amd/csrc tools/conv_probe.hip -o /tmp/conv_probe
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DCVVAE_CONV_PROBE -DCFG=<n> -Icvvae_amd/csrc tools/probes/conv_probe.hip -o /tmp/conv_probe
 // Marks per wave: [0] kernel start, [1] first stage done, then per chunk: loop top, after phase 1 (group 0: stage next,
 // group 1: nothing), after MFMAs, after phase 2 (group 1: stage next), [last-1] after the final barrier, [last] end.
 #include <hip/hip_runtime.h>

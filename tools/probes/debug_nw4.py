@@ -1,6 +1,6 @@
 """debug aid: determinism of the 4-wave per-frame conv when two workgroups share a CU (grid > #CUs)"""
 import os, sys, itertools
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from cvvae_amd import ops
 

@@ -1,6 +1,6 @@
 // fp6_probe.hip -- what gfx950's fp6 ("bf6" = e3m2) conversion and block-scaled MFMA instructions do, bit for bit (a measurement
 // aid: the fast-fp32 correction MFMA of conv_kernel.h relies on exactly these facts).
-//   hipcc --offload-arch=gfx950 -O2 tools/fp6_probe.hip -o /tmp/fp6_probe && /tmp/fp6_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/fp6_probe.hip -o /tmp/fp6_probe && /tmp/fp6_probe
 // Part 1: v_cvt_scalef32_2xpk16_bf6_f32 / v_cvt_scalef32_pk32_bf6_f16 -- which input element lands in which 6-bit slot, the
 //         direction of the scale, rounding, saturation, subnormals.
 // Part 2: v_mfma_scale_f32_32x32x64_f8f6f4 with bf6 operands -- lane/slot -> (row, k) map and the per-lane E8M0 scale bytes,
