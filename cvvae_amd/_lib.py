@@ -12,7 +12,7 @@ F16, BF16, F32, F32Q, F32Q6 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 class ConvDesc(ctypes.Structure):
@@ -68,6 +68,11 @@ PROTOTYPES = {
     "cvvae_gn_bwd_input": (_i32, [_i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
     "cvvae_softmax_bwd_rows": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),
     "cvvae_upsample2x_sum": (_i32, [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "cvvae_conv_wgrad_workspace_bytes": (_i64, [ctypes.POINTER(ConvDesc)]),
+    "cvvae_conv_wgrad": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _i64, _vp, _vp, _vp]),
+    "cvvae_channel_sums_workspace_bytes": (_i64, [_i32, _i64, _i32]),
+    "cvvae_channel_sums": (_i32, [_i32, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "cvvae_pad_fold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "cvvae_layernorm": (_i32, [_i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "cvvae_softmax_rows": (_i32, [_i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp]),
     "cvvae_transpose": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _vp, _i64, _i64, _vp]),

@@ -117,7 +117,11 @@
   X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2) \
   X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 1, 0,2) \
   X(1,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
-  X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2)
+  X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2) \
+  X(3,1,1, 1,1,1, 4,4,16, 8,1,1, 2, 1,0)
+// (the last row: the taps-in-N last layer, G13, for fp32 models -- exact AND fast: a (3,1,1) kernel has single-tap runs, which the
+//  fast form cannot pair, so both modes run it as three fp16 MFMAs per product: 9 MFMA units per k16 step instead of the 27-tap
+//  layer's 55 (fast) / 81 (exact) for 3 of 32 useful output columns)
 // (split in two translation units for the parallel build)
 #define CVVAE_CONV_XP_A(X) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 0,0) \
@@ -130,6 +134,7 @@
   X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2) \
   X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 1, 0,2)
 #define CVVAE_CONV_XP_B(X) \
+  X(3,1,1, 1,1,1, 4,4,16, 8,1,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 0,0) \
   X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0) \

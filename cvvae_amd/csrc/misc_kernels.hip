@@ -1731,6 +1731,9 @@ int cvvae_conv_out_gather(int32_t dtype, const float* V, int32_t B, int32_t T, i
   else if (dtype == CVVAE_F16)
     hipLaunchKernelGGL((conv_out_gather_kernel<_Float16, 3>), dim3(grid), dim3(256), 0, s, V, T, H, W, (long long)ldv, bias, pad_mode_hw,
                        npix, (_Float16*)out_ncdhw, out_u8);
+  else if (dtype == CVVAE_F32)
+    hipLaunchKernelGGL((conv_out_gather_kernel<float, 3>), dim3(grid), dim3(256), 0, s, V, T, H, W, (long long)ldv, bias, pad_mode_hw,
+                       npix, (float*)out_ncdhw, out_u8);
   else
     return CVVAE_EUNSUPPORTED;
   CHECK_LAUNCH();

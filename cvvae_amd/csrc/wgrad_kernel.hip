@@ -1,0 +1,495 @@
+// wgrad_kernel.hip -- weight gradient of the codec's convolutions on MFMA, and the small reductions of the training-side backward
+// (bias / GroupNorm-affine gradients, the adjoint of replicate padding).  SURVEY.md 8(f) rank 4: training the 3-D networks
+// (/root/reference/lvdm/models/autoencoder.py:1057-1090 runs `z, xrec = self(x)` through the TRAINABLE encoder / decoder).
+//
+//   dW[co][ci][tap] = sum over output pixels p of  gy[p][co] * a[src(p, tap)][ci]
+//
+// a = the operand the forward conv multiplied (after GroupNorm + SiLU; padding applied by coordinate mapping exactly as the
+// forward's staging does: replicate = clamp, zero = skip), gy = dL/d(conv output).  The contraction runs over PIXELS, which are
+// the slow axis of NDHWC tensors, so both MFMA operands are transposed on their way into LDS:
+//
+//   * workgroup = 8 waves; tile = 128 output channels x 64 input channels x the KH*KW spatial taps of ONE time tap
+//     (blockIdx.z = dt): 4 x 2 x 9 accumulator fragments of 32 x 32, nine per wave (144 registers);
+//   * K panel = KP consecutive output pixels of one output row (b, t, y).  Staging: 16-byte global loads (8 channels of one
+//     pixel; a wave covers 8 pixels x 64 channels = whole 128-byte lines) into registers, then eight 2-byte LDS writes per load
+//     into CHANNEL-major rows  GS[co][k]  and  XS[dy][dx][ci][k] = a[.., x0*sW + k*sW + dx - pw][ci]  -- one copy per kW tap, so
+//     that every MFMA operand is an ALIGNED ds_read_b128 of 8 consecutive k (row pitch KP*2+16 bytes: conflict-free for the
+//     reads and for the transposing writes); strides and both padding flavours live in the staging's coordinate map;
+//   * the loads of panel i+1 are issued before the MFMAs of panel i (register prefetch), LDS is single-buffered;
+//   * MFMA: v_mfma_f32_32x32x16 with A = gy^T fragment (rows = output channels), B = a fragment (columns = input channels): an
+//     accumulator lane holds one input channel and 16 output channels of one tap;
+//   * the output pixels are cut into `nslab` slabs of rows; every workgroup writes its fp32 partial tile
+//     part[slab][tap][co][ci]; wgrad_reduce_kernel sums the slabs in index order (deterministic) into PyTorch's [Cout][Cin][taps].
+//   * fp32 models (XP): both operands are split bf16 hi + lo (gradients have fp32's range, so bf16 rather than fp16) and every
+//     product runs as three MFMAs  g_hi a_hi + g_hi a_lo + g_lo a_hi  (~2^-16 relative); KP = 32 keeps the doubled LDS in budget.
+//
+// Bound: MFMA for the 3x3x3 layers (same FLOPs as the forward), but this first version is staging-bound (88 two-byte LDS writes
+// per thread and panel against 36 MFMAs per wave); it exists for correctness of the training path, not yet for speed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/cvvae.h"
+#include "conv_kernel.h"
+
+namespace cvvae {
+
+struct WgradArgs {
+  const void* a;
+  const void* g;
+  float* part;
+  int B, Ti, Hi, Wi, Cin;
+  long long a_ps;
+  int To, Ho, Wo, Cout;
+  long long g_ps;
+  int kT, sT, sH, sW, pt, ph, pw, mode_t, mode_hw;
+  int nslab, rows_total, n_ci_blk;
+  int Coutp, Cinp;  // padded to multiples of 128 / 64: the partial buffer's channel extents
+};
+
+template <typename T, int KHW, bool XP>
+__global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
+  using TIO = std::conditional_t<XP, float, T>;
+  using v8 = typename Tr<T>::v8;
+  constexpr int KP = XP ? 32 : 64;        // output pixels per K panel
+  constexpr int ROWP = KP * 2 + 16;       // LDS row pitch (bytes): odd multiple of 16
+  constexpr int NSP = KHW * KHW;          // spatial taps
+  constexpr int CO = 128, CI = 64;
+  constexpr int NPART = XP ? 2 : 1;       // hi (and lo) copies
+  constexpr int XS_BYTES = NSP * CI * ROWP, GS_BYTES = CO * ROWP;
+  constexpr int MAXSW = 2;
+  constexpr int XPIX_MAX = (KP - 1) * MAXSW + KHW;
+  constexpr int NXI = (KHW * XPIX_MAX * 8 + 511) / 512;  // 16-byte (8-channel) x items per thread and panel
+  constexpr int NGI = (KP * 16 + 511) / 512;
+  static_assert(NPART * (XS_BYTES + GS_BYTES) <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) char smem[NPART * (XS_BYTES + GS_BYTES)];
+  char* const xs = smem;                       // [part][tap][ci][ROWP]
+  char* const gs = smem + NPART * XS_BYTES;    // [part][co][ROWP]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int slab = blockIdx.x;
+  const int co_blk = blockIdx.y / p.n_ci_blk, ci_blk = blockIdx.y % p.n_ci_blk;
+  const int dt = blockIdx.z;
+  const int co0 = co_blk * CO, ci0 = ci_blk * CI;
+  const int r0 = (int)((long long)p.rows_total * slab / p.nslab), r1 = (int)((long long)p.rows_total * (slab + 1) / p.nslab);
+  const int npanel_row = (p.Wo + KP - 1) / KP;
+  const long long npanels = (long long)(r1 - r0) * npanel_row;
+  const int xpix = (KP - 1) * p.sW + KHW;  // halo pixels per staged input row
+
+  const TIO* __restrict__ ap = reinterpret_cast<const TIO*>(p.a);
+  const TIO* __restrict__ gp = reinterpret_cast<const TIO*>(p.g);
+
+  f32x16 acc[NSP];
+#pragma unroll
+  for (int t = 0; t < NSP; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  Raw8<TIO> xr[NXI], gr[NGI];
+  // source of my items of panel `pi` (coordinates only; the loads follow)
+  auto load_panel = [&](long long pi) {
+    const int row = r0 + (int)(pi / npanel_row), x0 = (int)(pi % npanel_row) * KP;
+    const int yo = row % p.Ho, to = (row / p.Ho) % p.To, b = row / (p.Ho * p.To);
+    bool zt = false;
+    const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zt);
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+      const int id = it * 512 + tid;
+      const int oct = id & 7, hx = (id >> 3) % xpix, dy = (id >> 3) / xpix;
+      bool zero = zt;
+      Raw8<TIO> r{};
+      if (dy < KHW) {
+        const int ys = map_coord(yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, zero);
+        const int xsrc = map_coord(x0 * p.sW + hx - p.pw, p.Wi, p.mode_hw, zero);
+        const int c = ci0 + oct * 8;
+        if (!zero && c < p.Cin) r = ldraw8<TIO>(ap + ((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi + xsrc) * p.a_ps + c);
+      }
+      xr[it] = r;
+    }
+#pragma unroll
+    for (int it = 0; it < NGI; ++it) {
+      const int id = it * 512 + tid;
+      const int oct = id & 15, k = id >> 4;
+      Raw8<TIO> r{};
+      const int c = co0 + oct * 8;
+      if (k < KP && x0 + k < p.Wo && c < p.Cout)
+        r = ldraw8<TIO>(gp + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo + (x0 + k)) * p.g_ps + c);
+      gr[it] = r;
+    }
+  };
+  // 8 values of one pixel -> 8 channel rows of the transposed LDS copy (hi, and lo for XP)
+  auto put8 = [&](char* base, int row0, int k, const Raw8<TIO>& r, long long part_stride) {
+    float f[8];
+    unraw8<TIO>(r, f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const T h = (T)f[j];
+      *reinterpret_cast<T*>(base + (row0 + j) * ROWP + k * 2) = h;
+      if constexpr (XP) *reinterpret_cast<T*>(base + part_stride + (row0 + j) * ROWP + k * 2) = (T)(f[j] - (float)h);
+    }
+  };
+  auto store_panel = [&]() {
+#pragma unroll
+    for (int it = 0; it < NXI; ++it) {
+      const int id = it * 512 + tid;
+      const int oct = id & 7, hx = (id >> 3) % xpix, dy = (id >> 3) / xpix;
+      if (dy >= KHW) continue;
+#pragma unroll
+      for (int dx = 0; dx < KHW; ++dx) {  // halo pixel hx is tap dx of output pixel k when k * sW + dx == hx
+        const int num = hx - dx;
+        if (num < 0) continue;
+        const int k = p.sW == 1 ? num : (num >> 1);
+        if ((p.sW == 2 && (num & 1)) || k >= KP) continue;
+        put8(xs, (dy * KHW + dx) * CI + oct * 8, k, xr[it], XS_BYTES);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < NGI; ++it) {
+      const int id = it * 512 + tid;
+      const int oct = id & 15, k = id >> 4;
+      if (k < KP) put8(gs, oct * 8, k, gr[it], GS_BYTES);
+    }
+  };
+
+  const int cof = wave & 3, cif = wave >> 2;
+  const unsigned a_off = (unsigned)((cof * 32 + (lane & 31)) * ROWP + (lane >> 5) * 16);
+  const unsigned b_off = (unsigned)((cif * 32 + (lane & 31)) * ROWP + (lane >> 5) * 16);
+
+  if (npanels > 0) load_panel(0);
+  for (long long pi = 0; pi < npanels; ++pi) {
+    store_panel();
+    __syncthreads();
+    if (pi + 1 < npanels) load_panel(pi + 1);
+#pragma unroll
+    for (int s = 0; s < KP / 16; ++s) {
+      const v8 ah = *reinterpret_cast<const v8*>(gs + a_off + s * 32);
+      v8 al;
+      if constexpr (XP) al = *reinterpret_cast<const v8*>(gs + GS_BYTES + a_off + s * 32);
+#pragma unroll
+      for (int t = 0; t < NSP; ++t) {
+        const v8 bh = *reinterpret_cast<const v8*>(xs + t * (CI * ROWP) + b_off + s * 32);
+        acc[t] = Tr<T>::mfma(ah, bh, acc[t]);
+        if constexpr (XP) {
+          const v8 bl = *reinterpret_cast<const v8*>(xs + XS_BYTES + t * (CI * ROWP) + b_off + s * 32);
+          acc[t] = Tr<T>::mfma(ah, bl, acc[t]);
+          acc[t] = Tr<T>::mfma(al, bh, acc[t]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // partial tile: part[slab][tap][co][ci]; accumulator register i of a lane = output channel 8*(i/4) + 4*(lane/32) + i%4 of the
+  // fragment, input channel lane % 32
+  const int ntaps = p.kT * NSP;
+#pragma unroll
+  for (int t = 0; t < NSP; ++t) {
+    float* o = p.part + (((long long)slab * ntaps + dt * NSP + t) * p.Coutp + co0 + cof * 32) * p.Cinp + ci0 + cif * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * p.Cinp] = acc[t][i];
+  }
+}
+
+// dW[co][ci][tap] = sum over slabs (index order) of part[slab][tap][co][ci]
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int ntaps, int Coutp, int Cinp,
+                                                           int Cout, int Cin, float* __restrict__ dw) {
+  const long long n = (long long)Cout * Cin * ntaps;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int tap = (int)(i % ntaps);
+    const long long r = i / ntaps;
+    const int ci = (int)(r % Cin), co = (int)(r / Cin);
+    const float* s = part + ((long long)tap * Coutp + co) * Cinp + ci;
+    const long long slab_stride = (long long)ntaps * Coutp * Cinp;
+    float acc = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) acc += s[sl * slab_stride];
+    dw[i] = acc;
+  }
+}
+
+static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_ci) {
+  n_co = (d->Cout + 127) / 128;
+  n_ci = (d->Cin + 63) / 64;
+  const long long rows = (long long)d->B * d->To * d->Ho;
+  const long long per_slab = (long long)n_co * n_ci * d->kT;
+  long long s = (1024 + per_slab - 1) / per_slab;                     // ~4 workgroups per CU in all
+  const long long tile_bytes = (long long)d->kT * d->kH * d->kW * n_co * 128 * n_ci * 64 * 4;
+  const long long cap = (512ll << 20) / (tile_bytes > 0 ? tile_bytes : 1);  // <= 512 MB of partials
+  if (s > cap) s = cap;
+  if (s > rows) s = rows;
+  if (s < 1) s = 1;
+  nslab = (int)s;
+}
+
+template <typename T, int KHW, bool XP>
+static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
+  int nslab, n_co, n_ci;
+  wgrad_plan(d, nslab, n_co, n_ci);
+  WgradArgs p{};
+  p.a = a; p.g = gy; p.part = (float*)ws;
+  p.B = d->B; p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.a_ps = d->in_pix_stride;
+  p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.g_ps = g_ps;
+  p.kT = d->kT; p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pt = d->pad_t; p.ph = d->pad_h; p.pw = d->pad_w;
+  p.mode_t = d->pad_mode_t; p.mode_hw = d->pad_mode_hw;
+  p.nslab = nslab; p.rows_total = d->B * d->To * d->Ho; p.n_ci_blk = n_ci;
+  p.Coutp = n_co * 128; p.Cinp = n_ci * 64;
+  hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP>), dim3(nslab, n_co * n_ci, d->kT), dim3(512), 0, s, p);
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  const int ntaps = d->kT * d->kH * d->kW;
+  long long blocks = ((long long)d->Cout * d->Cin * ntaps + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp,
+                     d->Cout, d->Cin, dw);
+  return (int)hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// per-channel sums over pixels: bias gradients (x = null: sum g) and GroupNorm affine gradients
+//   d beta[c] = sum g * act'(a),  d gamma[c] = sum g * act'(a) * xh      (xh, a as in gn_bwd_*: misc_kernels.hip)
+// Two passes: per (row, split) partial sums [C][2] written in place, then summed in index order.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_grad2_f(float a) {
+  const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-a));
+  return sg * (1.0f + a * (1.0f - sg));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x, const T* __restrict__ g, long long S, int C,
+                                                        long long g_ps, int nsplit, const float* __restrict__ rs,
+                                                        const float* __restrict__ nm, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int silu, float* __restrict__ ws) {
+  const int split = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
+  const int cv = (C + 7) >> 3;
+  const int ppp = 256 / cv > 0 ? 256 / cv : 1;
+  const int myv = tid % cv, mypl = tid / cv;
+  const long long per = (S + nsplit - 1) / nsplit;
+  const long long p0 = (long long)split * per;
+  long long p1 = p0 + per;
+  if (p1 > S) p1 = S;
+  float s1[8], s2[8], trs[8], tnm[8], tga[8], tbe[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    s1[j] = s2[j] = 0.f;
+    const int c = myv * 8 + j;
+    const bool ok = x != nullptr && c < C;
+    trs[j] = ok ? rs[(long long)row * C + c] : 0.f;
+    tnm[j] = ok ? nm[(long long)row * C + c] : 0.f;
+    tga[j] = ok ? gamma[c] : 0.f;
+    tbe[j] = ok ? beta[c] : 0.f;
+  }
+  if (mypl < ppp && myv * 8 < C) {
+    for (long long px = p0 + mypl; px < p1; px += ppp) {
+      float f[8], gg[8];
+      ld8<T>(g + ((long long)row * S + px) * g_ps + myv * 8, gg);
+      if (x != nullptr) {
+        ld8<T>(x + ((long long)row * S + px) * (long long)C + myv * 8, f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = __builtin_fmaf(f[j], trs[j], tnm[j]);
+          const float a = __builtin_fmaf(xh, tga[j], tbe[j]);
+          const float ga = gg[j] * (silu ? silu_grad2_f(a) : 1.0f);
+          s1[j] += ga;
+          s2[j] += ga * xh;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s1[j] += gg[j];
+      }
+    }
+  }
+  __shared__ float sh[256][17];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    sh[tid][j] = s1[j];
+    sh[tid][8 + j] = s2[j];
+  }
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {  // channel c: its vector c/8, every pixel lane, in index order
+    float a1 = 0.f, a2 = 0.f;
+    for (int pl = 0; pl < ppp; ++pl) {
+      const int th = pl * cv + (c >> 3);
+      if (th < 256) {
+        a1 += sh[th][c & 7];
+        a2 += sh[th][8 + (c & 7)];
+      }
+    }
+    float* o = ws + (((long long)row * nsplit + split) * C + c) * 2;
+    o[0] = a1;
+    o[1] = a2;
+  }
+}
+
+__global__ __launch_bounds__(256) void chan_sums_final_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ o1,
+                                                              float* __restrict__ o2) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float a1 = 0.f, a2 = 0.f;
+  for (int i = 0; i < nparts; ++i) {
+    a1 += ws[((long long)i * C + c) * 2];
+    a2 += ws[((long long)i * C + c) * 2 + 1];
+  }
+  if (o1) o1[c] = a1;
+  if (o2) o2[c] = a2;
+}
+
+static inline int chan_sums_splits(long long S, int rows) {
+  long long n = (S + 1023) / 1024;
+  const long long cap = rows > 0 ? (1024 + rows - 1) / rows : 1024;
+  if (n > cap) n = cap;
+  return (int)(n < 1 ? 1 : n);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// adjoint of replicate / zero padding: gp [B][Tp][Hp][Wp][C] is the gradient w.r.t. the PADDED input (front pads pt, ph, pw);
+// out[b][t][y][x] = sum of gp over every padded position that the forward's coordinate map sends to (t, y, x)
+// (replicate: clamp -- border elements collect their whole pad region; zero: only the interior copy).  `add` is summed in.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pad_fold_kernel(const T* __restrict__ gp, int B, int T_, int H, int W, int C, int Tp, int Hp,
+                                                       int Wp, int pt, int ph, int pw, int mode_t, int mode_hw,
+                                                       const T* __restrict__ add, T* __restrict__ out) {
+  const int cv = C >> 3;
+  const long long nvec = (long long)B * T_ * H * W * cv;
+  for (long long v = (long long)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (long long)gridDim.x * 256) {
+    const int c0 = (int)(v % cv) * 8;
+    long long pix = v / cv;
+    const int x = (int)(pix % W);
+    pix /= W;
+    const int y = (int)(pix % H);
+    pix /= H;
+    const int t = (int)(pix % T_);
+    const int b = (int)(pix / T_);
+    // padded index range [lo, hi] that maps to coordinate c of an axis of length L
+    auto range = [](int c, int L, int pf, int Lp, int mode, int& lo, int& hi) {
+      lo = hi = c + pf;
+      if (mode) {
+        if (c == 0) lo = 0;
+        if (c == L - 1) hi = Lp - 1;
+      }
+    };
+    int t0, t1, y0, y1, x0, x1;
+    range(t, T_, pt, Tp, mode_t, t0, t1);
+    range(y, H, ph, Hp, mode_hw, y0, y1);
+    range(x, W, pw, Wp, mode_hw, x0, x1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int tp = t0; tp <= t1; ++tp)
+      for (int yp = y0; yp <= y1; ++yp)
+        for (int xp = x0; xp <= x1; ++xp) {
+          float f[8];
+          ld8<T>(gp + ((((long long)b * Tp + tp) * Hp + yp) * Wp + xp) * C + c0, f);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += f[j];
+        }
+    const long long off = ((((long long)b * T_ + t) * H + y) * W + x) * C + c0;
+    if (add) {
+      float f[8];
+      ld8<T>(add + off, f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += f[j];
+    }
+    st8<T>(out + off, acc);
+  }
+}
+
+}  // namespace cvvae
+
+using namespace cvvae;
+
+extern "C" {
+
+int64_t cvvae_conv_wgrad_workspace_bytes(const cvvae_conv_desc* d) {
+  if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kT <= 0) return CVVAE_EINVAL;
+  int nslab, n_co, n_ci;
+  wgrad_plan(d, nslab, n_co, n_ci);
+  return (int64_t)nslab * d->kT * d->kH * d->kW * n_co * 128 * n_ci * 64 * (int64_t)sizeof(float);
+}
+
+int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, void* workspace,
+                     void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!d || !a || !gy || !dw || !workspace) return CVVAE_EINVAL;
+  if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVVAE_EINVAL;
+  if (d->Cin <= 0 || d->Cin % 8 || d->in_pix_stride < d->Cin || d->in_pix_stride % 8) return CVVAE_EINVAL;
+  if (d->Cout <= 0 || d->Cout % 8 || gy_pix_stride < d->Cout || gy_pix_stride % 8) return CVVAE_EINVAL;
+  if (d->upsample2x || d->in_overlap) return CVVAE_EUNSUPPORTED;
+  if (!(d->kH == d->kW && (d->kH == 3 || d->kH == 1) && (d->kT == 3 || d->kT == 1))) return CVVAE_EUNSUPPORTED;
+  if (d->sT < 1 || d->sT > 2 || d->sH < 1 || d->sH > 2 || d->sW < 1 || d->sW > 2 || d->sH != d->sW) return CVVAE_EUNSUPPORTED;
+  const bool k3 = d->kH == 3;
+  switch (d->dtype) {
+    case CVVAE_BF16:
+      return k3 ? wgrad_launch<__bf16, 3, false>(d, a, gy, gy_pix_stride, dw, workspace, stream)
+                : wgrad_launch<__bf16, 1, false>(d, a, gy, gy_pix_stride, dw, workspace, stream);
+    case CVVAE_F16:
+      return k3 ? wgrad_launch<_Float16, 3, false>(d, a, gy, gy_pix_stride, dw, workspace, stream)
+                : wgrad_launch<_Float16, 1, false>(d, a, gy, gy_pix_stride, dw, workspace, stream);
+    case CVVAE_F32:
+    case CVVAE_F32Q:
+    case CVVAE_F32Q6:
+      return k3 ? wgrad_launch<__bf16, 3, true>(d, a, gy, gy_pix_stride, dw, workspace, stream)
+                : wgrad_launch<__bf16, 1, true>(d, a, gy, gy_pix_stride, dw, workspace, stream);
+    default:
+      return CVVAE_EINVAL;
+  }
+}
+
+int64_t cvvae_channel_sums_workspace_bytes(int32_t rows, int64_t S, int32_t C) {
+  if (rows <= 0 || S <= 0 || C <= 0) return CVVAE_EINVAL;
+  return (int64_t)rows * chan_sums_splits(S, rows) * C * 2 * (int64_t)sizeof(float);
+}
+
+// x == NULL: sum1[c] = sum over rows x S pixels of g (a bias gradient); else the GroupNorm affine gradients
+// sum1 = d beta, sum2 = d gamma with (rstd, -mean*rstd) tables [rows][C] as in cvvae_gn_bwd_input
+int cvvae_channel_sums(int32_t dtype, const void* x, const void* g, int64_t g_pix_stride, int32_t rows, int64_t S, int32_t C,
+                       const float* rstd, const float* nmean, const float* gamma, const float* beta, int32_t silu, float* sum1,
+                       float* sum2, void* workspace, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!g || !sum1 || !workspace || rows <= 0 || S <= 0 || C <= 0 || C % 8 || C > 2048 || g_pix_stride < C || g_pix_stride % 8)
+    return CVVAE_EINVAL;
+  if (x && (!rstd || !nmean || !gamma || !beta || !sum2 || g_pix_stride != C)) return CVVAE_EINVAL;
+  if ((C >> 3) > 256) return CVVAE_EUNSUPPORTED;
+  const int nsplit = chan_sums_splits(S, rows);
+  float* ws = (float*)workspace;
+  switch (dtype) {
+    case CVVAE_BF16:
+      hipLaunchKernelGGL(chan_sums_kernel<__bf16>, dim3(nsplit, rows), dim3(256), 0, stream, (const __bf16*)x, (const __bf16*)g, S, C,
+                         g_pix_stride, nsplit, rstd, nmean, gamma, beta, silu, ws);
+      break;
+    case CVVAE_F16:
+      hipLaunchKernelGGL(chan_sums_kernel<_Float16>, dim3(nsplit, rows), dim3(256), 0, stream, (const _Float16*)x, (const _Float16*)g,
+                         S, C, g_pix_stride, nsplit, rstd, nmean, gamma, beta, silu, ws);
+      break;
+    case CVVAE_F32:
+      hipLaunchKernelGGL(chan_sums_kernel<float>, dim3(nsplit, rows), dim3(256), 0, stream, (const float*)x, (const float*)g, S, C,
+                         g_pix_stride, nsplit, rstd, nmean, gamma, beta, silu, ws);
+      break;
+    default:
+      return CVVAE_EINVAL;
+  }
+  int rc = (int)hipGetLastError();
+  if (rc) return rc;
+  hipLaunchKernelGGL(chan_sums_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, rows * nsplit, C, sum1,
+                     sum2);
+  return (int)hipGetLastError();
+}
+
+int cvvae_pad_fold(int32_t dtype, const void* gp, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t pad_t_front,
+                   int32_t pad_t_back, int32_t pad_h, int32_t pad_w, int32_t pad_mode_t, int32_t pad_mode_hw, const void* add, void* out,
+                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!gp || !out || B <= 0 || T <= 0 || H <= 0 || W <= 0 || C <= 0 || C % 8) return CVVAE_EINVAL;
+  if (pad_t_front < 0 || pad_t_back < 0 || pad_h < 0 || pad_w < 0) return CVVAE_EINVAL;
+  const int Tp = T + pad_t_front + pad_t_back, Hp = H + 2 * pad_h, Wp = W + 2 * pad_w;
+  long long blocks = ((long long)B * T * H * W * (C / 8) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+#define CVVAE_FOLD(TY)                                                                                                           \
+  hipLaunchKernelGGL(pad_fold_kernel<TY>, dim3((unsigned)blocks), dim3(256), 0, stream, (const TY*)gp, B, T, H, W, C, Tp, Hp, Wp, \
+                     pad_t_front, pad_h, pad_w, pad_mode_t, pad_mode_hw, (const TY*)add, (TY*)out)
+  switch (dtype) {
+    case CVVAE_BF16: CVVAE_FOLD(__bf16); break;
+    case CVVAE_F16: CVVAE_FOLD(_Float16); break;
+    case CVVAE_F32: CVVAE_FOLD(float); break;
+    default: return CVVAE_EINVAL;
+  }
+#undef CVVAE_FOLD
+  return (int)hipGetLastError();
+}
+
+}  // extern "C"

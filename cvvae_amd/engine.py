@@ -476,7 +476,8 @@ def spatial_attention(wc: WeightCache, x: torch.Tensor, norm: str, q: str, k: st
             vp = ops.pack_weight_batched(vt, (1, 1, 1), cin_pad=npad, strides=(N, 1, 0), cout=C, cin=N)
             o = ops.conv(p.view(B * T, 1, 1, N, npad), vp)                                         # [BT,1,1,N,C]
         if tape is not None:  # what the input-gradient pass (grad.py) needs again
-            tape.append(dict(op="attn", x=x, qq=qq, kk=kk, vv=vv, p=p, names=(norm, q, k, v, proj), eps=eps, residual=residual))
+            tape.append(dict(op="attn", x=x, qq=qq, kk=kk, vv=vv, p=p, o=o, gn=gn, names=(norm, q, k, v, proj), eps=eps,
+                             residual=residual))
     return conv1x1(wc, o.view(B, T, H, W, C), proj, residual=x if residual else None, gn_out=gn_out)
 
 
@@ -513,7 +514,7 @@ def tapsn_conv_out() -> bool:
 def decoder_conv_out(wc: WeightCache, h: torch.Tensor, g, pad, mode_t, mode_hw, u8: bool = False):
     """norm_out + SiLU + conv_out of both decoders -> pixels NCDHW (or, u8: the scripts' uint8 frames [T,H,W,3], one clip)"""
     w = wc.m.get_parameter("conv_out.weight")
-    if (tapsn_conv_out() and h.dtype in (torch.float16, torch.bfloat16) and 9 * w.shape[0] <= 32 and w.shape[0] == 3
+    if (tapsn_conv_out() and 9 * w.shape[0] <= 32 and w.shape[0] == 3
             and pad[1] == (1, 1) and pad[2] == (1, 1) and h.shape[-1] % 32 == 0):
         pw, bias = wc.conv_tapsn("conv_out", time_folds=mode_t == REP and fold_time())
         v = ops.conv(h, pw, pad=(pad[0], (0, 0), (0, 0)), pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=L.PRO_GN_SILU, gn=g,
@@ -552,7 +553,7 @@ def _encoder_input(x: torch.Tensor, cfg: dict, dtype: torch.dtype):
 # --------------------------------------------------------------------------------------------------------
 # vae3d_sd3 family
 # --------------------------------------------------------------------------------------------------------
-def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want_stats: bool = True):
+def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want_stats: bool = True, tape: Optional[list] = None):
     """ResnetBlock3D.forward, vae_blocks3d_sd3.py:517-569: GN(eps 1e-6)+SiLU fused into conv1 (replicate pad, causal
     T(2,0) or (1,1)) and into conv2 (per-frame 3x3, zero pad); 1x1 shortcut; residual add in conv2's epilogue.
     xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
@@ -560,35 +561,46 @@ def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, wan
     h, hp = conv3(wc, x, pre + ".conv1", pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
                      prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32, act_norm=pre + ".norm1")
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
+    if tape is not None:  # what the training-side backward (grad3d.py) reads again: block input, conv1 output, their statistics
+        tape.append(dict(op="resnet3d", pre=pre, x=x, xp=xp, h=h, hp=hp, g1=g1, g2=g2, causal=causal))
     return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
 
 
-def sd3_mid(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, attention: bool):
+def sd3_mid(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, attention: bool, tape: Optional[list] = None):
     """UNetMidBlock3D.forward, vae_blocks3d_sd3.py:847-856."""
-    x, xp = sd3_resnet(wc, x, xp, pre + ".resnets.0", causal)  # (its records also give the attention's per-frame statistics)
+    x, xp = sd3_resnet(wc, x, xp, pre + ".resnets.0", causal, tape=tape)  # (its records also give the attention's per-frame statistics)
     if attention:
         a = pre + ".attentions.0"
         x, xp = spatial_attention(wc, x, a + ".group_norm", a + ".to_q", a + ".to_k", a + ".to_v", a + ".to_out.0", 1e-6, True,
-                                  gn_out=G32, xp=xp)
-    return sd3_resnet(wc, x, xp, pre + ".resnets.1", causal)
+                                  gn_out=G32, xp=xp, tape=tape)
+    return sd3_resnet(wc, x, xp, pre + ".resnets.1", causal, tape=tape)
 
 
-def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
-    """Encoder3D.forward, vae_models3d_sd3.py:162-208.  x: NCDHW (any float dtype) -> moments NCDHW."""
+def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
+    """Encoder3D.forward, vae_models3d_sd3.py:162-208.  x: NCDHW (any float dtype) -> moments NCDHW.
+    tape: a list that receives what the backward pass of the TRAINABLE encoder (grad3d.sd3_encoder_backward) reads again; the
+    launches are the inference pass's own (same bits)."""
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
-    h, hp = encoder_conv_in(wc, x, cfg, dtype, PC if causal else P1, REP, REP)
+    pad = PC if causal else P1
+    h, hp = encoder_conv_in(wc, x, cfg, dtype, pad, REP, REP)
+    if tape is not None:
+        tape.append(dict(op="conv_in", x=x, pad=pad, ndhwc_in=bool(cfg.get("ndhwc_in"))))
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"]):
-            h, hp = sd3_resnet(wc, h, hp, f"down_blocks.{i}.resnets.{j}", causal)
+            h, hp = sd3_resnet(wc, h, hp, f"down_blocks.{i}.resnets.{j}", causal, tape=tape)
         if i != len(boc) - 1:  # Downsample3D vae_blocks3d_sd3.py:224-239; time stride on even blocks (:115)
             st = (2, 2, 2) if i % 2 == 0 else (1, 2, 2)
+            if tape is not None:
+                tape.append(dict(op="down3d", pre=f"down_blocks.{i}.downsamplers.0.conv", x=h, stride=st, pad=pad))
             h, hp = conv3(wc, h, f"down_blocks.{i}.downsamplers.0.conv", stride=st,
-                             pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP, gn_out=G32)
-    h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"])
+                             pad=pad, pad_mode_t=REP, pad_mode_hw=REP, gn_out=G32)
+    h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"], tape=tape)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
-    return conv3(wc, h, "conv_out", pad=PC if causal else P1, pad_mode_t=REP, pad_mode_hw=REP,
+    if tape is not None:
+        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad))
+    return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
                     prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
 
 

@@ -16,7 +16,7 @@ backward pass is autograd's input gradient of each of its ops -- no weight gradi
 Gradients are carried in the module's dtype with fp32 accumulation inside every kernel (what autocast training does).
 The decoder's own parameters must be frozen; weight gradients (training the codec itself) are not built.
 """
-from typing import List
+from typing import List, Optional
 
 import torch
 
@@ -60,8 +60,18 @@ def resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict) -> torch.Tensor:
     return ops.gn_bwd_input(x, g_a1, _unit_tabs(wc, x, e["xp"], 1e-6), *wc.norm(pre + ".norm1"), silu=True, add=skip)
 
 
-def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict) -> torch.Tensor:
-    """engine.spatial_attention: out = x + proj(softmax(q k^T / sqrt(C)) v), q,k,v = linear(GroupNorm(x)) per frame.  g = dL/dout."""
+def _linear_grads(wc: WeightCache, grads: dict, pre: str, a: torch.Tensor, g: torch.Tensor):
+    """parameter gradients of y = linear(a) (nn.Linear / 1x1 conv `pre`) given g = dL/dy: dW = g^T a on the wgrad kernel, db = sum g"""
+    w = wc.m.get_parameter(pre + ".weight")
+    a5, g5 = a.reshape(a.shape[0], 1, 1, -1, a.shape[-1]), g.reshape(g.shape[0], 1, 1, -1, g.shape[-1])
+    grads[pre + ".weight"] = ops.conv_wgrad(a5.contiguous(), g5.contiguous(), K1, cin=w.shape[1], cout=w.shape[0]).reshape(w.shape)
+    if wc.has(pre + ".bias"):
+        grads[pre + ".bias"] = ops.bias_grad(g5.contiguous(), cout=w.shape[0])
+
+
+def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Optional[dict] = None) -> torch.Tensor:
+    """engine.spatial_attention: out = x + proj(softmax(q k^T / sqrt(C)) v), q,k,v = linear(GroupNorm(x)) per frame.  g = dL/dout.
+    grads: a dict that receives the block's PARAMETER gradients (training the network itself, grad3d.py); None = frozen module."""
     x, qq, kk, vv, p = e["x"], e["qq"], e["kk"], e["vv"], e["p"]
     norm, q, k, v, proj = e["names"]
     B, T, H, W, C = x.shape
@@ -89,6 +99,14 @@ def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict) -> torch.Tenso
     g_n = _dgrad1x1(wc, g_k, k, residual=g_n)
     g_n = _dgrad1x1(wc, g_v, v, residual=g_n)
     tabs = _unit_tabs(wc, x, None, e["eps"], per_frame=True)
+    if grads is not None:
+        n = ops.gn_silu_apply(x, e["gn"], silu=False, per_frame=True).view(BT, 1, 1, N, C)   # what to_q / to_k / to_v consumed
+        _linear_grads(wc, grads, proj, e["o"].view(BT, 1, 1, N, C), g.view(BT, 1, 1, N, C))
+        _linear_grads(wc, grads, q, n, g_q)
+        _linear_grads(wc, grads, k, n, g_k)
+        _linear_grads(wc, grads, v, n, g_v)
+        dg, db = ops.gn_bwd_params(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, per_frame=True)
+        grads[norm + ".weight"], grads[norm + ".bias"] = dg, db
     return ops.gn_bwd_input(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, add=g if e["residual"] else None,
                             per_frame=True)
 

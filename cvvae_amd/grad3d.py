@@ -1,0 +1,172 @@
+"""Backward pass of the TRAINABLE 3-D encoder on the MI355X kernels (second half).
+
+The reference's training step runs the 3-D VAE itself under autograd -- `z, xrec, reg = self(x)`, then the latent-compatibility loss
+through the frozen 2-D decoder (`xrec_2d = self.constraint_decoder(z)`; /root/reference/lvdm/models/autoencoder.py:1057-1090) -- so
+every layer of `Encoder3D` (/root/reference/models/vae_models3d_sd3.py:162-208) owes autograd its input gradient AND its parameter
+gradients.  `grad.py` is the frozen half (input gradients only); this file is the trainable half for the vae3d_sd3 encoder:
+
+  conv 3x3x3, replicate padding (CausalConv3d T(2,0) / Conv3d T(1,1); vae_blocks3d_sd3.py:16-104)
+      input gradient   the FULL correlation of gy with the tap-flipped, transposed weights (the forward MFMA kernel, zero pad 2 on
+                       every side = the gradient w.r.t. the PADDED input), then `cvvae_pad_fold`: the adjoint of the replicate
+                       coordinate map (border elements collect their pad region, e.g. frame 0 its two causal copies)
+      strided          Downsample3D (stride (2,2,2) / (1,2,2)): gy is zero-stuffed onto the stride-1 grid first (4-8x wasted MFMAs on
+                       three small layers; a first version)
+      weight gradient  `cvvae_conv_wgrad` over the operand the forward multiplied (GroupNorm + SiLU re-applied by
+                       `cvvae_gn_silu_apply`; padding by the kernel's own coordinate map), bias gradient `cvvae_channel_sums`
+  conv 1x3x3 zero padding, 1x1 shortcut, nn.Linear   as in grad.py + the same wgrad / bias kernels
+  GroupNorm (+ SiLU)  input gradient `cvvae_gn_bwd_input`, affine gradients `cvvae_channel_sums` (both from the forward's statistics)
+  attention           grad.attention_backward with its parameter gradients switched on
+
+`Encoder3DFn` makes a taped forward + this backward ONE autograd node whose inputs are the clip and the module's parameters, so
+`loss(constraint_decoder(encoder(x))).backward()` fills `encoder.<param>.grad` (modeling._Net.forward takes this path for a module in
+train() mode under grad mode).  Gradients are carried in the module's dtype with fp32 accumulation inside every kernel; parameter
+gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  Not built yet: the decoder's backward (folded
+upsample / time-shuffle adjoints), the vae3d family, spatial tiling under autograd (one window, one tile per call).
+"""
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from . import _lib as L
+from . import engine, grad, ops
+from .engine import P2D, REP, ZERO, WeightCache
+
+K333 = (3, 3, 3)
+K133 = (1, 3, 3)
+K1 = (1, 1, 1)
+FULL = ((2, 2), (2, 2), (2, 2))  # zero padding of the full correlation of a 3x3x3 kernel
+
+
+def _conv_param_grads(wc: WeightCache, grads: Dict[str, torch.Tensor], pre: str, a: torch.Tensor, g: torch.Tensor, k, **geom):
+    """dW, db of `pre` (a conv over operand a with output gradient g)"""
+    w = wc.m.get_parameter(pre + ".weight")
+    grads[pre + ".weight"] = ops.conv_wgrad(a, g, k, cin=w.shape[1], cout=w.shape[0], **geom).reshape(w.shape)
+    if wc.has(pre + ".bias"):
+        grads[pre + ".bias"] = ops.bias_grad(g, cout=w.shape[0])
+
+
+def dgrad333_replicate(wc: WeightCache, g: torch.Tensor, pre: str, pad_t: Tuple[int, int], in_shape, stride=(1, 1, 1),
+                       add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """input gradient of a 3x3x3 conv with replicate padding (T pads pad_t, H / W pads 1) and `stride`: g [B,To,Ho,Wo,Cout] ->
+    [B,T,H,W,Cin] (+ add)."""
+    B, T, H, W = in_shape
+    if tuple(stride) != (1, 1, 1):
+        # zero-stuff onto the stride-1 output grid [T+pt-2, H, W] (= padded extent - 2 per axis): positions o*s carry g
+        Tz = T + pad_t[0] + pad_t[1] - 2
+        gz = g.new_zeros((B, Tz, H, W, g.shape[-1]))
+        gz[:, ::stride[0], ::stride[1], ::stride[2]][:, :g.shape[1], :g.shape[2], :g.shape[3]] = g
+        g = gz
+    assert g.shape[1] == T + pad_t[0] + pad_t[1] - 2 and g.shape[2] == H and g.shape[3] == W, (tuple(g.shape), in_shape, pad_t)
+    pw = wc.conv_dgrad(pre, K333)
+    cp = ops.round_up(pw.cout, 8)  # (conv_in: 3 input channels -> an 8-channel gradient tensor, pad channels zero)
+    gp = ops.conv(g, pw, pad=FULL, pad_mode_t=ZERO, pad_mode_hw=ZERO, cout_pad=cp if cp != pw.cout else None)  # [B,T+pt0+pt1,H+2,W+2,Cin]
+    return ops.pad_fold(gp, pad_t, 1, REP, REP, add=add)
+
+
+def sd3_resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """ResnetBlock3D (vae_blocks3d_sd3.py:517-569): y = conv2(silu(norm2(h))) + shortcut(x), h = conv1(silu(norm1(x))); g = dL/dy."""
+    pre, x, h = e["pre"], e["x"], e["h"]
+    pad_t = (2, 0) if e["causal"] else (1, 1)
+    B, T, H, W, _ = x.shape
+    # conv2: per-frame 3x3, zero padding, over a2 = silu(norm2(h))
+    a2 = ops.gn_silu_apply(h, e["g2"])
+    _conv_param_grads(wc, grads, pre + ".conv2", a2, g, K133, pad=P2D)
+    del a2
+    g_a2 = ops.conv(g, wc.conv_dgrad(pre + ".conv2", K133), pad=P2D, pad_mode_hw=ZERO)
+    tabs2 = grad._unit_tabs(wc, h, e["hp"], 1e-6)
+    n2 = wc.norm(pre + ".norm2")
+    grads[pre + ".norm2.weight"], grads[pre + ".norm2.bias"] = ops.gn_bwd_params(h, g_a2, tabs2, *n2, silu=True)
+    g_h = ops.gn_bwd_input(h, g_a2, tabs2, *n2, silu=True)
+    del g_a2
+    # conv1: 3x3x3, replicate padding, over a1 = silu(norm1(x))
+    a1 = ops.gn_silu_apply(x, e["g1"])
+    _conv_param_grads(wc, grads, pre + ".conv1", a1, g_h, K333, pad=(pad_t, (1, 1), (1, 1)), pad_mode_t=REP, pad_mode_hw=REP)
+    del a1
+    g_a1 = dgrad333_replicate(wc, g_h, pre + ".conv1", pad_t, (B, T, H, W))
+    # skip branch
+    sc = pre + ".conv_shortcut"
+    if wc.has(sc + ".weight"):
+        grad._linear_grads(wc, grads, sc, x.view(B, 1, 1, -1, x.shape[-1]), g.view(B, 1, 1, -1, g.shape[-1]))
+        skip = grad._dgrad1x1(wc, g, sc)
+    else:
+        skip = g
+    tabs1 = grad._unit_tabs(wc, x, e["xp"], 1e-6)
+    n1 = wc.norm(pre + ".norm1")
+    grads[pre + ".norm1.weight"], grads[pre + ".norm1.bias"] = ops.gn_bwd_params(x, g_a1, tabs1, *n1, silu=True)
+    return ops.gn_bwd_input(x, g_a1, tabs1, *n1, silu=True, add=skip)
+
+
+def sd3_encoder_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False):
+    """gy = dL/d(moments) [B,2z,T',h,w] of engine.sd3_encoder(wc, x, cfg, tape) -> (dL/dx [B,3,T,H,W] or None, {parameter name:
+    fp32 gradient})."""
+    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    grads: Dict[str, torch.Tensor] = {}
+    last = tape[-1]
+    assert last["op"] == "out3d"
+    pad = last["pad"]
+    cout = wc.m.get_parameter("conv_out.weight").shape[0]
+    g = ops.ncdhw_to_ndhwc(gy.contiguous(), ops.round_up(cout, 16), dtype)                      # [B,T',h,w,Cpad], pad channels zero
+    x = last["x"]
+    a = ops.gn_silu_apply(x, last["g"])
+    _conv_param_grads(wc, grads, "conv_out", a, g, K333, pad=pad, pad_mode_t=REP, pad_mode_hw=REP)
+    del a
+    g = dgrad333_replicate(wc, g, "conv_out", pad[0], tuple(x.shape[:4]))
+    tabs = grad._unit_tabs(wc, x, last["xp"], 1e-6)
+    no = wc.norm("conv_norm_out")
+    grads["conv_norm_out.weight"], grads["conv_norm_out.bias"] = ops.gn_bwd_params(x, g, tabs, *no, silu=True)
+    g = ops.gn_bwd_input(x, g, tabs, *no, silu=True)
+    gx = None
+    for e in reversed(tape[:-1]):
+        if e["op"] == "resnet3d":
+            g = sd3_resnet_backward(wc, g, e, grads)
+        elif e["op"] == "attn":
+            g = grad.attention_backward(wc, g, e, grads)
+        elif e["op"] == "down3d":
+            xin = e["x"]
+            _conv_param_grads(wc, grads, e["pre"], xin, g, K333, stride=e["stride"], pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
+            g = dgrad333_replicate(wc, g, e["pre"], e["pad"][0], tuple(xin.shape[:4]), stride=e["stride"])
+        elif e["op"] == "conv_in":
+            xin = e["x"] if e["ndhwc_in"] else ops.ncdhw_to_ndhwc(e["x"], 16, dtype)           # [B,T,H,W,16], channels 3.. zero
+            _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
+            if need_input_grad:
+                # (conv_in's weights as a 128 -> 16-channel transposed kernel: the input channels padded 3 -> 16 in the packed form)
+                gi = dgrad333_replicate(wc, g, "conv_in", e["pad"][0], tuple(xin.shape[:4]))
+                cin = wc.m.get_parameter("conv_in.weight").shape[1]
+                gx = ops.ndhwc_to_ncdhw(gi, cin)
+        else:
+            raise AssertionError(e["op"])
+    return gx, grads
+
+
+class Encoder3DFn(torch.autograd.Function):
+    """(x, *parameters) -> Encoder3D(x): the inference launches with a tape; backward = sd3_encoder_backward (input and parameter
+    gradients, all on the HIP kernels)"""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, net, names: Tuple[str, ...], *params) -> torch.Tensor:
+        tape: List[dict] = []
+        with torch.cuda.device(x.device):
+            y = engine.sd3_encoder(net._cache(), x.detach(), dict(net._cfg), tape)
+        ctx.net, ctx.tape, ctx.names = net, tape, names
+        ctx.x_dtype, ctx.need_x = x.dtype, x.requires_grad
+        ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        net = ctx.net
+        with torch.cuda.device(gy.device):
+            gx, grads = sd3_encoder_backward(net._cache(), ctx.tape, gy, need_input_grad=ctx.need_x)
+        out = []
+        for name, (dt, req, shape) in zip(ctx.names, ctx.pmeta):
+            gq = grads.get(name)
+            out.append(gq.reshape(shape).to(dt) if (req and gq is not None) else None)
+        return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, *out)
+
+
+def run_trainable(net, x: torch.Tensor, kwargs: dict) -> torch.Tensor:
+    """modeling._Net.forward for a module in train() mode under grad mode: one autograd node over (x, parameters)"""
+    if kwargs:
+        raise NotImplementedError(f"training-mode forward takes no extra arguments (got {sorted(kwargs)})")
+    named = [(n, p) for n, p in net.named_parameters()]
+    return Encoder3DFn.apply(x, net, tuple(n for n, _ in named), *[p for _, p in named])

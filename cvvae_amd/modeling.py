@@ -88,9 +88,20 @@ class _Net(nn.Module):
         if pdev != x.device:
             raise RuntimeError(f"input on {x.device} but the network's parameters are on {pdev}")
 
-    @torch.no_grad()
+    _trainable = False  # networks with a backward pass on the kernels (grad3d.py): Encoder3D of the vae3d_sd3 family
+
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         self._check_input(x)
+        if (self._trainable and self.training and torch.is_grad_enabled()
+                and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # training the codec itself (lvdm/models/autoencoder.py:1057-1090 runs the 3-D networks under autograd): the same
+            # launches with a tape, one autograd node over (x, parameters).  eval() mode / no_grad: the inference pass below
+            from . import grad3d
+            return grad3d.run_trainable(self, x, kwargs)
+        with torch.no_grad():
+            return self._forward_inference(x, **kwargs)
+
+    def _forward_inference(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         # every launch of the pass goes to x's device and its current stream, whatever the caller's current device is
         with torch.cuda.device(x.device):
             if self._graphs is not None and not torch.cuda.is_current_stream_capturing():
@@ -157,6 +168,7 @@ def _sd3_mid(c: int, attention: bool) -> nn.Module:
 
 class Encoder3D(_Net):
     _program = staticmethod(engine.sd3_encoder)
+    _trainable = True  # train() mode under grad mode: the taped pass + grad3d.sd3_encoder_backward as one autograd node
 
     def __init__(self, in_channels=3, out_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
                  double_z=True, mid_block_add_attention=True, causal=True, **_):

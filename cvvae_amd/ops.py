@@ -182,7 +182,7 @@ def pack_weight_tapsn(w: torch.Tensor, time_folds: bool = False) -> PackedConv:
     w[co, :, dt, dy, dx]: the nine spatial taps in the GEMM's N axis (include/cvvae.h cvvae_conv_out_gather).  No bias: the gather
     pass adds it."""
     co, ci = w.shape[0], w.shape[1]
-    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and 9 * co <= 32 and w.dtype in (torch.float16, torch.bfloat16)
+    assert w.dim() == 5 and tuple(w.shape[2:]) == (3, 3, 3) and 9 * co <= 32
     wv = torch.zeros((32, ci, 3, 1, 1), dtype=w.dtype, device=w.device)                 # (columns 9*co .. 31: zero weights)
     wv[:9 * co] = w.detach().permute(3, 4, 0, 1, 2).reshape(9 * co, ci, 3, 1, 1)          # [(dy, dx, co), ci, dt, 1, 1]
     pw = pack_weight_tfolds(wv, None) if time_folds else pack_weight(wv.reshape(32, ci, 3), None, (3, 1, 1))
@@ -549,6 +549,98 @@ def gn_bwd_input(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Tensor, to
     L.check(lib.cvvae_gn_bwd_input(_dt(x.dtype), x.data_ptr(), gy.data_ptr(), add.data_ptr() if add is not None else None, rows, S, C,
                                    groups, rs.data_ptr(), nm.data_ptr(), gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0,
                                    out.data_ptr(), ws.data_ptr(), _stream(x)), "cvvae_gn_bwd_input")
+    return out
+
+
+def conv_wgrad(a: torch.Tensor, gy: torch.Tensor, k: Tuple[int, int, int], *, stride=(1, 1, 1),
+               pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO, cin: Optional[int] = None,
+               cout: Optional[int] = None) -> torch.Tensor:
+    """Weight gradient of conv(a, W, stride, pad, modes) given gy = dL/d(output) (cvvae_conv_wgrad).  a: [B,Ti,Hi,Wi,Cs] -- the
+    operand the forward multiplied (AFTER its GroupNorm + SiLU, before padding); gy: [B,To,Ho,Wo,Cg].  cin / cout: the weight's real
+    channel counts (default: the tensors' last dims).  Returns fp32 [cout, cin, kT, kH, kW] (nn.Conv3d's layout)."""
+    lib = L.load()
+    _need_gpu(a)
+    assert a.dim() == 5 and gy.dim() == 5 and a.is_contiguous() and gy.is_contiguous() and a.dtype == gy.dtype
+    B, Ti, Hi, Wi, Cs = a.shape
+    _, To, Ho, Wo, Cg = gy.shape
+    kT, kH, kW = k
+    assert gy.shape[0] == B
+    assert To == (Ti + pad[0][0] + pad[0][1] - kT) // stride[0] + 1 and Ho == (Hi + pad[1][0] + pad[1][1] - kH) // stride[1] + 1 and \
+        Wo == (Wi + pad[2][0] + pad[2][1] - kW) // stride[2] + 1, "gy does not have the forward conv's output shape"
+    cin = Cs if cin is None else cin
+    cout = Cg if cout is None else cout
+    d = L.ConvDesc()
+    d.dtype = _dt(a.dtype)
+    d.B, d.Ti, d.Hi, d.Wi = B, Ti, Hi, Wi
+    d.Cin = round_up(cin, 8)
+    assert d.Cin <= Cs
+    d.in_pix_stride = Cs
+    d.kT, d.kH, d.kW = kT, kH, kW
+    d.sT, d.sH, d.sW = stride
+    d.pad_t, d.pad_h, d.pad_w = pad[0][0], pad[1][0], pad[2][0]
+    d.pad_mode_t, d.pad_mode_hw = pad_mode_t, pad_mode_hw
+    d.To, d.Ho, d.Wo = To, Ho, Wo
+    d.Cout = round_up(cout, 8)
+    assert d.Cout <= Cg
+    nb = int(lib.cvvae_conv_wgrad_workspace_bytes(d))
+    if nb <= 0:
+        L.check(nb, "cvvae_conv_wgrad_workspace_bytes")
+    ws = torch.empty(nb, dtype=torch.uint8, device=a.device)
+    dw = torch.empty((d.Cout, d.Cin, kT * kH * kW), dtype=torch.float32, device=a.device)
+    L.check(lib.cvvae_conv_wgrad(d, a.data_ptr(), gy.data_ptr(), Cg, dw.data_ptr(), ws.data_ptr(), _stream(a)), "cvvae_conv_wgrad")
+    return dw[:cout, :cin].reshape(cout, cin, kT, kH, kW)
+
+
+def bias_grad(gy: torch.Tensor, cout: Optional[int] = None) -> torch.Tensor:
+    """sum of gy [..., C] over every pixel -> fp32 [cout] (a conv's bias gradient; cvvae_channel_sums with x = NULL)"""
+    lib = L.load()
+    _need_gpu(gy)
+    assert gy.is_contiguous()
+    C = gy.shape[-1]
+    S = gy.numel() // C
+    cc = round_up(C if cout is None else cout, 8)
+    assert cc <= C
+    ws = torch.empty(max(int(lib.cvvae_channel_sums_workspace_bytes(1, S, cc)), 16), dtype=torch.uint8, device=gy.device)
+    out = torch.empty(cc, dtype=torch.float32, device=gy.device)
+    L.check(lib.cvvae_channel_sums(_dt(gy.dtype), None, gy.data_ptr(), C, 1, S, cc, None, None, None, None, 0, out.data_ptr(), None,
+                                   ws.data_ptr(), _stream(gy)), "cvvae_channel_sums")
+    return out[:C if cout is None else cout]
+
+
+def gn_bwd_params(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Tensor, torch.Tensor], gamma: torch.Tensor,
+                  beta: torch.Tensor, silu: bool, per_frame: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
+    """(d gamma, d beta) fp32 [C] of act(GroupNorm(x)) given gy = dL/d(act(...)): the affine half of
+    aten::native_group_norm_backward (cvvae_channel_sums); arguments as gn_bwd_input."""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape and gy.dtype == x.dtype
+    B, T, H, W, C = x.shape
+    rows, S = (B * T, H * W) if per_frame else (B, T * H * W)
+    rs, nm = tabs
+    assert rs.dtype == torch.float32 and tuple(rs.shape) == (rows, C) and rs.is_contiguous() and nm.is_contiguous()
+    ws = torch.empty(max(int(lib.cvvae_channel_sums_workspace_bytes(rows, S, C)), 16), dtype=torch.uint8, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    L.check(lib.cvvae_channel_sums(_dt(x.dtype), x.data_ptr(), gy.data_ptr(), C, rows, S, C, rs.data_ptr(), nm.data_ptr(),
+                                   gamma.data_ptr(), beta.data_ptr(), 1 if silu else 0, db.data_ptr(), dg.data_ptr(), ws.data_ptr(),
+                                   _stream(x)), "cvvae_channel_sums")
+    return dg, db
+
+
+def pad_fold(gp: torch.Tensor, pad_t: Tuple[int, int], pad_hw: int, pad_mode_t: int, pad_mode_hw: int,
+             add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """gp: gradient w.r.t. the PADDED input [B, T+pt0+pt1, H+2p, W+2p, C] -> gradient w.r.t. the input [B,T,H,W,C]: the adjoint of
+    the forward's out-of-range coordinate map (replicate: borders collect their pad region; zero: the interior) (+ add)."""
+    lib = L.load()
+    _need_gpu(gp)
+    assert gp.dim() == 5 and gp.is_contiguous()
+    B, Tp, Hp, Wp, C = gp.shape
+    T, H, W = Tp - pad_t[0] - pad_t[1], Hp - 2 * pad_hw, Wp - 2 * pad_hw
+    out = torch.empty((B, T, H, W, C), dtype=gp.dtype, device=gp.device)
+    if add is not None:
+        assert add.shape == out.shape and add.dtype == gp.dtype and add.is_contiguous()
+    L.check(lib.cvvae_pad_fold(_dt(gp.dtype), gp.data_ptr(), B, T, H, W, C, pad_t[0], pad_t[1], pad_hw, pad_hw, pad_mode_t, pad_mode_hw,
+                               add.data_ptr() if add is not None else None, out.data_ptr(), _stream(gp)), "cvvae_pad_fold")
     return out
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 9
+#define CVVAE_ABI_VERSION 10
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
@@ -306,6 +306,51 @@ int cvvae_softmax_bwd_rows(int32_t dtype, const void* p, int64_t ld_p, const flo
  * [N][2H][2W][C], out [N][H][W][C], C % 8 == 0.
  */
 int cvvae_upsample2x_sum(int32_t dtype, const void* g, int64_t N, int32_t H, int32_t W, int32_t C, void* out, void* stream);
+
+/*
+ * Training the 3-D networks themselves (second half): the reference's training step runs `z, xrec = self(x)`
+ * through the TRAINABLE Encoder3D / Decoder3D (lvdm/models/autoencoder.py:1057-1090; models/vae_models3d_sd3.py:162-208), so
+ * autograd also needs every layer's PARAMETER gradients.  Input gradients run on cvvae_conv_fwd* with transposed, tap-flipped
+ * weights as above (replicate padding: the full correlation over the padded extent, then cvvae_pad_fold); the entries below are
+ * the parameter-gradient pieces (cvvae_amd/grad3d.py).
+ *
+ * cvvae_conv_wgrad: dW[co][ci][tap] = sum over output pixels of gy[pixel][co] * a[source(pixel, tap)][ci] -- aten::convolution_backward's
+ * weight gradient.  `d` describes the FORWARD convolution (B, Ti, Hi, Wi, Cin, in_pix_stride of `a`; kT/kH/kW in {1,3} with
+ * kH == kW; strides 1 or 2 with sH == sW; FRONT pads and pad modes; To, Ho, Wo, Cout); prologue / output fields are ignored.
+ * a: the operand the forward multiplied, NDHWC -- i.e. AFTER its GroupNorm + SiLU (cvvae_gn_silu_apply) but BEFORE padding: out-of-range
+ * taps are mapped exactly as the forward maps them (replicate = clamp, zero = no contribution).  gy: NDHWC [B][To][Ho][Wo] with
+ * gy_pix_stride elements per pixel.  dw: fp32 [Cout][Cin][kT*kH*kW] (PyTorch's layout; Cin = d->Cin, i.e. including any channel
+ * padding of `a`).  dtype CVVAE_F16 / CVVAE_BF16: 16-bit operands on the matching MFMA; CVVAE_F32 (and the fast codes): float
+ * tensors, every product as three bf16 MFMAs (hi/lo split of both operands, ~2^-16 relative).  Accumulation is fp32 and
+ * deterministic (per-slab partial tiles summed in index order).  workspace: cvvae_conv_wgrad_workspace_bytes(d) bytes.
+ * Cin % 8 == 0, Cout % 8 == 0.
+ */
+int64_t cvvae_conv_wgrad_workspace_bytes(const cvvae_conv_desc* d);
+int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, void* workspace,
+                     void* stream);
+
+/*
+ * Per-channel sums over rows x S pixels (aten::convolution_backward's bias gradient; aten::native_group_norm_backward's affine
+ * gradients):  x == NULL:  sum1[c] = sum g[r][s][c]  (g with g_pix_stride elements per pixel);
+ * x != NULL:  d beta = sum1[c] = sum g * act'(a),  d gamma = sum2[c] = sum g * act'(a) * xh  with xh = x * rstd[r][c] + nmean[r][c],
+ * a = xh * gamma[c] + beta[c], act = SiLU when silu != 0 (tables as in cvvae_gn_bwd_input; x and g are [rows][S][C] of `dtype`).
+ * Deterministic (two passes).  workspace: cvvae_channel_sums_workspace_bytes(rows, S, C) bytes.  C % 8 == 0, C <= 2048.
+ */
+int64_t cvvae_channel_sums_workspace_bytes(int32_t rows, int64_t S, int32_t C);
+int cvvae_channel_sums(int32_t dtype, const void* x, const void* g, int64_t g_pix_stride, int32_t rows, int64_t S, int32_t C,
+                       const float* rstd, const float* nmean, const float* gamma, const float* beta, int32_t silu, float* sum1,
+                       float* sum2, void* workspace, void* stream);
+
+/*
+ * Adjoint of the padding in front of a convolution (aten::replication_pad3d_backward / constant_pad_nd's slice): gp is the gradient
+ * w.r.t. the PADDED input, NDHWC [B][T + pad_t_front + pad_t_back][H + 2 pad_h][W + 2 pad_w][C]; out [B][T][H][W][C] receives, per
+ * element, the sum of gp over every padded position the forward's coordinate map sends there (replicate: border elements collect
+ * their pad region -- CausalConv3d's two leading copies of frame 0, models/vae_blocks3d_sd3.py:81-104; zero: the interior copy
+ * only).  `add` (optional, same shape as out) is summed into the result.  C % 8 == 0.
+ */
+int cvvae_pad_fold(int32_t dtype, const void* gp, int32_t B, int32_t T, int32_t H, int32_t W, int32_t C, int32_t pad_t_front,
+                   int32_t pad_t_back, int32_t pad_h, int32_t pad_w, int32_t pad_mode_t, int32_t pad_mode_hw, const void* add, void* out,
+                   void* stream);
 
 /* LayerNorm over C for every pixel (vae3d temporal attention, models/vae_models.py:571,575). in/out [P][C]. */
 int cvvae_layernorm(int32_t dtype, const void* x, int64_t P, int32_t C, float eps, const float* gamma, const float* beta,

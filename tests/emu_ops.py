@@ -346,6 +346,50 @@ def gn_bwd_input(x, gy, tabs, gamma, beta, silu, add=None, per_frame=False, grou
     return gx.to(x.dtype)
 
 
+def conv_wgrad(a, gy, k, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO, cin=None,
+               cout=None):
+    """dW of conv(a, W) given gy (cvvae_conv_wgrad): autograd of the plain convolution over the padded operand"""
+    cin = a.shape[-1] if cin is None else cin
+    cout = gy.shape[-1] if cout is None else cout
+    f = _pad3(a.float()[..., :cin].permute(0, 4, 1, 2, 3), pad, pad_mode_t, pad_mode_hw)
+    w = torch.zeros(cout, cin, *k, requires_grad=True)
+    with torch.enable_grad():
+        y = F.conv3d(f, w, None, stride=stride)
+        assert tuple(y.shape[2:]) == tuple(gy.shape[1:4]), (tuple(y.shape), tuple(gy.shape))
+        (y * gy.float()[..., :cout].permute(0, 4, 1, 2, 3)).sum().backward()
+    return w.grad.detach()
+
+
+def bias_grad(gy, cout=None):
+    C = gy.shape[-1]
+    return gy.float().reshape(-1, C).sum(0)[:C if cout is None else cout]
+
+
+def gn_bwd_params(x, gy, tabs, gamma, beta, silu, per_frame=False):
+    B, T, H, W, C = x.shape
+    rows, S = (B * T, H * W) if per_frame else (B, T * H * W)
+    rs, nm = tabs
+    xh = x.float().reshape(rows, S, C) * rs[:, None, :] + nm[:, None, :]
+    a = xh * gamma + beta
+    d = torch.sigmoid(a) * (1 + a * (1 - torch.sigmoid(a))) if silu else torch.ones_like(a)
+    ga = gy.float().reshape(rows, S, C) * d
+    return (ga * xh).sum((0, 1)), ga.sum((0, 1))
+
+
+def pad_fold(gp, pad_t, pad_hw, pad_mode_t, pad_mode_hw, add=None):
+    """adjoint of _pad3 (cvvae_pad_fold): autograd of the padding itself"""
+    B, Tp, Hp, Wp, C = gp.shape
+    T, H, W = Tp - pad_t[0] - pad_t[1], Hp - 2 * pad_hw, Wp - 2 * pad_hw
+    x = torch.zeros(B, C, T, H, W, requires_grad=True)
+    with torch.enable_grad():
+        y = _pad3(x, (pad_t, (pad_hw, pad_hw), (pad_hw, pad_hw)), pad_mode_t, pad_mode_hw)
+        (y * gp.float().permute(0, 4, 1, 2, 3)).sum().backward()
+    out = x.grad.detach().permute(0, 2, 3, 4, 1)
+    if add is not None:
+        out = out + add.float()
+    return out.contiguous().to(gp.dtype)
+
+
 def softmax_bwd_rows(p, gp, n_valid, alpha, ld_o=None):
     rows, ld_p = p.shape
     out = torch.zeros(rows, ld_p if ld_o is None else ld_o, dtype=p.dtype)
@@ -361,7 +405,8 @@ def upsample2x_sum(g):
 
 _NAMES = ["ncdhw_to_rowpack", "ndhwc_to_rowpack", "pack_weight_rowpack", "pack_weight_tapsn", "conv_out_gather", "pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
           "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "attention_d512", "temporal_attention", "ncdhw_to_ndhwc",
-          "ndhwc_to_ncdhw", "blend_", "resize_frames_u8", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum"]
+          "ndhwc_to_ncdhw", "blend_", "resize_frames_u8", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum",
+          "conv_wgrad", "bias_grad", "gn_bwd_params", "pad_fold"]
 
 
 @contextlib.contextmanager

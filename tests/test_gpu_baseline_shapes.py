@@ -91,3 +91,41 @@ def test_baseline_shape_golden(name, dtype, mode, golden_dir):
         assert r["latent_mean_abs"] <= 1.0e-3  # north_star's bound, met in the mean by the fp16 path
     if dtype == torch.float32:
         assert r["latent_max_abs"] <= 1.0e-3   # ... and as a maximum by both fp32 modes
+
+
+@pytest.mark.parametrize("dtype,mode", MODES, ids=["float16", "bfloat16", "float32", "float32-fast"])
+def test_cfg5_batch_slice_encode_golden(dtype, mode, golden_dir):
+    """BASELINE cfg 5 (batch-8 T=33 512x512 encode-only) at full size: a B = 2 slice of the batch -- both 17-frame windows of both
+    clips -- against the reference's own modules (oracle/make_golden.py enc), through the `encode()` API (moments) AND through the
+    latent pre-compute entry point bench.py times (`encode_latents`, posterior mode).  Bands as for cfg 3 (same frame size; the
+    maximum runs over 2.3x more latent values: sqrt(2 ln N) growth 1.03)."""
+    name = "cfg5slice_sd3_b2_t33_512_enc"
+    if not os.path.isfile(os.path.join(golden_dir, name + ".npz")):
+        pytest.skip(f"fixture {name}.npz not generated")
+    from oracle.golden_cases import ENC_CASES
+    family, over, shape, wseed, xseed = ENC_CASES[name]
+    m = _model(family, over, dtype, wseed)
+    if mode is not None:
+        m.fp32_mode = mode
+    r = P.measure_encode(m, name, golden_dir)
+    r2 = P.measure_encode(m, name, golden_dir, latents=lambda x: m.encode_latents(x, sample=False))
+    if mode is not None:
+        t = TOL_F32[mode]
+    else:
+        e = P.reference_self_noise("cfg3_sd3_t17_512", TAG[dtype], golden_dir)
+        if e is None or "shape" not in e:  # (fp16 at 512x512 has no CPU entry: the T=9 probe grown to this size)
+            e = dict(P.REFERENCE_SELF_NOISE[TAG[dtype]])
+            e["latent_max"] *= 1.35
+        t = dict(latent_max=K_MAX * 1.03 * e["latent_max"], latent_mean=K_MEAN * e["latent_mean"])
+    tag = TAG[dtype] + ("q" if mode == "fast" else "")
+    line = (f"{name:28s} {tag:5s} latent max|d| {r['latent_max_abs']:.3e} mean|d| {r['latent_mean_abs']:.3e} per item "
+            f"{['%.2e' % v for v in r['latent_max_abs_per_batch_item']]} (encode_latents: {r2['latent_max_abs']:.3e})   "
+            f"[band: max {t['latent_max']:.3e} mean {t['latent_mean']:.3e}]")
+    print("\n" + line)
+    _log(line)
+    for rr in (r, r2):
+        assert rr["latent_max_abs"] <= t["latent_max"], line
+        assert rr["latent_mean_abs"] <= t["latent_mean"], line
+    assert r2["latent_max_abs"] == r["latent_max_abs"]  # the pre-compute entry point returns the same posterior mean
+    if dtype == torch.float32:
+        assert r["latent_max_abs"] <= 1.0e-3

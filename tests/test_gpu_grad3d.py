@@ -1,0 +1,205 @@
+"""Training the 3-D encoder on the kernels (cvvae_amd/grad3d.py; /root/reference/lvdm/models/autoencoder.py:1057-1090 runs
+`z, xrec = self(x)` under autograd): the weight-gradient kernel, the bias / GroupNorm-affine reductions and the padding adjoint
+against torch autograd of the same op, then a whole (small) sd3 encoder -- conv_in, a down block of every kind (2x2x2 and 1x2x2
+Downsample3D), the mid block with its attention, norm_out + conv_out -- against autograd over the ORACLE's ops (plain PyTorch fp32 on
+the CPU, same dtype-rounded weights and inputs), and the training step's chain loss(constraint_decoder(encoder(x))).backward().
+Errors are relative L2 norms; every printed value is appended to gpurun_out/grad3d_parity.txt (kept as profiles/r4_grad3d_parity.log)."""
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import cvvae_oracle as O
+from oracle.seeded import seeded_input, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DT = [torch.float32, torch.float16, torch.bfloat16]
+# one op: the operands are exact in the storage dtype, the products accumulate in fp32: only the summation order differs
+# (fp32 models: three bf16 MFMAs per product, ~2^-16 relative)
+WGRAD_TOL = {torch.float32: 5e-5, torch.float16: 2e-5, torch.bfloat16: 2e-5}
+NET_IN_TOL = {torch.float32: 2e-3, torch.float16: 2e-2, torch.bfloat16: 1e-1}     # input gradient through 11 blocks
+NET_W_TOL = {torch.float32: 3e-3, torch.float16: 3e-2, torch.bfloat16: 1.5e-1}    # worst parameter tensor
+REP, ZERO = 1, 0
+
+
+def rel(a, b, floor=0.0):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(floor if floor else 1e-30))
+
+
+def _log(line):
+    print("\n" + line)
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "grad3d_parity.txt"), "a") as f:
+            f.write(line + "\n")
+
+
+def _pad3(f, pad, mode_t, mode_hw):
+    (tf, tb), (hf, hb), (wf, wb) = pad
+    if hf or hb or wf or wb:
+        f = F.pad(f, (wf, wb, hf, hb, 0, 0), mode="replicate") if mode_hw == REP else F.pad(f, (wf, wb, hf, hb))
+    if tf or tb:
+        f = F.pad(f, (0, 0, 0, 0, tf, tb), mode="replicate") if mode_t == REP else F.pad(f, (0, 0, 0, 0, tf, tb))
+    return f
+
+
+CASES = [
+    # name, Cin (real), Cs (stored), Cout (real), Cg (stored), k, stride, pad, mode_t, mode_hw, (B, T, H, W)
+    ("causal333_128", 128, 128, 128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 12, 70)),
+    ("sym333_256to128", 256, 256, 128, 128, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (2, 3, 9, 33)),
+    ("zero333_128to256", 128, 128, 256, 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), ZERO, ZERO, (1, 2, 8, 64)),
+    ("down222", 128, 128, 128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 16, 40)),
+    ("down122", 256, 256, 256, 256, (3, 3, 3), (1, 2, 2), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 3, 10, 24)),
+    ("frame133_zero", 128, 128, 256, 256, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, (2, 3, 20, 36)),
+    ("conv_in_3of16", 3, 16, 128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 24, 40)),
+    ("conv_out_32", 512, 512, 32, 32, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 3, 8, 12)),
+    ("linear_1x1", 512, 512, 512, 512, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), ZERO, ZERO, (3, 1, 1, 150)),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_conv_wgrad(case, dtype):
+    """cvvae_conv_wgrad vs autograd's weight gradient of F.conv3d over the padded operand (every padding flavour, both strides,
+    channel padding on either side, row lengths that are not a multiple of the 64-pixel K panel); bit-reproducible."""
+    from cvvae_amd import ops
+    name, cin, cs, cout, cg, k, stride, pad, mt, mhw, (B, T, H, W) = case
+    torch.manual_seed(len(name))
+    a = torch.zeros(B, T, H, W, cs)
+    a[..., :cin] = torch.randn(B, T, H, W, cin)
+    a = a.to(dtype)
+    f = _pad3(a.float()[..., :cin].permute(0, 4, 1, 2, 3), pad, mt, mhw)
+    w = torch.zeros(cout, cin, *k, requires_grad=True)
+    y = F.conv3d(f, w, None, stride=stride)
+    gy = torch.zeros(B, *y.shape[2:], cg)
+    gy[..., :cout] = torch.randn(B, *y.shape[2:], cout)
+    gy = gy.to(dtype)
+    (y * gy.float()[..., :cout].permute(0, 4, 1, 2, 3)).sum().backward()
+    got = ops.conv_wgrad(a.cuda(), gy.cuda(), k, stride=stride, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, cin=cin, cout=cout)
+    e = rel(got, w.grad)
+    _log(f"[wgrad {name} {str(dtype)[6:]}] dW {tuple(got.shape)} rel {e:.2e}")
+    assert got.shape == w.shape and got.dtype == torch.float32
+    assert e <= WGRAD_TOL[dtype]
+    again = ops.conv_wgrad(a.cuda(), gy.cuda(), k, stride=stride, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, cin=cin, cout=cout)
+    assert torch.equal(got, again), "not deterministic"
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_bias_and_groupnorm_affine_gradients(dtype):
+    from cvvae_amd import ops
+    torch.manual_seed(3)
+    for (B, T, H, W, C, per_frame, silu) in [(2, 3, 40, 52, 128, False, True), (1, 5, 9, 7, 512, True, False), (2, 1, 33, 17, 256, False, True)]:
+        x = (torch.randn(B, T, H, W, C) * 1.5 + 1.0).to(dtype)
+        gy = torch.randn(B, T, H, W, C).to(dtype)
+        gamma = (torch.randn(C) * 0.5 + 1.0).requires_grad_(True)
+        beta = (torch.randn(C) * 0.3).requires_grad_(True)
+        xf = x.float()
+        f = xf.permute(0, 1, 4, 2, 3).reshape(B * T, C, H * W) if per_frame else xf.permute(0, 4, 1, 2, 3).reshape(B, C, -1)
+        y = F.group_norm(f, 32, gamma, beta, 1e-6)
+        y = F.silu(y) if silu else y
+        gyf = gy.float().permute(0, 1, 4, 2, 3).reshape(B * T, C, H * W) if per_frame else gy.float().permute(0, 4, 1, 2, 3).reshape(B, C, -1)
+        y.backward(gyf)
+        xd = x.cuda()
+        one, zero = torch.ones(C, device="cuda"), torch.zeros(C, device="cuda")
+        tabs = ops.gn_stats(xd, one, zero, 1e-6, per_frame=per_frame)
+        dg, db = ops.gn_bwd_params(xd, gy.cuda(), tabs, gamma.detach().cuda(), beta.detach().cuda(), silu, per_frame=per_frame)
+        bg = ops.bias_grad(gy.cuda())
+        e = (rel(dg, gamma.grad), rel(db, beta.grad), rel(bg, gy.float().reshape(-1, C).sum(0)))
+        _log(f"[affine grads {str(dtype)[6:]} C{C} {T}x{H}x{W} per_frame={per_frame}] d gamma {e[0]:.2e} d beta {e[1]:.2e} bias {e[2]:.2e}")
+        assert max(e) <= 2e-4, e  # (fp32 sums of 16-bit-exact products; GroupNorm statistics from the kernel's own pass)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("pad_t,mode", [((2, 0), REP), ((1, 1), REP), ((1, 1), ZERO)])
+def test_pad_fold_is_the_adjoint_of_the_padding(dtype, pad_t, mode):
+    from cvvae_amd import ops
+    torch.manual_seed(5)
+    B, T, H, W, C = 2, 3, 6, 7, 16
+    gp = torch.randn(B, T + pad_t[0] + pad_t[1], H + 2, W + 2, C).to(dtype)
+    add = torch.randn(B, T, H, W, C).to(dtype)
+    x = torch.zeros(B, C, T, H, W, requires_grad=True)
+    y = _pad3(x, (pad_t, (1, 1), (1, 1)), mode, mode)
+    (y * gp.float().permute(0, 4, 1, 2, 3)).sum().backward()
+    ref = x.grad.permute(0, 2, 3, 4, 1) + add.float()
+    got = ops.pad_fold(gp.cuda(), pad_t, 1, mode, mode, add=add.cuda())
+    assert rel(got, ref) <= {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
+
+
+SMALL = dict(block_out_channels=[128, 256, 512], layers_per_block=1)
+
+
+def _encoder(dtype):
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 7)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dtype).cuda()
+    ref_sd = {k: v.to(dtype).float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    return m, ref_sd
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_sd3_encoder_backward_vs_autograd_of_the_oracle(dtype):
+    """conv_in -> down block (ResnetBlock3D + 2x2x2 Downsample3D) -> down block (channel change: 1x1 shortcut; 1x2x2 Downsample3D)
+    -> block without downsampler -> mid block (ResnetBlock3D, spatial attention at 512 channels, ResnetBlock3D) -> norm_out ->
+    conv_out: input gradient and EVERY parameter gradient against autograd over the oracle's ops; and the result is reproducible."""
+    m, ref_sd = _encoder(dtype)
+    enc = m.encoder.train()
+    x = seeded_input((1, 3, 5, 32, 32), 11).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    yr = O.sd3_encoder(xr, ref_sd, dict(SMALL))
+    cot = seeded_input(tuple(yr.shape), 4).to(dtype)
+    (yr * cot.float()).sum().backward()
+    xa = x.cuda().requires_grad_(True)
+    ya = enc(xa)
+    assert ya.requires_grad
+    (ya.float() * cot.cuda().float()).sum().backward()
+    e_y, e_x = rel(ya, yr), rel(xa.grad, xr.grad)
+    names = [n for n, _ in enc.named_parameters()]
+    scale = max(float(ref_sd["encoder." + n].grad.norm()) for n in names)
+    errs = sorted(((rel(p.grad, ref_sd["encoder." + n].grad, 1e-3 * scale), n) for n, p in enc.named_parameters()), reverse=True)
+    conv_w = [e for e, n in errs if n.endswith("weight") and ("conv" in n or "to_" in n)]
+    _log(f"[sd3 encoder backward {str(dtype)[6:]}] forward rel {e_y:.2e}; dL/dx rel {e_x:.2e}; parameters: worst {errs[0][0]:.2e} "
+         f"({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}, conv/linear weights worst {max(conv_w):.2e} ({len(names)} tensors)")
+    assert e_x <= NET_IN_TOL[dtype], e_x
+    assert errs[0][0] <= NET_W_TOL[dtype], errs[:5]
+    assert all(p.grad is not None and p.grad.dtype == p.dtype for p in enc.parameters())
+    # reproducible: the same step again gives the same bits
+    g1 = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    enc.zero_grad()
+    xb = x.cuda().requires_grad_(True)
+    (enc(xb).float() * cot.cuda().float()).sum().backward()
+    assert torch.equal(xb.grad, xa.grad) and all(torch.equal(p.grad, g1[n]) for n, p in enc.named_parameters())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_training_step_chain_through_the_frozen_constraint_decoder(dtype):
+    """the reference's step (autoencoder.py:1057-1069): z from the TRAINABLE encoder, xrec_2d = frozen constraint_decoder(z), a loss
+    on xrec_2d; .backward() must fill every encoder parameter's .grad -- compared with autograd over the oracle's two networks."""
+    from cvvae_amd.constraint import DecoderWith3DWrapper
+    from oracle.golden_cases import CONSTRAINT_CFG
+    cfg = dict(CONSTRAINT_CFG, up_block_types=["UpDecoderBlock2D"] * 2, block_out_channels=[128, 256], layers_per_block=1)
+    m, ref_sd = _encoder(dtype)
+    enc = m.encoder.train()
+    dec = DecoderWith3DWrapper(**cfg)
+    dsd = seeded_state_dict({k: v.shape for k, v in dec.state_dict().items()}, 9)
+    dec.load_state_dict(dsd, strict=True)
+    dec = dec.to(dtype).cuda().eval().requires_grad_(False)
+    dref = {k: v.to(dtype).float() for k, v in dsd.items()}
+    x = seeded_input((1, 3, 5, 32, 32), 12).to(dtype)
+    zr = O.sd3_encoder(x.float(), ref_sd, dict(SMALL))[:, :16]
+    yr = O.constraint_decoder(zr, dref, cfg)
+    cot = seeded_input(tuple(yr.shape), 6).to(dtype)
+    (yr * cot.float()).sum().backward()
+    z = enc(x.cuda())[:, :16].contiguous()
+    y = dec(z)
+    (y.float() * cot.cuda().float()).sum().backward()
+    names = [n for n, _ in enc.named_parameters()]
+    scale = max(float(ref_sd["encoder." + n].grad.norm()) for n in names)
+    errs = sorted(((rel(p.grad, ref_sd["encoder." + n].grad, 1e-3 * scale), n) for n, p in enc.named_parameters()), reverse=True)
+    _log(f"[training chain {str(dtype)[6:]}] loss(constraint_decoder(encoder(x))): xrec rel {rel(y, yr):.2e}; encoder parameter "
+         f"gradients worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    assert errs[0][0] <= 2 * NET_W_TOL[dtype], errs[:5]

@@ -1,0 +1,64 @@
+"""CPU check of the HOST logic of the trainable 3-D encoder's backward pass (cvvae_amd/grad3d.py): with every kernel replaced by a
+plain-PyTorch emulation of its documented arithmetic (tests/emu_ops.py), the taped forward must reproduce the oracle's moments and
+the backward pass torch.autograd's gradients of the oracle's ops -- for the INPUT and for EVERY PARAMETER of the network.  That
+pins what is taped, which operand / padding / stride each weight-gradient launch gets, the full-correlation + pad-fold form of the
+replicate-padded input gradients, the zero-stuffed strided ones, and the autograd.Function wiring (parameter order, dtypes).
+(The kernels themselves are compared with autograd on the GPU: tests/test_gpu_grad3d.py.)"""
+import pytest
+import torch
+
+from oracle import cvvae_oracle as O
+from oracle.seeded import seeded_input, seeded_state_dict
+from tests import emu_ops
+
+SMALL = dict(block_out_channels=[128, 256, 256], layers_per_block=1)
+
+
+def _rel(a, b, floor=0.0):
+    """relative L2 error; `floor`: an absolute scale below which the reference counts as zero (the key bias of an attention block
+    has an exactly zero gradient -- softmax rows are invariant to a constant added to every score -- and autograd returns noise)"""
+    return float((a - b).norm() / b.norm().clamp_min(floor if floor else 1e-30))
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 5, 16, 24), (2, 3, 1, 8, 8)])
+def test_sd3_encoder_backward_wiring(shape):
+    import cvvae_amd
+    from cvvae_amd import engine, grad3d
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 7)
+    m.load_state_dict(sd, strict=True)
+    enc = m.encoder
+    # reference: autograd over the oracle's ops on the same weights
+    ref_sd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    x = seeded_input(shape, 11)
+    xr = x.clone().requires_grad_(True)
+    cfg = dict(block_out_channels=SMALL["block_out_channels"], layers_per_block=1)
+    yr = O.sd3_encoder(xr, ref_sd, cfg)
+    cot = seeded_input(tuple(yr.shape), 4)
+    (yr * cot).sum().backward()
+    with emu_ops.patched(whole_model=True):
+        with torch.no_grad():
+            wc = engine.WeightCache(enc)
+            tape = []
+            y = engine.sd3_encoder(wc, x, dict(enc._cfg), tape)
+            assert torch.allclose(y, yr.detach(), rtol=1e-4, atol=1e-5), float((y - yr).abs().max())
+            gx, grads = grad3d.sd3_encoder_backward(wc, tape, cot, need_input_grad=True)
+        assert _rel(gx, xr.grad) < 1e-4, _rel(gx, xr.grad)
+        names = [n for n, _ in enc.named_parameters()]
+        assert sorted(grads) == sorted(names), sorted(set(names) ^ set(grads))
+        scale = max(float(ref_sd["encoder." + n].grad.norm()) for n in names)
+        worst = max((_rel(grads[n].reshape(ref_sd["encoder." + n].shape), ref_sd["encoder." + n].grad, 1e-4 * scale), n) for n in names)
+        assert worst[0] < 2e-4, worst
+        # the autograd.Function wiring: module in train() mode, grad mode on
+        enc.train()
+        xa = x.clone().requires_grad_(True)
+        ya = enc(xa)
+        assert ya.requires_grad and torch.equal(ya.detach(), y)
+        (ya * cot).sum().backward()
+        assert _rel(xa.grad, xr.grad) < 1e-4
+        for n, p in enc.named_parameters():
+            assert p.grad is not None and p.grad.shape == p.shape, n
+            assert _rel(p.grad, ref_sd["encoder." + n].grad, 1e-4 * scale) < 2e-4, n
+        # eval() mode stays the inference pass (no graph)
+        enc.eval()
+        assert not enc(x).requires_grad
