@@ -604,8 +604,9 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list
                     prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
 
 
-def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
-    """Decoder3D.forward, vae_models3d_sd3.py:323-388.  z: NCDHW latents -> pixels NCDHW."""
+def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
+    """Decoder3D.forward, vae_models3d_sd3.py:323-388.  z: NCDHW latents -> pixels NCDHW.
+    tape: receives what grad3d.sd3_decoder_backward reads again (training the decoder; the launches are the inference pass's)."""
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
@@ -613,16 +614,22 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     zin = z.shape[1]
     cpad = ops.round_up(zin, 32 if (z.shape[2] == 1 and fold_t1()) else 16)
     h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
+    if tape is not None:
+        tape.append(dict(op="dec_in", x=h, pad=pad, zin=zin))
     h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
                      gn_out=G32)
-    h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"])
+    h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"], tape=tape)
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"] + 1):
-            h, hp = sd3_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}", causal)
+            h, hp = sd3_resnet(wc, h, hp, f"up_blocks.{i}.resnets.{j}", causal, tape=tape)
         if i != len(boc) - 1:  # Upsample3D vae_blocks3d_sd3.py:314-364; up_time on even blocks (vae_models3d_sd3.py:289)
             up_time = i % 2 == 0
+            if tape is not None:
+                tape.append(dict(op="up3d", pre=f"up_blocks.{i}.upsamplers.0.conv", x=h, pad=pad, up_time=up_time))
             h, hp = upsample_conv(wc, h, f"up_blocks.{i}.upsamplers.0.conv", pad, REP, REP, up_time)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
+    if tape is not None:
+        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad))
     return decoder_conv_out(wc, h, g, pad, REP, REP, u8=bool(cfg.get("u8_out")))
 
 

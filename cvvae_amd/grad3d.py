@@ -2,8 +2,9 @@
 
 The reference's training step runs the 3-D VAE itself under autograd -- `z, xrec, reg = self(x)`, then the latent-compatibility loss
 through the frozen 2-D decoder (`xrec_2d = self.constraint_decoder(z)`; /root/reference/lvdm/models/autoencoder.py:1057-1090) -- so
-every layer of `Encoder3D` (/root/reference/models/vae_models3d_sd3.py:162-208) owes autograd its input gradient AND its parameter
-gradients.  `grad.py` is the frozen half (input gradients only); this file is the trainable half for the vae3d_sd3 encoder:
+every layer of `Encoder3D` / `Decoder3D` (/root/reference/models/vae_models3d_sd3.py:162-208, 323-388) owes autograd its input
+gradient AND its parameter gradients.  `grad.py` is the frozen half (input gradients only); this file is the trainable half for the
+vae3d_sd3 family:
 
   conv 3x3x3, replicate padding (CausalConv3d T(2,0) / Conv3d T(1,1); vae_blocks3d_sd3.py:16-104)
       input gradient   the FULL correlation of gy with the tap-flipped, transposed weights (the forward MFMA kernel, zero pad 2 on
@@ -17,11 +18,15 @@ gradients.  `grad.py` is the frozen half (input gradients only); this file is th
   GroupNorm (+ SiLU)  input gradient `cvvae_gn_bwd_input`, affine gradients `cvvae_channel_sums` (both from the forward's statistics)
   attention           grad.attention_backward with its parameter gradients switched on
 
-`Encoder3DFn` makes a taped forward + this backward ONE autograd node whose inputs are the clip and the module's parameters, so
-`loss(constraint_decoder(encoder(x))).backward()` fills `encoder.<param>.grad` (modeling._Net.forward takes this path for a module in
-train() mode under grad mode).  Gradients are carried in the module's dtype with fp32 accumulation inside every kernel; parameter
-gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  Not built yet: the decoder's backward (folded
-upsample / time-shuffle adjoints), the vae3d family, spatial tiling under autograd (one window, one tile per call).
+  Upsample3D          (decoder) the adjoint of the time shuffle + frame drop (index plumbing), the 27-tap conv's gradients over the
+                      nearest-upsampled operand, then `cvvae_upsample2x_sum`
+
+`Net3DFn` makes a taped forward + this backward ONE autograd node whose inputs are the clip (or latent) and the module's parameters,
+so `loss(x, decoder(encoder(x)), constraint_decoder(z)).backward()` fills `<net>.<param>.grad` (modeling._Net.forward takes this path
+for a module in train() mode under grad mode).  Gradients are carried in the module's dtype with fp32 accumulation inside every
+kernel; parameter gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  Not built yet: the vae3d
+family's backward, spatial tiling / temporal windows under autograd (one window, one tile per call: the training crops of the
+reference's configs fit one).
 """
 from typing import Dict, List, Optional, Tuple
 
@@ -96,9 +101,31 @@ def sd3_resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[s
     return ops.gn_bwd_input(x, g_a1, tabs1, *n1, silu=True, add=skip)
 
 
-def sd3_encoder_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False):
-    """gy = dL/d(moments) [B,2z,T',h,w] of engine.sd3_encoder(wc, x, cfg, tape) -> (dL/dx [B,3,T,H,W] or None, {parameter name:
-    fp32 gradient})."""
+def _unshuffle_time(g: torch.Tensor) -> torch.Tensor:
+    """adjoint of Upsample3D's 'b (n c) t h w -> b c (t n) h w' + drop of frame 0 (vae_blocks3d_sd3.py:358-362): g [B,2T-1,H,W,C]
+    (stored frames 2t+n-1) -> the conv output's gradient [B,T,H,W,2C] (channel n*C+c of frame t; the dropped frame gets zeros)"""
+    B, F2, H, W, C = g.shape
+    gf = torch.cat([g.new_zeros((B, 1, H, W, C)), g], dim=1)                      # frame -1 back in place
+    return gf.view(B, (F2 + 1) // 2, 2, H, W, C).permute(0, 1, 3, 4, 2, 5).reshape(B, (F2 + 1) // 2, H, W, 2 * C).contiguous()
+
+
+def sd3_upsample_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """Upsample3D (vae_blocks3d_sd3.py:314-364): nearest x(1,2,2) -> 3x3x3 conv (replicate pad) -> time shuffle + drop.  The
+    forward ran the folded 3x2x2 phase form; the backward differentiates the op it equals: the 27-tap conv over the upsampled
+    operand (materialised here -- a first version), then the 2x2 block sum of the nearest upsample's adjoint."""
+    x, pre, pad = e["x"], e["pre"], e["pad"]
+    B, T, H, W, C = x.shape
+    gc = _unshuffle_time(g) if e["up_time"] else g
+    a_up = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)                # F.interpolate(scale=(1,2,2), mode="nearest")
+    _conv_param_grads(wc, grads, pre, a_up, gc, K333, pad=pad, pad_mode_t=REP, pad_mode_hw=REP)
+    del a_up
+    gup = dgrad333_replicate(wc, gc, pre, pad[0], (B, T, 2 * H, 2 * W))
+    return ops.upsample2x_sum(gup.view(B * T, 1, 2 * H, 2 * W, C)).view(B, T, H, W, C)
+
+
+def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False):
+    """gy = dL/d(output) (NCDHW) of engine.sd3_encoder / engine.sd3_decoder run with `tape` -> (dL/d(input) NCDHW or None,
+    {parameter name: fp32 gradient})."""
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     grads: Dict[str, torch.Tensor] = {}
     last = tape[-1]
@@ -125,28 +152,39 @@ def sd3_encoder_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, ne
             xin = e["x"]
             _conv_param_grads(wc, grads, e["pre"], xin, g, K333, stride=e["stride"], pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
             g = dgrad333_replicate(wc, g, e["pre"], e["pad"][0], tuple(xin.shape[:4]), stride=e["stride"])
-        elif e["op"] == "conv_in":
+        elif e["op"] == "up3d":
+            g = sd3_upsample_backward(wc, g, e, grads)
+        elif e["op"] == "conv_in":   # the encoder's first layer over the clip
             xin = e["x"] if e["ndhwc_in"] else ops.ncdhw_to_ndhwc(e["x"], 16, dtype)           # [B,T,H,W,16], channels 3.. zero
             _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
             if need_input_grad:
-                # (conv_in's weights as a 128 -> 16-channel transposed kernel: the input channels padded 3 -> 16 in the packed form)
+                # (conv_in's weights as a 128 -> 3-channel transposed kernel; the gradient tensor is channel-padded to 8)
                 gi = dgrad333_replicate(wc, g, "conv_in", e["pad"][0], tuple(xin.shape[:4]))
-                cin = wc.m.get_parameter("conv_in.weight").shape[1]
-                gx = ops.ndhwc_to_ncdhw(gi, cin)
+                gx = ops.ndhwc_to_ncdhw(gi, wc.m.get_parameter("conv_in.weight").shape[1])
+        elif e["op"] == "dec_in":    # the decoder's first layer over the (channel-padded NDHWC) latent
+            xin = e["x"]
+            _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
+            if need_input_grad:
+                gi = dgrad333_replicate(wc, g, "conv_in", e["pad"][0], tuple(xin.shape[:4]))
+                gx = ops.ndhwc_to_ncdhw(gi, e["zin"])
         else:
             raise AssertionError(e["op"])
     return gx, grads
 
 
-class Encoder3DFn(torch.autograd.Function):
-    """(x, *parameters) -> Encoder3D(x): the inference launches with a tape; backward = sd3_encoder_backward (input and parameter
-    gradients, all on the HIP kernels)"""
+sd3_encoder_backward = sd3_net_backward  # (the encoder's tape through the common walker)
+sd3_decoder_backward = sd3_net_backward
+
+
+class Net3DFn(torch.autograd.Function):
+    """(x, *parameters) -> Encoder3D(x) / Decoder3D(z): the inference launches with a tape; backward = sd3_net_backward (input and
+    parameter gradients, all on the HIP kernels)"""
 
     @staticmethod
     def forward(ctx, x: torch.Tensor, net, names: Tuple[str, ...], *params) -> torch.Tensor:
         tape: List[dict] = []
         with torch.cuda.device(x.device):
-            y = engine.sd3_encoder(net._cache(), x.detach(), dict(net._cfg), tape)
+            y = type(net)._program(net._cache(), x.detach(), dict(net._cfg), tape)
         ctx.net, ctx.tape, ctx.names = net, tape, names
         ctx.x_dtype, ctx.need_x = x.dtype, x.requires_grad
         ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
@@ -156,7 +194,7 @@ class Encoder3DFn(torch.autograd.Function):
     def backward(ctx, gy: torch.Tensor):
         net = ctx.net
         with torch.cuda.device(gy.device):
-            gx, grads = sd3_encoder_backward(net._cache(), ctx.tape, gy, need_input_grad=ctx.need_x)
+            gx, grads = sd3_net_backward(net._cache(), ctx.tape, gy, need_input_grad=ctx.need_x)
         out = []
         for name, (dt, req, shape) in zip(ctx.names, ctx.pmeta):
             gq = grads.get(name)
@@ -164,9 +202,12 @@ class Encoder3DFn(torch.autograd.Function):
         return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, *out)
 
 
+Encoder3DFn = Net3DFn
+
+
 def run_trainable(net, x: torch.Tensor, kwargs: dict) -> torch.Tensor:
     """modeling._Net.forward for a module in train() mode under grad mode: one autograd node over (x, parameters)"""
     if kwargs:
         raise NotImplementedError(f"training-mode forward takes no extra arguments (got {sorted(kwargs)})")
     named = [(n, p) for n, p in net.named_parameters()]
-    return Encoder3DFn.apply(x, net, tuple(n for n, _ in named), *[p for _, p in named])
+    return Net3DFn.apply(x, net, tuple(n for n, _ in named), *[p for _, p in named])

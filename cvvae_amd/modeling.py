@@ -193,6 +193,7 @@ class Encoder3D(_Net):
 
 class Decoder3D(_Net):
     _program = staticmethod(engine.sd3_decoder)
+    _trainable = True
 
     def __init__(self, in_channels=16, out_channels=3, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
                  mid_block_add_attention=True, causal=False, **_):

@@ -175,6 +175,35 @@ def test_sd3_encoder_backward_vs_autograd_of_the_oracle(dtype):
     assert torch.equal(xb.grad, xa.grad) and all(torch.equal(p.grad, g1[n]) for n, p in enc.named_parameters())
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_sd3_decoder_backward_vs_autograd_of_the_oracle(dtype):
+    """Decoder3D: conv_in over the latent, mid block (attention at 512 channels), up blocks with both Upsample3D kinds (time
+    shuffle + frame drop; spatial only), norm_out + conv_out: dL/dz and every parameter gradient against autograd over the oracle"""
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 8)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dtype).cuda()
+    dec = m.decoder.train()
+    ref_sd = {k: v.to(dtype).float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    z = seeded_input((1, 16, 3, 8, 8), 13).to(dtype)
+    zr = z.float().clone().requires_grad_(True)
+    yr = O.sd3_decoder(zr, ref_sd, dict(SMALL))
+    cot = seeded_input(tuple(yr.shape), 5).to(dtype)
+    (yr * cot.float()).sum().backward()
+    za = z.cuda().requires_grad_(True)
+    ya = dec(za)
+    (ya.float() * cot.cuda().float()).sum().backward()
+    e_y, e_z = rel(ya, yr), rel(za.grad, zr.grad)
+    names = [n for n, _ in dec.named_parameters()]
+    scale = max(float(ref_sd["decoder." + n].grad.norm()) for n in names)
+    errs = sorted(((rel(p.grad, ref_sd["decoder." + n].grad, 1e-3 * scale), n) for n, p in dec.named_parameters()), reverse=True)
+    _log(f"[sd3 decoder backward {str(dtype)[6:]}] forward rel {e_y:.2e}; dL/dz rel {e_z:.2e}; parameters: worst {errs[0][0]:.2e} "
+         f"({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e} ({len(names)} tensors)")
+    assert e_z <= NET_IN_TOL[dtype], e_z
+    assert errs[0][0] <= NET_W_TOL[dtype], errs[:5]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_step_chain_through_the_frozen_constraint_decoder(dtype):
     """the reference's step (autoencoder.py:1057-1069): z from the TRAINABLE encoder, xrec_2d = frozen constraint_decoder(z), a loss

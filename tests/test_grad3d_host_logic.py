@@ -62,3 +62,36 @@ def test_sd3_encoder_backward_wiring(shape):
         # eval() mode stays the inference pass (no graph)
         enc.eval()
         assert not enc(x).requires_grad
+
+
+@pytest.mark.parametrize("zshape", [(1, 16, 3, 4, 6), (2, 16, 1, 4, 4)])
+def test_sd3_decoder_backward_wiring(zshape):
+    """Decoder3D: conv_in over the latent, mid block, up blocks with BOTH Upsample3D kinds (time shuffle + frame drop on even
+    blocks, spatial only on odd ones), norm_out + conv_out (the taps-in-N forward form): dL/dz and every parameter gradient"""
+    import cvvae_amd
+    from cvvae_amd import engine, grad3d
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 8)
+    m.load_state_dict(sd, strict=True)
+    dec = m.decoder
+    ref_sd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    z = seeded_input(zshape, 13)
+    zr = z.clone().requires_grad_(True)
+    cfg = dict(block_out_channels=SMALL["block_out_channels"], layers_per_block=1)
+    yr = O.sd3_decoder(zr, ref_sd, cfg)
+    cot = seeded_input(tuple(yr.shape), 5)
+    (yr * cot).sum().backward()
+    with emu_ops.patched(whole_model=True):
+        dec.train()
+        za = z.clone().requires_grad_(True)
+        ya = dec(za)
+        assert ya.requires_grad and torch.allclose(ya.detach(), yr.detach(), rtol=1e-4, atol=1e-5), float((ya - yr).abs().max())
+        (ya * cot).sum().backward()
+        assert _rel(za.grad, zr.grad) < 1e-4, _rel(za.grad, zr.grad)
+        names = [n for n, _ in dec.named_parameters()]
+        scale = max(float(ref_sd["decoder." + n].grad.norm()) for n in names)
+        for n, p in dec.named_parameters():
+            assert p.grad is not None and p.grad.shape == p.shape, n
+            assert _rel(p.grad, ref_sd["decoder." + n].grad, 1e-4 * scale) < 2e-4, (n, _rel(p.grad, ref_sd["decoder." + n].grad))
+        dec.eval()
+        assert not dec(z).requires_grad
