@@ -698,12 +698,21 @@ def main():
             out["encode_tflops"] = round(et / enc_ms * 1e3, 1)
             out["decode_tflops"] = round((ALG_TFLOP[args.workload] - et) / dec_ms * 1e3, 1)
             out["encode_frac_of_mfma_peak"] = round(et / enc_ms * 1e3 / MFMA_PEAK_TFLOPS, 4)
-    if rank == 0 and not args.no_roofline:
+    roof_step = step
+    if dist is not None:
+        # rank 0 alone runs the per-launch timing pass: it must not enter a collective.  The temporal shard's per-GPU work is one
+        # 17-frame window -- rank 0's own frames ARE such a clip; other multi-GPU workloads: no roofline pass
+        if tshard:
+            def roof_step():
+                return vae.decode(vae.encode(x).latent_dist.mode()).sample
+        elif cfg4:
+            roof_step = None
+    if rank == 0 and not args.no_roofline and roof_step is not None:
         vae.enable_hip_graphs(False)  # per-launch timing needs the eager launches
-        out.update(roofline_report(roofline_pass(step), args, elapsed / args.steps,
+        out.update(roofline_report(roofline_pass(roof_step), args, elapsed / args.steps,
                                    profiled=args.workload.startswith("cfg3") and args.dtype == "bf16"))
         out["hbm"].update(out.pop("hbm_pmc", {}))
-    golden = GOLDEN_OF.get(args.workload)
+    golden = GOLDEN_OF.get("cfg3_sd3_T17_512" if tshard else args.workload)  # (the shard's per-GPU window is cfg 3's clip shape)
     have_golden = golden is not None and os.path.isfile(os.path.join(P.GOLDEN_DIR, golden + ".npz"))
     tol_mode = (rank == 0 and world == 1 and not args.no_tolerance_mode and not args.no_parity and not args.dtype.startswith("f32")
                 and not cfg5 and have_golden)

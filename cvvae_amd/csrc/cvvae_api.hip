@@ -130,7 +130,13 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
     // (not for the 1x1 family: its batch items are the FRAMES of the attention blocks -- 32 workgroups each, several per launch --
     //  and the per-item term pushed those products to the instance with more, smaller workgroups: 0.69 -> 0.41 ms per cfg 3 step
     //  with the 256-channel tile)
-    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + 0.5 * (ceil(wgs / cus) / (wgs / cus) - 1.0);
+    // weight of the term: 0.5 until round 4 ("a partly filled last round costs half of its share"), measured when the 128-pixel
+    // tiles were as fast per MFMA as the 256-pixel ones.  Since the MREP >= 8 instances keep their B fragments single-buffered and
+    // batch their staging loads (round 2), a 128-pixel tile costs ~1.25x per MFMA, and on vae3d's small frames (cfg 2: 9x128x128
+    // at 256 channels, 9x64x64 at 512) the 256-pixel tile is 15-23 % faster even at 1.1-2.25 rounds
+    // (profiles/r4_tune_instances_cfg2.log): 0.1 keeps the term as the tie-breaker against starved grids (5x32x32: 40 workgroups)
+    static const double quant_w = getenv("CVVAE_CONV_QUANT_W") ? atof(getenv("CVVAE_CONV_QUANT_W")) : 0.1;
+    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + quant_w * (ceil(wgs / cus) / (wgs / cus) - 1.0);
   }
   return cost;
 }

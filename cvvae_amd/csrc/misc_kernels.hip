@@ -778,8 +778,10 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const T* __restrict
 }
 
 static inline int gn_bwd_splits(long long S) {  // >= 2048 pixels per split: the per-split reduction stays a small share
+  // (up to 512 splits: a 5-D GroupNorm has ONE row per sample, and 64 workgroups left three quarters of the CUs idle on the
+  //  million-pixel tensors of a training step -- 372 us per call, profiles/r4_train_step_kernel_stats_v2.txt)
   const long long n = (S + 2047) / 2048;
-  return (int)(n < 1 ? 1 : (n > 64 ? 64 : n));
+  return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
 }
 template <typename T>
 static void gn_bwd_launch(const void* x, const void* gy, const void* add, int rows, long long S, int C, int G, const float* rs,

@@ -10,11 +10,13 @@
 //
 //   * workgroup = 8 waves; tile = 128 output channels x 64 input channels x the KH*KW spatial taps of ONE time tap
 //     (blockIdx.z = dt): 4 x 2 x 9 accumulator fragments of 32 x 32, nine per wave (144 registers);
-//   * K panel = KP consecutive output pixels of one output row (b, t, y).  Staging: 16-byte global loads (8 channels of one
-//     pixel; a wave covers 8 pixels x 64 channels = whole 128-byte lines) into registers, then eight 2-byte LDS writes per load
-//     into CHANNEL-major rows  GS[co][k]  and  XS[dy][dx][ci][k] = a[.., x0*sW + k*sW + dx - pw][ci]  -- one copy per kW tap, so
-//     that every MFMA operand is an ALIGNED ds_read_b128 of 8 consecutive k (row pitch KP*2+16 bytes: conflict-free for the
-//     reads and for the transposing writes); strides and both padding flavours live in the staging's coordinate map;
+//   * K panel = KP consecutive output pixels of one output row (b, t, y).  Staging: ONE task per thread and panel -- the input
+//     pixels under 8 consecutive output pixels x 8 channels (7 sW + kW sixteen-byte global loads; a wave's lanes cover whole
+//     128-byte lines), whose 8 x 8 (pixel, channel) block is transposed IN REGISTERS (static indices) and written as 16-byte rows
+//     into CHANNEL-major LDS copies  GS[co][k]  and  XS[dy][dx][ci][k] = a[.., (x0+k)*sW + dx - pw][ci]  -- one copy per kW tap, so
+//     that every MFMA operand is an ALIGNED ds_read_b128 of 8 consecutive k (row pitch KP*2+16 bytes: conflict-free for the reads
+//     and for the 16-byte writes); strides and both padding flavours live in the staging's coordinate map.  (The first version
+//     wrote 2-byte elements -- 88 ds_write_b16 per thread and panel -- and ran at 0.09 of the MFMA peak: profiles/r4_train_step_v1_*.json);
 //   * the loads of panel i+1 are issued before the MFMAs of panel i (register prefetch), LDS is single-buffered;
 //   * MFMA: v_mfma_f32_32x32x16 with A = gy^T fragment (rows = output channels), B = a fragment (columns = input channels): an
 //     accumulator lane holds one input channel and 16 output channels of one tap;
@@ -23,8 +25,8 @@
 //   * fp32 models (XP): both operands are split bf16 hi + lo (gradients have fp32's range, so bf16 rather than fp16) and every
 //     product runs as three MFMAs  g_hi a_hi + g_hi a_lo + g_lo a_hi  (~2^-16 relative); KP = 32 keeps the doubled LDS in budget.
 //
-// Bound: MFMA for the 3x3x3 layers (same FLOPs as the forward), but this first version is staging-bound (88 two-byte LDS writes
-// per thread and panel against 36 MFMAs per wave); it exists for correctness of the training path, not yet for speed.
+// Bound: MFMA for the 3x3x3 layers (same FLOPs as the forward).  LDS is single-buffered (101 KB per panel set), so a panel's
+// staging and its 36 MFMAs per wave alternate; the global loads of panel i+1 fly under the MFMAs of panel i.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -46,20 +48,31 @@ struct WgradArgs {
   int Coutp, Cinp;  // padded to multiples of 128 / 64: the partial buffer's channel extents
 };
 
-template <typename T, int KHW, bool XP>
+// 16-bit pair (a = element of the earlier pixel, b = of the later one) from channel j of two pixels' packed 8-channel vectors
+__device__ __forceinline__ unsigned pair16(const uint4& pa, const uint4& pb, int j) {
+  const unsigned wa = j < 2 ? pa.x : (j < 4 ? pa.y : (j < 6 ? pa.z : pa.w));
+  const unsigned wb = j < 2 ? pb.x : (j < 4 ? pb.y : (j < 6 ? pb.z : pb.w));
+  return (j & 1) ? ((wa >> 16) | (wb & 0xffff0000u)) : ((wa & 0xffffu) | (wb << 16));
+}
+
+template <typename T, int KHW, bool XP, int SW>
 __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   using TIO = std::conditional_t<XP, float, T>;
   using v8 = typename Tr<T>::v8;
-  constexpr int KP = XP ? 32 : 64;        // output pixels per K panel
+  // output pixels per K panel (single-tap kernels -- shortcuts, linear layers -- take longer panels: one accumulator fragment per
+  // wave is little MFMA work per staged panel)
+  constexpr int KP = KHW == 1 ? (XP ? 64 : 128) : (XP ? 32 : 64);
   constexpr int ROWP = KP * 2 + 16;       // LDS row pitch (bytes): odd multiple of 16
   constexpr int NSP = KHW * KHW;          // spatial taps
   constexpr int CO = 128, CI = 64;
   constexpr int NPART = XP ? 2 : 1;       // hi (and lo) copies
   constexpr int XS_BYTES = NSP * CI * ROWP, GS_BYTES = CO * ROWP;
-  constexpr int MAXSW = 2;
-  constexpr int XPIX_MAX = (KP - 1) * MAXSW + KHW;
-  constexpr int NXI = (KHW * XPIX_MAX * 8 + 511) / 512;  // 16-byte (8-channel) x items per thread and panel
-  constexpr int NGI = (KP * 16 + 511) / 512;
+  constexpr int KB = KP / 8;              // 8-pixel k blocks per panel
+  constexpr int NL = 7 * SW + KHW;        // input pixels one x task loads: the 8 outputs' taps along W
+  constexpr int CH = XP ? 4 : 8;          // channels per staging task = one 16-byte load per pixel (8 x 16 bit, or 4 floats)
+  constexpr int NCX = CI / CH, NCG = CO / CH;       // channel groups of the x / g tile
+  constexpr int NXT = KHW * KB * NCX, NGT = KB * NCG;  // staging tasks per panel: x (dy, k block, channel group), g (k block, group)
+  static_assert(NXT + NGT <= 512, "one staging task per thread");
   static_assert(NPART * (XS_BYTES + GS_BYTES) <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) char smem[NPART * (XS_BYTES + GS_BYTES)];
   char* const xs = smem;                       // [part][tap][ci][ROWP]
@@ -70,10 +83,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   const int co_blk = blockIdx.y / p.n_ci_blk, ci_blk = blockIdx.y % p.n_ci_blk;
   const int dt = blockIdx.z;
   const int co0 = co_blk * CO, ci0 = ci_blk * CI;
-  const int r0 = (int)((long long)p.rows_total * slab / p.nslab), r1 = (int)((long long)p.rows_total * (slab + 1) / p.nslab);
+  // the panels of all output rows, cut into nslab contiguous runs (a flattened 1x1 layer is ONE long row)
   const int npanel_row = (p.Wo + KP - 1) / KP;
-  const long long npanels = (long long)(r1 - r0) * npanel_row;
-  const int xpix = (KP - 1) * p.sW + KHW;  // halo pixels per staged input row
+  const long long ptotal = (long long)p.rows_total * npanel_row;
+  const long long pbeg = ptotal * slab / p.nslab, npanels = ptotal * (slab + 1) / p.nslab - pbeg;
 
   const TIO* __restrict__ ap = reinterpret_cast<const TIO*>(p.a);
   const TIO* __restrict__ gp = reinterpret_cast<const TIO*>(p.g);
@@ -84,69 +97,95 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  Raw8<TIO> xr[NXI], gr[NGI];
-  // source of my items of panel `pi` (coordinates only; the loads follow)
+  // ---- staging: ONE task per thread and panel.  Threads [0, NXT): x task (dy, k block kb, channel group): the NL input pixels
+  //      under the 8 output pixels of the block, CH channels each (one 16-byte load per pixel; consecutive lanes = consecutive
+  //      channel groups of a pixel, i.e. whole 128-byte lines); the 8 x CH (pixel, channel) block is transposed IN REGISTERS (static
+  //      indices: free) and written as 16-byte rows  XS[dy][dx][channel][8 consecutive k]  -- one row per channel and kW tap.
+  //      Threads [NXT, NXT + NGT): g task (k block, channel group) the same way into GS[channel][k].
+  const bool is_x = tid < NXT, is_g = tid >= NXT && tid < NXT + NGT;
+  const int xt_cg = tid % NCX, xt_kb = (tid / NCX) % KB, xt_dy = (tid / NCX) / KB;
+  const int gt = tid - NXT, gt_cg = gt % NCG, gt_kb = gt / NCG;
+  constexpr int NREG = NL > 8 ? NL : 8;
+  uint4 raw[NREG];
   auto load_panel = [&](long long pi) {
-    const int row = r0 + (int)(pi / npanel_row), x0 = (int)(pi % npanel_row) * KP;
+    const long long pg_ = pbeg + pi;
+    const int row = (int)(pg_ / npanel_row), x0 = (int)(pg_ % npanel_row) * KP;
     const int yo = row % p.Ho, to = (row / p.Ho) % p.To, b = row / (p.Ho * p.To);
-    bool zt = false;
-    const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zt);
+    if (is_x) {
+      bool zrow = false;
+      const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zrow);
+      const int ys = map_coord(yo * p.sH + xt_dy - p.ph, p.Hi, p.mode_hw, zrow);
+      const int c = ci0 + xt_cg * CH;
+      const TIO* rowp = ap + (((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi * p.a_ps + c;
+      const int xb = (x0 + xt_kb * 8) * SW - p.pw;  // unpadded input column of pixel 0 of my block
 #pragma unroll
-    for (int it = 0; it < NXI; ++it) {
-      const int id = it * 512 + tid;
-      const int oct = id & 7, hx = (id >> 3) % xpix, dy = (id >> 3) / xpix;
-      bool zero = zt;
-      Raw8<TIO> r{};
-      if (dy < KHW) {
-        const int ys = map_coord(yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, zero);
-        const int xsrc = map_coord(x0 * p.sW + hx - p.pw, p.Wi, p.mode_hw, zero);
-        const int c = ci0 + oct * 8;
-        if (!zero && c < p.Cin) r = ldraw8<TIO>(ap + ((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi + xsrc) * p.a_ps + c);
+      for (int i = 0; i < NL; ++i) {
+        bool zero = zrow;
+        const int xsrc = map_coord(xb + i, p.Wi, p.mode_hw, zero);
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (!zero && c < p.Cin) r = *reinterpret_cast<const uint4*>(rowp + (long long)xsrc * p.a_ps);
+        raw[i] = r;
       }
-      xr[it] = r;
-    }
+    } else if (is_g) {
+      const int c = co0 + gt_cg * CH;
+      const TIO* rowp = gp + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * p.g_ps + c;
+      const int kx = x0 + gt_kb * 8;
 #pragma unroll
-    for (int it = 0; it < NGI; ++it) {
-      const int id = it * 512 + tid;
-      const int oct = id & 15, k = id >> 4;
-      Raw8<TIO> r{};
-      const int c = co0 + oct * 8;
-      if (k < KP && x0 + k < p.Wo && c < p.Cout)
-        r = ldraw8<TIO>(gp + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo + (x0 + k)) * p.g_ps + c);
-      gr[it] = r;
+      for (int i = 0; i < 8; ++i) {
+        uint4 r = make_uint4(0u, 0u, 0u, 0u);
+        if (kx + i < p.Wo && c < p.Cout) r = *reinterpret_cast<const uint4*>(rowp + (long long)(kx + i) * p.g_ps);
+        raw[i] = r;
+      }
     }
   };
-  // 8 values of one pixel -> 8 channel rows of the transposed LDS copy (hi, and lo for XP)
-  auto put8 = [&](char* base, int row0, int k, const Raw8<TIO>& r, long long part_stride) {
-    float f[8];
-    unraw8<TIO>(r, f);
+  // my task's pixels -> the storage type T, packed per pixel: `hi` (16-bit models: the loaded 8-channel vector itself) and, for
+  // fp32 models (4 floats per pixel), hi = T(x) and lo = T(x - hi) in the low halves of the vectors
+  auto convert = [&](auto n_tag, uint4 (&hi)[NREG], uint4 (&lo)[NREG]) {
+    constexpr int N = decltype(n_tag)::value;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const T h = (T)f[j];
-      *reinterpret_cast<T*>(base + (row0 + j) * ROWP + k * 2) = h;
-      if constexpr (XP) *reinterpret_cast<T*>(base + part_stride + (row0 + j) * ROWP + k * 2) = (T)(f[j] - (float)h);
+    for (int i = 0; i < N; ++i) {
+      if constexpr (XP) {
+        const float f[4] = {__uint_as_float(raw[i].x), __uint_as_float(raw[i].y), __uint_as_float(raw[i].z), __uint_as_float(raw[i].w)};
+        float fh[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, fl[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          fh[j] = (float)(T)f[j];
+          fl[j] = f[j] - fh[j];
+        }
+        hi[i] = pack8<T>(fh);
+        lo[i] = pack8<T>(fl);
+      } else {
+        hi[i] = raw[i];
+      }
+    }
+  };
+  // pixels first, first + step, ..., first + 7 step of px -> CH channel rows of 8 consecutive k each (16-byte LDS writes)
+  auto put_block = [&](const uint4 (&px)[NREG], int first, int step, char* dst) {
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      uint4 o;
+      o.x = pair16(px[first], px[first + step], j);
+      o.y = pair16(px[first + 2 * step], px[first + 3 * step], j);
+      o.z = pair16(px[first + 4 * step], px[first + 5 * step], j);
+      o.w = pair16(px[first + 6 * step], px[first + 7 * step], j);
+      *reinterpret_cast<uint4*>(dst + j * ROWP) = o;
     }
   };
   auto store_panel = [&]() {
+    uint4 hi[NREG], lo[NREG];
+    if (is_x) {
+      convert(std::integral_constant<int, NL>{}, hi, lo);
 #pragma unroll
-    for (int it = 0; it < NXI; ++it) {
-      const int id = it * 512 + tid;
-      const int oct = id & 7, hx = (id >> 3) % xpix, dy = (id >> 3) / xpix;
-      if (dy >= KHW) continue;
-#pragma unroll
-      for (int dx = 0; dx < KHW; ++dx) {  // halo pixel hx is tap dx of output pixel k when k * sW + dx == hx
-        const int num = hx - dx;
-        if (num < 0) continue;
-        const int k = p.sW == 1 ? num : (num >> 1);
-        if ((p.sW == 2 && (num & 1)) || k >= KP) continue;
-        put8(xs, (dy * KHW + dx) * CI + oct * 8, k, xr[it], XS_BYTES);
+      for (int dx = 0; dx < KHW; ++dx) {
+        char* dst = xs + ((xt_dy * KHW + dx) * CI + xt_cg * CH) * ROWP + xt_kb * 16;
+        put_block(hi, dx, SW, dst);
+        if constexpr (XP) put_block(lo, dx, SW, dst + XS_BYTES);
       }
-    }
-#pragma unroll
-    for (int it = 0; it < NGI; ++it) {
-      const int id = it * 512 + tid;
-      const int oct = id & 15, k = id >> 4;
-      if (k < KP) put8(gs, oct * 8, k, gr[it], GS_BYTES);
+    } else if (is_g) {
+      convert(std::integral_constant<int, 8>{}, hi, lo);
+      char* dst = gs + (gt_cg * CH) * ROWP + gt_kb * 16;
+      put_block(hi, 0, 1, dst);
+      if constexpr (XP) put_block(lo, 0, 1, dst + GS_BYTES);
     }
   };
 
@@ -154,11 +193,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   const unsigned a_off = (unsigned)((cof * 32 + (lane & 31)) * ROWP + (lane >> 5) * 16);
   const unsigned b_off = (unsigned)((cif * 32 + (lane & 31)) * ROWP + (lane >> 5) * 16);
 
-  if (npanels > 0) load_panel(0);
+  // 16-bit models: the loads of panel i+1 fly under the MFMAs of panel i (40-68 registers of prefetch).  fp32 models: no room
+  // beside the 144 accumulators and the three-MFMA operand sets -- the loads are issued right before they are staged
+  constexpr bool PREFETCH = !XP;
+  if (PREFETCH && npanels > 0) load_panel(0);
   for (long long pi = 0; pi < npanels; ++pi) {
+    if (!PREFETCH) load_panel(pi);
     store_panel();
     __syncthreads();
-    if (pi + 1 < npanels) load_panel(pi + 1);
+    if (PREFETCH && pi + 1 < npanels) load_panel(pi + 1);
 #pragma unroll
     for (int s = 0; s < KP / 16; ++s) {
       const v8 ah = *reinterpret_cast<const v8*>(gs + a_off + s * 32);
@@ -207,9 +250,11 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_ci) {
   n_co = (d->Cout + 127) / 128;
   n_ci = (d->Cin + 63) / 64;
-  const long long rows = (long long)d->B * d->To * d->Ho;
+  const bool xp = d->dtype >= CVVAE_F32;
+  const int kp = d->kH == 1 ? (xp ? 64 : 128) : (xp ? 32 : 64);      // the kernel's K panel (wgrad_kernel)
+  const long long rows = (long long)d->B * d->To * d->Ho * ((d->Wo + kp - 1) / kp);  // panels in all
   const long long per_slab = (long long)n_co * n_ci * d->kT;
-  long long s = (1024 + per_slab - 1) / per_slab;                     // ~4 workgroups per CU in all
+  long long s = (768 + per_slab - 1) / per_slab;                      // ~3 workgroups per CU in all
   const long long tile_bytes = (long long)d->kT * d->kH * d->kW * n_co * 128 * n_ci * 64 * 4;
   const long long cap = (512ll << 20) / (tile_bytes > 0 ? tile_bytes : 1);  // <= 512 MB of partials
   if (s > cap) s = cap;
@@ -218,8 +263,8 @@ static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_c
   nslab = (int)s;
 }
 
-template <typename T, int KHW, bool XP>
-static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
+template <typename T, int KHW, bool XP, int SW>
+static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
   int nslab, n_co, n_ci;
   wgrad_plan(d, nslab, n_co, n_ci);
   WgradArgs p{};
@@ -230,7 +275,7 @@ static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy,
   p.mode_t = d->pad_mode_t; p.mode_hw = d->pad_mode_hw;
   p.nslab = nslab; p.rows_total = d->B * d->To * d->Ho; p.n_ci_blk = n_ci;
   p.Coutp = n_co * 128; p.Cinp = n_ci * 64;
-  hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP>), dim3(nslab, n_co * n_ci, d->kT), dim3(512), 0, s, p);
+  hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3(nslab, n_co * n_ci, d->kT), dim3(512), 0, s, p);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const int ntaps = d->kT * d->kH * d->kW;
@@ -239,6 +284,11 @@ static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy,
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp,
                      d->Cout, d->Cin, dw);
   return (int)hipGetLastError();
+}
+
+template <typename T, int KHW, bool XP>
+static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
+  return d->sW == 2 ? wgrad_launch_sw<T, KHW, XP, 2>(d, a, gy, g_ps, dw, ws, s) : wgrad_launch_sw<T, KHW, XP, 1>(d, a, gy, g_ps, dw, ws, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -319,15 +369,31 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
 
 __global__ __launch_bounds__(256) void chan_sums_final_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ o1,
                                                               float* __restrict__ o2) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  // a block = 32 channels x 8 part lanes: lane pl sums parts pl, pl + 8, ... (coalesced 256-byte rows), then the 8 lanes are
+  // added in index order -- a fixed summation order, hence bit-reproducible
+  __shared__ float sh[8][32][2];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
   float a1 = 0.f, a2 = 0.f;
-  for (int i = 0; i < nparts; ++i) {
-    a1 += ws[((long long)i * C + c) * 2];
-    a2 += ws[((long long)i * C + c) * 2 + 1];
+  if (c < C)
+    for (int i = pl; i < nparts; i += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(ws + ((long long)i * C + c) * 2);
+      a1 += v.x;
+      a2 += v.y;
+    }
+  sh[pl][cl][0] = a1;
+  sh[pl][cl][1] = a2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s1 += sh[k][cl][0];
+      s2 += sh[k][cl][1];
+    }
+    if (o1) o1[c] = s1;
+    if (o2) o2[c] = s2;
   }
-  if (o1) o1[c] = a1;
-  if (o2) o2[c] = a2;
 }
 
 static inline int chan_sums_splits(long long S, int rows) {
@@ -465,7 +531,7 @@ int cvvae_channel_sums(int32_t dtype, const void* x, const void* g, int64_t g_pi
   }
   int rc = (int)hipGetLastError();
   if (rc) return rc;
-  hipLaunchKernelGGL(chan_sums_final_kernel, dim3((C + 255) / 256), dim3(256), 0, stream, (const float*)ws, rows * nsplit, C, sum1,
+  hipLaunchKernelGGL(chan_sums_final_kernel, dim3((C + 31) / 32), dim3(256), 0, stream, (const float*)ws, rows * nsplit, C, sum1,
                      sum2);
   return (int)hipGetLastError();
 }

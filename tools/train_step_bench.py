@@ -1,0 +1,103 @@
+"""Timing of the training-side path (cvvae_amd/grad3d.py): one step of the reference's autoencoder training
+(lvdm/models/autoencoder.py:1057-1090) on the vae3d_sd3 networks -- z = encoder(x), xrec = decoder(z), a reconstruction loss,
+backward into every parameter of both networks -- and the weight-gradient kernel alone on the layer shapes of such a step.
+  python tools/train_step_bench.py [--T 17 --H 256 --W 256 --dtype bf16]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def ev():
+    return torch.cuda.Event(enable_timing=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--T", type=int, default=17)
+    ap.add_argument("--H", type=int, default=256)
+    ap.add_argument("--W", type=int, default=256)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
+    ap.add_argument("--steps", type=int, default=3)
+    args = ap.parse_args()
+    import cvvae_amd
+    from cvvae_amd import ops
+    from oracle import parity as P
+    dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
+    out = {"dtype": args.dtype, "clip": [1, 3, args.T, args.H, args.W]}
+    # ---- the weight-gradient kernel alone (bf16 / fp16 operands; fp32 = three bf16 MFMAs per product)
+    layers = [("128->128 3x3x3 causal", 128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), (args.T, args.H, args.W)),
+              ("128->128 1x3x3", 128, 128, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), (args.T, args.H, args.W)),
+              ("256->256 3x3x3 causal", 256, 256, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), ((args.T + 1) // 2, args.H // 2, args.W // 2)),
+              ("512->512 3x3x3 causal", 512, 512, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), ((args.T + 1) // 2, args.H // 4, args.W // 4)),
+              ("128->128 3x3x3 stride 2", 128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (1, 1), (1, 1)), (args.T, args.H, args.W))]
+    out["wgrad"] = []
+    for name, ci, co, k, st, pad, (T, H, W) in layers:
+        a = torch.randn(1, T, H, W, ci, device="cuda").to(dtype)
+        To = (T + pad[0][0] + pad[0][1] - k[0]) // st[0] + 1
+        Ho = (H + 2 - k[1]) // st[1] + 1
+        Wo = (W + 2 - k[2]) // st[2] + 1
+        g = torch.randn(1, To, Ho, Wo, co, device="cuda").to(dtype)
+        kw = dict(stride=st, pad=pad, pad_mode_t=1, pad_mode_hw=1 if k[0] == 3 else 0)
+        ops.conv_wgrad(a, g, k, **kw)
+        e0, e1 = ev(), ev()
+        e0.record()
+        for _ in range(3):
+            ops.conv_wgrad(a, g, k, **kw)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 3
+        fl = 2.0 * To * Ho * Wo * co * ci * k[0] * k[1] * k[2]
+        out["wgrad"].append({"layer": name, "in": [T, H, W], "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1),
+                             "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500.0, 4)})
+        del a, g
+    # ---- one training step of both networks
+    m = cvvae_amd.CVVAESD3Model()
+    P.load_seeded(m, 0)
+    m = m.to(dtype).cuda().train()
+    x = (torch.rand((1, 3, args.T, args.H, args.W)) * 2 - 1).to(dtype).cuda()
+    zc = m.encoder.conv_out.weight.shape[0] // 2
+
+    def step():
+        t = [ev() for _ in range(4)]
+        m.zero_grad(set_to_none=True)
+        t[0].record()
+        mom = m.encoder(x)
+        z = mom[:, :zc].contiguous()
+        t[1].record()
+        xrec = m.decoder(z)
+        t[2].record()
+        loss = (xrec.float() - x.float()).pow(2).mean()
+        loss.backward()
+        t[3].record()
+        torch.cuda.synchronize()
+        return [t[i].elapsed_time(t[i + 1]) for i in range(3)], float(loss)
+    step()
+    ts = [step() for _ in range(args.steps)]
+    enc_f = sum(t[0][0] for t in ts) / len(ts)
+    dec_f = sum(t[0][1] for t in ts) / len(ts)
+    bwd = sum(t[0][2] for t in ts) / len(ts)
+    with torch.no_grad():
+        m.eval()
+        e0, e1 = ev(), ev()
+        m.decoder(m.encoder(x)[:, :zc].contiguous())
+        e0.record()
+        m.decoder(m.encoder(x)[:, :zc].contiguous())
+        e1.record()
+        torch.cuda.synchronize()
+        inf = e0.elapsed_time(e1)
+    ngrad = sum(1 for p in m.parameters() if p.grad is not None)
+    out["train_step"] = {"encoder_forward_taped_ms": round(enc_f, 2), "decoder_forward_taped_ms": round(dec_f, 2),
+                         "backward_ms": round(bwd, 2), "inference_forward_ms": round(inf, 2),
+                         "backward_over_forward": round(bwd / (enc_f + dec_f), 2), "loss": ts[-1][1],
+                         "parameters_with_grad": ngrad, "parameters": sum(1 for _ in m.parameters()),
+                         "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
