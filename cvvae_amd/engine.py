@@ -562,7 +562,8 @@ def sd3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, wan
                      prologue=L.PRO_GN_SILU, gn=g1, gn_out=G32, act_norm=pre + ".norm1")
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-6)
     if tape is not None:  # what the training-side backward (grad3d.py) reads again: block input, conv1 output, their statistics
-        tape.append(dict(op="resnet3d", pre=pre, x=x, xp=xp, h=h, hp=hp, g1=g1, g2=g2, causal=causal))
+        tape.append(dict(op="resnet3d", pre=pre, x=x, xp=xp, h=h, hp=hp, g1=g1, g2=g2, pad=PC if causal else P1, mode_t=REP, mode_hw=REP,
+                         eps=1e-6, sc=".conv_shortcut"))
     return resnet_tail(wc, x, h, pre, pre + ".conv_shortcut", g2, want_stats)
 
 
@@ -586,20 +587,20 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list
     pad = PC if causal else P1
     h, hp = encoder_conv_in(wc, x, cfg, dtype, pad, REP, REP)
     if tape is not None:
-        tape.append(dict(op="conv_in", x=x, pad=pad, ndhwc_in=bool(cfg.get("ndhwc_in"))))
+        tape.append(dict(op="conv_in", x=x, pad=pad, mode_t=REP, mode_hw=REP, ndhwc_in=bool(cfg.get("ndhwc_in"))))
     for i in range(len(boc)):
         for j in range(cfg["layers_per_block"]):
             h, hp = sd3_resnet(wc, h, hp, f"down_blocks.{i}.resnets.{j}", causal, tape=tape)
         if i != len(boc) - 1:  # Downsample3D vae_blocks3d_sd3.py:224-239; time stride on even blocks (:115)
             st = (2, 2, 2) if i % 2 == 0 else (1, 2, 2)
             if tape is not None:
-                tape.append(dict(op="down3d", pre=f"down_blocks.{i}.downsamplers.0.conv", x=h, stride=st, pad=pad))
+                tape.append(dict(op="down3d", pre=f"down_blocks.{i}.downsamplers.0.conv", x=h, stride=st, pad=pad, mode_t=REP, mode_hw=REP))
             h, hp = conv3(wc, h, f"down_blocks.{i}.downsamplers.0.conv", stride=st,
                              pad=pad, pad_mode_t=REP, pad_mode_hw=REP, gn_out=G32)
     h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"], tape=tape)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
     if tape is not None:
-        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad))
+        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad, mode_t=REP, mode_hw=REP, eps=1e-6, norm="conv_norm_out"))
     return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
                     prologue=L.PRO_GN_SILU, gn=g, out_mode=L.OUT_NCDHW)
 
@@ -615,7 +616,7 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list
     cpad = ops.round_up(zin, 32 if (z.shape[2] == 1 and fold_t1()) else 16)
     h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
     if tape is not None:
-        tape.append(dict(op="dec_in", x=h, pad=pad, zin=zin))
+        tape.append(dict(op="dec_in", x=h, pad=pad, mode_t=REP, mode_hw=REP, zin=zin))
     h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=REP, pad_mode_hw=REP,
                      gn_out=G32)
     h, hp = sd3_mid(wc, h, hp, "mid_block", causal, cfg["mid_block_add_attention"], tape=tape)
@@ -625,11 +626,11 @@ def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list
         if i != len(boc) - 1:  # Upsample3D vae_blocks3d_sd3.py:314-364; up_time on even blocks (vae_models3d_sd3.py:289)
             up_time = i % 2 == 0
             if tape is not None:
-                tape.append(dict(op="up3d", pre=f"up_blocks.{i}.upsamplers.0.conv", x=h, pad=pad, up_time=up_time))
+                tape.append(dict(op="up3d", pre=f"up_blocks.{i}.upsamplers.0.conv", x=h, pad=pad, mode_t=REP, mode_hw=REP, up_time=up_time))
             h, hp = upsample_conv(wc, h, f"up_blocks.{i}.upsamplers.0.conv", pad, REP, REP, up_time)
     g = _norm(wc, h, hp, "conv_norm_out", 1e-6)
     if tape is not None:
-        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad))
+        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad, mode_t=REP, mode_hw=REP, eps=1e-6, norm="conv_norm_out"))
     return decoder_conv_out(wc, h, g, pad, REP, REP, u8=bool(cfg.get("u8_out")))
 
 
@@ -767,7 +768,7 @@ def _v3_pad(causal: bool):
     return (PC, REP, ZERO) if causal else (P1, ZERO, ZERO)
 
 
-def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want_stats: bool = True):
+def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want_stats: bool = True, tape: Optional[list] = None):
     """ResnetBlock3D.forward, vae_models.py:390-410 (GN eps 1e-5, swish, nin_shortcut 1x1x1).
     xp: GroupNorm partials of x from its producer (or None).  Returns (out, partials of out or None)."""
     pad, mt, mhw = _v3_pad(causal)
@@ -775,28 +776,39 @@ def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want
     h, hp = conv3(wc, x, pre + ".conv1", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU,
                      gn=g1, gn_out=G32, act_norm=pre + ".norm1")
     g2 = ops.gn_finalize(hp, *wc.norm(pre + ".norm2"), 1e-5)
+    if tape is not None:
+        tape.append(dict(op="resnet3d", pre=pre, x=x, xp=xp, h=h, hp=hp, g1=g1, g2=g2, pad=pad, mode_t=mt, mode_hw=mhw, eps=1e-5,
+                         sc=".nin_shortcut"))
     return resnet_tail(wc, x, h, pre, pre + ".nin_shortcut", g2, want_stats)
 
 
-def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
-    """Encoder.forward, vae_models.py:790-823."""
+def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
+    """Encoder.forward, vae_models.py:790-823.  tape: see sd3_encoder (grad3d.py trains this network too)."""
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
     h, hp = encoder_conv_in(wc, x, cfg, dtype, pad, mt, mhw)
+    if tape is not None:
+        tape.append(dict(op="conv_in", x=x, pad=pad, mode_t=mt, mode_hw=mhw, ndhwc_in=bool(cfg.get("ndhwc_in"))))
     for lvl in range(nlev):
         for j in range(cfg["num_res_blocks"]):
-            h, hp = v3_resnet(wc, h, hp, f"down.{lvl}.block.{j}", causal)
+            h, hp = v3_resnet(wc, h, hp, f"down.{lvl}.block.{j}", causal, tape=tape)
         if lvl != nlev - 1:  # Downsample3D vae_models.py:251-263: zero pad right/bottom, replicate T front 2
             st = (2, 2, 2) if lvl % 2 == 0 else (1, 2, 2)
-            h, hp = conv3(wc, h, f"down.{lvl}.downsample.conv", stride=st, pad=((2, 0), (0, 1), (0, 1)),
+            dpad = ((2, 0), (0, 1), (0, 1))
+            if tape is not None:
+                tape.append(dict(op="down3d", pre=f"down.{lvl}.downsample.conv", x=h, stride=st, pad=dpad, mode_t=REP, mode_hw=ZERO))
+            h, hp = conv3(wc, h, f"down.{lvl}.downsample.conv", stride=st, pad=dpad,
                              pad_mode_t=REP, pad_mode_hw=ZERO, gn_out=G32)
-    h, hp = v3_resnet(wc, h, hp, "mid.block_1", causal)
+    h, hp = v3_resnet(wc, h, hp, "mid.block_1", causal, tape=tape)
     a = "mid.attn_1"
-    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True, gn_out=G32, xp=hp)
-    h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
+    h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, True, gn_out=G32, xp=hp,
+                              tape=tape)
+    h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal, tape=tape)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
+    if tape is not None:
+        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad, mode_t=mt, mode_hw=mhw, eps=1e-5, norm="norm_out"))
     return conv3(wc, h, "conv_out", pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, prologue=L.PRO_GN_SILU, gn=g,
                     out_mode=L.OUT_NCDHW)
 

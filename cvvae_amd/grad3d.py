@@ -24,8 +24,10 @@ vae3d_sd3 family:
 `Net3DFn` makes a taped forward + this backward ONE autograd node whose inputs are the clip (or latent) and the module's parameters,
 so `loss(x, decoder(encoder(x)), constraint_decoder(z)).backward()` fills `<net>.<param>.grad` (modeling._Net.forward takes this path
 for a module in train() mode under grad mode).  Gradients are carried in the module's dtype with fp32 accumulation inside every
-kernel; parameter gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  Not built yet: the vae3d
-family's backward, spatial tiling / temporal windows under autograd (one window, one tile per call: the training crops of the
+kernel; parameter gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  The walker takes every layer's
+padding, GroupNorm eps and names from the tape, so the vae3d (SD2.1-compatible) family's ENCODER (vae_models.py:790-823: zero H / W
+padding, asymmetric Downsample3D pads, eps 1e-5) trains through it too.  Not built yet: the vae3d DECODER's backward (its
+MemoryEfficientAttnVideoBlock needs a temporal-attention and a LayerNorm backward), spatial tiling / temporal windows under autograd (one window, one tile per call: the training crops of the
 reference's configs fit one).
 """
 from typing import Dict, List, Optional, Tuple
@@ -50,52 +52,66 @@ def _conv_param_grads(wc: WeightCache, grads: Dict[str, torch.Tensor], pre: str,
         grads[pre + ".bias"] = ops.bias_grad(g, cout=w.shape[0])
 
 
-def dgrad333_replicate(wc: WeightCache, g: torch.Tensor, pre: str, pad_t: Tuple[int, int], in_shape, stride=(1, 1, 1),
-                       add: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """input gradient of a 3x3x3 conv with replicate padding (T pads pad_t, H / W pads 1) and `stride`: g [B,To,Ho,Wo,Cout] ->
-    [B,T,H,W,Cin] (+ add)."""
+def dgrad333(wc: WeightCache, g: torch.Tensor, pre: str, pad, mode_t: int, mode_hw: int, in_shape, stride=(1, 1, 1),
+             add: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """input gradient of a 3x3x3 conv with padding `pad` = ((tf, tb), (hf, hb), (wf, wb)) in modes (mode_t, mode_hw) and `stride`:
+    g [B,To,Ho,Wo,Cout] -> [B,T,H,W,Cin] (+ add).  The full correlation with the tap-flipped, transposed weights gives the gradient
+    w.r.t. the PADDED input; the adjoint of the padding folds it back (replicate: cvvae_pad_fold; zero: a crop)."""
     B, T, H, W = in_shape
+    (tf, tb), (hf, hb), (wf, wb) = pad
+    Tz, Hz, Wz = T + tf + tb - 2, H + hf + hb - 2, W + wf + wb - 2   # the stride-1 output grid = padded extent - 2 per axis
     if tuple(stride) != (1, 1, 1):
-        # zero-stuff onto the stride-1 output grid [T+pt-2, H, W] (= padded extent - 2 per axis): positions o*s carry g
-        Tz = T + pad_t[0] + pad_t[1] - 2
-        gz = g.new_zeros((B, Tz, H, W, g.shape[-1]))
+        gz = g.new_zeros((B, Tz, Hz, Wz, g.shape[-1]))                # zero-stuffed: positions o*s carry g
         gz[:, ::stride[0], ::stride[1], ::stride[2]][:, :g.shape[1], :g.shape[2], :g.shape[3]] = g
         g = gz
-    assert g.shape[1] == T + pad_t[0] + pad_t[1] - 2 and g.shape[2] == H and g.shape[3] == W, (tuple(g.shape), in_shape, pad_t)
+    assert tuple(g.shape[1:4]) == (Tz, Hz, Wz), (tuple(g.shape), in_shape, pad)
     pw = wc.conv_dgrad(pre, K333)
     cp = ops.round_up(pw.cout, 8)  # (conv_in: 3 input channels -> an 8-channel gradient tensor, pad channels zero)
-    gp = ops.conv(g, pw, pad=FULL, pad_mode_t=ZERO, pad_mode_hw=ZERO, cout_pad=cp if cp != pw.cout else None)  # [B,T+pt0+pt1,H+2,W+2,Cin]
-    return ops.pad_fold(gp, pad_t, 1, REP, REP, add=add)
+    gp = ops.conv(g, pw, pad=FULL, pad_mode_t=ZERO, pad_mode_hw=ZERO, cout_pad=cp if cp != pw.cout else None)  # [B,T+tf+tb,H+hf+hb,W+wf+wb,Cin]
+    if mode_hw == ZERO:   # zero padding in H / W: the adjoint is the interior crop (any front / back split)
+        if hf or hb or wf or wb:
+            gp = gp[:, :, hf:hf + H, wf:wf + W].contiguous()
+        phw = 0
+    else:
+        assert hf == hb == wf == wb, "replicate H / W padding: symmetric"
+        phw = hf
+    return ops.pad_fold(gp, (tf, tb), phw, mode_t, mode_hw, add=add)
+
+
+def dgrad333_replicate(wc, g, pre, pad_t, in_shape, stride=(1, 1, 1), add=None):
+    """(the vae3d_sd3 flavour: replicate everywhere, H / W pads 1)"""
+    return dgrad333(wc, g, pre, (tuple(pad_t), (1, 1), (1, 1)), REP, REP, in_shape, stride=stride, add=add)
 
 
 def sd3_resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
-    """ResnetBlock3D (vae_blocks3d_sd3.py:517-569): y = conv2(silu(norm2(h))) + shortcut(x), h = conv1(silu(norm1(x))); g = dL/dy."""
+    """ResnetBlock3D of either family (vae_blocks3d_sd3.py:517-569, vae_models.py:390-410): y = conv2(silu(norm2(h))) + shortcut(x),
+    h = conv1(silu(norm1(x))); g = dL/dy.  Padding, GroupNorm eps and the shortcut's name come with the tape entry."""
     pre, x, h = e["pre"], e["x"], e["h"]
-    pad_t = (2, 0) if e["causal"] else (1, 1)
+    pad, mt, mhw, eps = e["pad"], e["mode_t"], e["mode_hw"], e["eps"]
     B, T, H, W, _ = x.shape
     # conv2: per-frame 3x3, zero padding, over a2 = silu(norm2(h))
     a2 = ops.gn_silu_apply(h, e["g2"])
     _conv_param_grads(wc, grads, pre + ".conv2", a2, g, K133, pad=P2D)
     del a2
     g_a2 = ops.conv(g, wc.conv_dgrad(pre + ".conv2", K133), pad=P2D, pad_mode_hw=ZERO)
-    tabs2 = grad._unit_tabs(wc, h, e["hp"], 1e-6)
+    tabs2 = grad._unit_tabs(wc, h, e["hp"], eps)
     n2 = wc.norm(pre + ".norm2")
     grads[pre + ".norm2.weight"], grads[pre + ".norm2.bias"] = ops.gn_bwd_params(h, g_a2, tabs2, *n2, silu=True)
     g_h = ops.gn_bwd_input(h, g_a2, tabs2, *n2, silu=True)
     del g_a2
-    # conv1: 3x3x3, replicate padding, over a1 = silu(norm1(x))
+    # conv1: 3x3x3 over a1 = silu(norm1(x))
     a1 = ops.gn_silu_apply(x, e["g1"])
-    _conv_param_grads(wc, grads, pre + ".conv1", a1, g_h, K333, pad=(pad_t, (1, 1), (1, 1)), pad_mode_t=REP, pad_mode_hw=REP)
+    _conv_param_grads(wc, grads, pre + ".conv1", a1, g_h, K333, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
     del a1
-    g_a1 = dgrad333_replicate(wc, g_h, pre + ".conv1", pad_t, (B, T, H, W))
+    g_a1 = dgrad333(wc, g_h, pre + ".conv1", pad, mt, mhw, (B, T, H, W))
     # skip branch
-    sc = pre + ".conv_shortcut"
+    sc = pre + e["sc"]
     if wc.has(sc + ".weight"):
         grad._linear_grads(wc, grads, sc, x.view(B, 1, 1, -1, x.shape[-1]), g.view(B, 1, 1, -1, g.shape[-1]))
         skip = grad._dgrad1x1(wc, g, sc)
     else:
         skip = g
-    tabs1 = grad._unit_tabs(wc, x, e["xp"], 1e-6)
+    tabs1 = grad._unit_tabs(wc, x, e["xp"], eps)
     n1 = wc.norm(pre + ".norm1")
     grads[pre + ".norm1.weight"], grads[pre + ".norm1.bias"] = ops.gn_bwd_params(x, g_a1, tabs1, *n1, silu=True)
     return ops.gn_bwd_input(x, g_a1, tabs1, *n1, silu=True, add=skip)
@@ -117,9 +133,9 @@ def sd3_upsample_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict
     B, T, H, W, C = x.shape
     gc = _unshuffle_time(g) if e["up_time"] else g
     a_up = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)                # F.interpolate(scale=(1,2,2), mode="nearest")
-    _conv_param_grads(wc, grads, pre, a_up, gc, K333, pad=pad, pad_mode_t=REP, pad_mode_hw=REP)
+    _conv_param_grads(wc, grads, pre, a_up, gc, K333, pad=pad, pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
     del a_up
-    gup = dgrad333_replicate(wc, gc, pre, pad[0], (B, T, 2 * H, 2 * W))
+    gup = dgrad333(wc, gc, pre, pad, e["mode_t"], e["mode_hw"], (B, T, 2 * H, 2 * W))
     return ops.upsample2x_sum(gup.view(B * T, 1, 2 * H, 2 * W, C)).view(B, T, H, W, C)
 
 
@@ -130,17 +146,17 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
     grads: Dict[str, torch.Tensor] = {}
     last = tape[-1]
     assert last["op"] == "out3d"
-    pad = last["pad"]
+    pad, mt, mhw = last["pad"], last["mode_t"], last["mode_hw"]
     cout = wc.m.get_parameter("conv_out.weight").shape[0]
     g = ops.ncdhw_to_ndhwc(gy.contiguous(), ops.round_up(cout, 16), dtype)                      # [B,T',h,w,Cpad], pad channels zero
     x = last["x"]
     a = ops.gn_silu_apply(x, last["g"])
-    _conv_param_grads(wc, grads, "conv_out", a, g, K333, pad=pad, pad_mode_t=REP, pad_mode_hw=REP)
+    _conv_param_grads(wc, grads, "conv_out", a, g, K333, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
     del a
-    g = dgrad333_replicate(wc, g, "conv_out", pad[0], tuple(x.shape[:4]))
-    tabs = grad._unit_tabs(wc, x, last["xp"], 1e-6)
-    no = wc.norm("conv_norm_out")
-    grads["conv_norm_out.weight"], grads["conv_norm_out.bias"] = ops.gn_bwd_params(x, g, tabs, *no, silu=True)
+    g = dgrad333(wc, g, "conv_out", pad, mt, mhw, tuple(x.shape[:4]))
+    tabs = grad._unit_tabs(wc, x, last["xp"], last["eps"])
+    no = wc.norm(last["norm"])
+    grads[last["norm"] + ".weight"], grads[last["norm"] + ".bias"] = ops.gn_bwd_params(x, g, tabs, *no, silu=True)
     g = ops.gn_bwd_input(x, g, tabs, *no, silu=True)
     gx = None
     for e in reversed(tape[:-1]):
@@ -150,22 +166,23 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
             g = grad.attention_backward(wc, g, e, grads)
         elif e["op"] == "down3d":
             xin = e["x"]
-            _conv_param_grads(wc, grads, e["pre"], xin, g, K333, stride=e["stride"], pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
-            g = dgrad333_replicate(wc, g, e["pre"], e["pad"][0], tuple(xin.shape[:4]), stride=e["stride"])
+            _conv_param_grads(wc, grads, e["pre"], xin, g, K333, stride=e["stride"], pad=e["pad"], pad_mode_t=e["mode_t"],
+                              pad_mode_hw=e["mode_hw"])
+            g = dgrad333(wc, g, e["pre"], e["pad"], e["mode_t"], e["mode_hw"], tuple(xin.shape[:4]), stride=e["stride"])
         elif e["op"] == "up3d":
             g = sd3_upsample_backward(wc, g, e, grads)
         elif e["op"] == "conv_in":   # the encoder's first layer over the clip
             xin = e["x"] if e["ndhwc_in"] else ops.ncdhw_to_ndhwc(e["x"], 16, dtype)           # [B,T,H,W,16], channels 3.. zero
-            _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
+            _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
             if need_input_grad:
                 # (conv_in's weights as a 128 -> 3-channel transposed kernel; the gradient tensor is channel-padded to 8)
-                gi = dgrad333_replicate(wc, g, "conv_in", e["pad"][0], tuple(xin.shape[:4]))
+                gi = dgrad333(wc, g, "conv_in", e["pad"], e["mode_t"], e["mode_hw"], tuple(xin.shape[:4]))
                 gx = ops.ndhwc_to_ncdhw(gi, wc.m.get_parameter("conv_in.weight").shape[1])
         elif e["op"] == "dec_in":    # the decoder's first layer over the (channel-padded NDHWC) latent
             xin = e["x"]
-            _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=REP, pad_mode_hw=REP)
+            _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
             if need_input_grad:
-                gi = dgrad333_replicate(wc, g, "conv_in", e["pad"][0], tuple(xin.shape[:4]))
+                gi = dgrad333(wc, g, "conv_in", e["pad"], e["mode_t"], e["mode_hw"], tuple(xin.shape[:4]))
                 gx = ops.ndhwc_to_ncdhw(gi, e["zin"])
         else:
             raise AssertionError(e["op"])

@@ -233,6 +233,7 @@ def _v3_attn(c: int, temporal: bool) -> nn.Module:
 
 class Encoder(_Net):
     _program = staticmethod(engine.v3_encoder)
+    _trainable = True  # (grad3d.py: the encoder of this family trains on the kernels; its decoder does not yet)
 
     def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4, double_z=True,
                  causal=True, **_):

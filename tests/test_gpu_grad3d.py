@@ -204,6 +204,36 @@ def test_sd3_decoder_backward_vs_autograd_of_the_oracle(dtype):
     assert errs[0][0] <= NET_W_TOL[dtype], errs[:5]
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_vae3d_encoder_backward_vs_autograd_of_the_oracle(dtype):
+    """the SD2.1-compatible family's Encoder (vae_models.py:790-823) through the same tape walker: causal convs with zero H / W
+    padding, Downsample3D's (0, 1) pads in both stride kinds, GroupNorm eps 1e-5, nin_shortcut, the mid block's attention"""
+    import cvvae_amd
+    over = dict(ch=128, ch_mult=(1, 2, 4), num_res_blocks=1)
+    m = cvvae_amd.CVVAEModel(**over)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 9)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dtype).cuda()
+    enc = m.encoder.train()
+    ref_sd = {k: v.to(dtype).float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    x = seeded_input((1, 3, 5, 32, 32), 14).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    yr = O.v3_encoder(xr, ref_sd, dict(over))
+    cot = seeded_input(tuple(yr.shape), 6).to(dtype)
+    (yr * cot.float()).sum().backward()
+    xa = x.cuda().requires_grad_(True)
+    ya = enc(xa)
+    (ya.float() * cot.cuda().float()).sum().backward()
+    e_x = rel(xa.grad, xr.grad)
+    names = [n for n, _ in enc.named_parameters()]
+    scale = max(float(ref_sd["encoder." + n].grad.norm()) for n in names)
+    errs = sorted(((rel(p.grad, ref_sd["encoder." + n].grad, 1e-3 * scale), n) for n, p in enc.named_parameters()), reverse=True)
+    _log(f"[vae3d encoder backward {str(dtype)[6:]}] forward rel {rel(ya, yr):.2e}; dL/dx rel {e_x:.2e}; parameters: worst {errs[0][0]:.2e} "
+         f"({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e} ({len(names)} tensors)")
+    assert e_x <= NET_IN_TOL[dtype], e_x
+    assert errs[0][0] <= NET_W_TOL[dtype], errs[:5]
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_training_step_chain_through_the_frozen_constraint_decoder(dtype):
     """the reference's step (autoencoder.py:1057-1069): z from the TRAINABLE encoder, xrec_2d = frozen constraint_decoder(z), a loss

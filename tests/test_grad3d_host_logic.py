@@ -95,3 +95,36 @@ def test_sd3_decoder_backward_wiring(zshape):
             assert _rel(p.grad, ref_sd["decoder." + n].grad, 1e-4 * scale) < 2e-4, (n, _rel(p.grad, ref_sd["decoder." + n].grad))
         dec.eval()
         assert not dec(z).requires_grad
+
+
+@pytest.mark.parametrize("shape,causal", [((1, 3, 5, 16, 24), True), ((1, 3, 5, 16, 16), False)])
+def test_vae3d_encoder_backward_wiring(shape, causal):
+    """the SD2.1-compatible family's Encoder (vae_models.py:790-823) through the same tape walker: zero H / W padding with the
+    causal replicate time pad (or zero padding everywhere), Downsample3D's asymmetric (0, 1) pads, GroupNorm eps 1e-5,
+    nin_shortcut, the mid block's spatial attention"""
+    import cvvae_amd
+    over = dict(ch=128, ch_mult=(1, 2, 2), num_res_blocks=1, causal_encoder=causal) if causal else dict(ch=128, ch_mult=(1, 2, 2), num_res_blocks=1, causal_encoder=False)
+    m = cvvae_amd.CVVAEModel(**over)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 9)
+    m.load_state_dict(sd, strict=True)
+    enc = m.encoder
+    ref_sd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    x = seeded_input(shape, 14)
+    xr = x.clone().requires_grad_(True)
+    yr = O.v3_encoder(xr, ref_sd, dict(over))
+    cot = seeded_input(tuple(yr.shape), 6)
+    (yr * cot).sum().backward()
+    with emu_ops.patched(whole_model=True):
+        enc.train()
+        xa = x.clone().requires_grad_(True)
+        ya = enc(xa)
+        assert ya.requires_grad and torch.allclose(ya.detach(), yr.detach(), rtol=1e-4, atol=1e-5), float((ya - yr).abs().max())
+        (ya * cot).sum().backward()
+        assert _rel(xa.grad, xr.grad) < 1e-4, _rel(xa.grad, xr.grad)
+        names = [n for n, _ in enc.named_parameters()]
+        scale = max(float(ref_sd["encoder." + n].grad.norm()) for n in names)
+        for n, p in enc.named_parameters():
+            assert p.grad is not None and p.grad.shape == p.shape, n
+            assert _rel(p.grad, ref_sd["encoder." + n].grad, 1e-4 * scale) < 2e-4, (n, _rel(p.grad, ref_sd["encoder." + n].grad))
+        # the decoder of this family has no backward yet: train() + grad mode stays the inference pass
+        assert not getattr(type(m.decoder), "_trainable", False)
