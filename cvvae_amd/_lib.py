@@ -72,6 +72,7 @@ PROTOTYPES = {
     "cvvae_conv_wgrad": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _i64, _vp, _vp, _vp]),
     "cvvae_channel_sums_workspace_bytes": (_i64, [_i32, _i64, _i32]),
     "cvvae_channel_sums": (_i32, [_i32, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
+    "cvvae_temporal_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),
     "cvvae_pad_fold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "cvvae_layernorm": (_i32, [_i32, _vp, _i64, _i32, _f32, _vp, _vp, _vp, _vp]),
     "cvvae_softmax_rows": (_i32, [_i32, _vp, _i64, _i32, _i64, _vp, _i64, _vp]),

@@ -455,6 +455,133 @@ __global__ __launch_bounds__(256) void pad_fold_kernel(const T* __restrict__ gp,
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// backward of cvvae_temporal_attention (MemoryEfficientAttnVideoBlock.attention_t, models/vae_models.py:573-587): per pixel,
+// softmax(q k^T * scale) v over the Tn <= 8 frames of a clip.  One wave per pixel, as the forward: pass 1 over the channels forms
+// S = q k^T and dP = go v^T (two 8 x 8 tables per lane, reduced over the wave), the softmax and its gradient
+// dS = scale * P o (dP - rowsum(P o dP)) are per lane; pass 2 writes dq = dS k, dk = dS^T q, dv = P^T go.
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                                const T* __restrict__ v, const T* __restrict__ go, long long P,
+                                                                int Tn, long long S, int C, float scale, T* __restrict__ gq,
+                                                                T* __restrict__ gk, T* __restrict__ gv) {
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);  // over B*S
+  if (pix >= P) return;
+  const int lane = threadIdx.x & 63;
+  const int nv = C >> 3;
+  const long long b = pix / S, s = pix - b * S;
+  const long long base = (b * Tn * S + s) * C, tstride = S * C;
+  float sc[8][8], dp[8][8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sc[i][j] = dp[i][j] = 0.f;
+  for (int vv = lane; vv < nv; vv += 64) {
+    float qf[8][8], gf[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < Tn) {
+        ld8<T>(q + base + i * tstride + vv * 8, qf[i]);
+        ld8<T>(go + base + i * tstride + vv * 8, gf[i]);
+      }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < Tn) {
+        float kf[8], vf[8];
+        ld8<T>(k + base + j * tstride + vv * 8, kf);
+        ld8<T>(v + base + j * tstride + vv * 8, vf);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < Tn) {
+            float d1 = 0.f, d2 = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              d1 += qf[i][e] * kf[e];
+              d2 += gf[i][e] * vf[e];
+            }
+            sc[i][j] += d1;
+            dp[i][j] += d2;
+          }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float x = sc[i][j], y = dp[i][j];
+#pragma unroll
+      for (int off = 32; off; off >>= 1) {
+        x += __shfl_xor(x, off);
+        y += __shfl_xor(y, off);
+      }
+      sc[i][j] = x * scale;
+      dp[i][j] = y;
+    }
+  // P (as the forward computes it), then dS in place of dp
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (i < Tn) {
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < Tn) mx = fmaxf(mx, sc[i][j]);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (j < Tn) {
+          sc[i][j] = __expf(sc[i][j] - mx);
+          sum += sc[i][j];
+        }
+      const float inv = 1.0f / sum;
+      float dot = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sc[i][j] = (j < Tn) ? sc[i][j] * inv : 0.f;
+        dot += sc[i][j] * dp[i][j];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dp[i][j] = (j < Tn) ? scale * sc[i][j] * (dp[i][j] - dot) : 0.f;
+    }
+  for (int vv = lane; vv < nv; vv += 64) {
+    float qf[8][8], gf[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < Tn) {
+        ld8<T>(q + base + i * tstride + vv * 8, qf[i]);
+        ld8<T>(go + base + i * tstride + vv * 8, gf[i]);
+      }
+    float dq[8][8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dq[i][e] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (j < Tn) {
+        float kf[8], dk[8], dv[8];
+        ld8<T>(k + base + j * tstride + vv * 8, kf);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dk[e] = dv[e] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          if (i < Tn) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              dq[i][e] += dp[i][j] * kf[e];
+              dk[e] += dp[i][j] * qf[i][e];
+              dv[e] += sc[i][j] * gf[i][e];
+            }
+          }
+        st8<T>(gk + base + j * tstride + vv * 8, dk);
+        st8<T>(gv + base + j * tstride + vv * 8, dv);
+      }
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (i < Tn) st8<T>(gq + base + i * tstride + vv * 8, dq[i]);
+  }
+}
+
 }  // namespace cvvae
 
 using namespace cvvae;
@@ -555,6 +682,27 @@ int cvvae_pad_fold(int32_t dtype, const void* gp, int32_t B, int32_t T, int32_t 
     default: return CVVAE_EINVAL;
   }
 #undef CVVAE_FOLD
+  return (int)hipGetLastError();
+}
+
+int cvvae_temporal_attention_bwd(int32_t dtype, const void* q, const void* k, const void* v, const void* go, int32_t B, int32_t Tn,
+                                 int64_t S, int32_t C, void* gq, void* gk, void* gv, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!q || !k || !v || !go || !gq || !gk || !gv || B <= 0 || Tn <= 0 || S <= 0 || C <= 0 || C % 8) return CVVAE_EINVAL;
+  if (Tn > 8) return CVVAE_EUNSUPPORTED;  // (the windows of the reference's wrapper give T' <= 5; longer sequences: not built)
+  const long long P = (long long)B * S;
+  const float scale = 1.0f / sqrtf((float)C);
+  const unsigned grid = (unsigned)((P + 3) / 4);
+#define CVVAE_TAB(TY)                                                                                                          \
+  hipLaunchKernelGGL(temporal_attn_bwd_kernel<TY>, dim3(grid), dim3(256), 0, stream, (const TY*)q, (const TY*)k, (const TY*)v, \
+                     (const TY*)go, P, Tn, (long long)S, C, scale, (TY*)gq, (TY*)gk, (TY*)gv)
+  switch (dtype) {
+    case CVVAE_BF16: CVVAE_TAB(__bf16); break;
+    case CVVAE_F16: CVVAE_TAB(_Float16); break;
+    case CVVAE_F32: CVVAE_TAB(float); break;
+    default: return CVVAE_EINVAL;
+  }
+#undef CVVAE_TAB
   return (int)hipGetLastError();
 }
 

@@ -813,21 +813,23 @@ def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list]
                     out_mode=L.OUT_NCDHW)
 
 
-def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str, xp=None):
+def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str, xp=None, tape: Optional[list] = None):
     """MemoryEfficientAttnVideoBlock.forward, vae_models.py:619-629: spatial attention without residual, then over T
     per pixel: LayerNorm -> q_t,k_t,v_t -> attention -> proj_out_t; one residual.  Stays NDHWC throughout.
     Returns (out, GroupNorm partials of out)."""
-    h = spatial_attention(wc, x, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, False, xp=xp)
+    h = spatial_attention(wc, x, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-5, False, xp=xp, tape=tape)
     n = ops.layernorm(h, *wc.norm(a + ".norm_t"), 1e-5)
     q = conv1x1(wc, n, a + ".q_t")
     k = conv1x1(wc, n, a + ".k_t")
     v = conv1x1(wc, n, a + ".v_t")
     o = ops.temporal_attention(q, k, v)
+    if tape is not None:  # (after the spatial part's own entry: the backward walks the tape in reverse)
+        tape.append(dict(op="attn_t", pre=a, h=h, n=n, q=q, k=k, v=v, o=o))
     return conv1x1(wc, o, a + ".proj_out_t", residual=x, gn_out=G32)
 
 
-def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
-    """Decoder.forward, vae_models.py:960-1002."""
+def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
+    """Decoder.forward, vae_models.py:960-1002.  tape: see sd3_decoder."""
     dtype = wc.m.get_parameter("conv_in.weight").dtype
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
@@ -835,16 +837,22 @@ def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     zin = z.shape[1]
     cpad = ops.round_up(zin, 32 if (z.shape[2] == 1 and fold_t1()) else 16)
     h = ops.ncdhw_to_ndhwc(z, cpad, dtype)
+    if tape is not None:
+        tape.append(dict(op="dec_in", x=h, pad=pad, mode_t=mt, mode_hw=mhw, zin=zin))
     h, hp = conv3(wc, h, "conv_in", cin_pad=cpad, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw,
                      gn_out=G32)
-    h, hp = v3_resnet(wc, h, hp, "mid.block_1", causal)
-    h, hp = v3_attn_spatial_temporal(wc, h, "mid.attn_1", xp=hp)
-    h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal)
+    h, hp = v3_resnet(wc, h, hp, "mid.block_1", causal, tape=tape)
+    h, hp = v3_attn_spatial_temporal(wc, h, "mid.attn_1", xp=hp, tape=tape)
+    h, hp = v3_resnet(wc, h, hp, "mid.block_2", causal, tape=tape)
     for lvl in reversed(range(nlev)):
         for j in range(cfg["num_res_blocks"] + 1):
-            h, hp = v3_resnet(wc, h, hp, f"up.{lvl}.block.{j}", causal)
+            h, hp = v3_resnet(wc, h, hp, f"up.{lvl}.block.{j}", causal, tape=tape)
         if lvl != 0:  # Upsample3D vae_models.py:214-235 (built non-causal, :936): zero pad W,H, replicate T (1,1)
             up_time = lvl % 2 == 1
+            if tape is not None:
+                tape.append(dict(op="up3d", pre=f"up.{lvl}.upsample.conv", x=h, pad=P1, mode_t=REP, mode_hw=ZERO, up_time=up_time))
             h, hp = upsample_conv(wc, h, f"up.{lvl}.upsample.conv", P1, REP, ZERO, up_time)
     g = _norm(wc, h, hp, "norm_out", 1e-5)
+    if tape is not None:
+        tape.append(dict(op="out3d", x=h, xp=hp, g=g, pad=pad, mode_t=mt, mode_hw=mhw, eps=1e-5, norm="norm_out"))
     return decoder_conv_out(wc, h, g, pad, mt, mhw, u8=bool(cfg.get("u8_out")))

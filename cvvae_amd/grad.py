@@ -69,7 +69,8 @@ def _linear_grads(wc: WeightCache, grads: dict, pre: str, a: torch.Tensor, g: to
         grads[pre + ".bias"] = ops.bias_grad(g5.contiguous(), cout=w.shape[0])
 
 
-def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Optional[dict] = None) -> torch.Tensor:
+def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Optional[dict] = None,
+                       add_extra: Optional[torch.Tensor] = None) -> torch.Tensor:
     """engine.spatial_attention: out = x + proj(softmax(q k^T / sqrt(C)) v), q,k,v = linear(GroupNorm(x)) per frame.  g = dL/dout.
     grads: a dict that receives the block's PARAMETER gradients (training the network itself, grad3d.py); None = frozen module."""
     x, qq, kk, vv, p = e["x"], e["qq"], e["kk"], e["vv"], e["p"]
@@ -107,7 +108,8 @@ def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Optiona
         _linear_grads(wc, grads, v, n, g_v)
         dg, db = ops.gn_bwd_params(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, per_frame=True)
         grads[norm + ".weight"], grads[norm + ".bias"] = dg, db
-    return ops.gn_bwd_input(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, add=g if e["residual"] else None,
+    # (add_extra: a block without its own residual -- vae3d's spatial-temporal attention -- passes the gradient of the outer one)
+    return ops.gn_bwd_input(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, add=g if e["residual"] else add_extra,
                             per_frame=True)
 
 

@@ -26,8 +26,9 @@ so `loss(x, decoder(encoder(x)), constraint_decoder(z)).backward()` fills `<net>
 for a module in train() mode under grad mode).  Gradients are carried in the module's dtype with fp32 accumulation inside every
 kernel; parameter gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  The walker takes every layer's
 padding, GroupNorm eps and names from the tape, so the vae3d (SD2.1-compatible) family's ENCODER (vae_models.py:790-823: zero H / W
-padding, asymmetric Downsample3D pads, eps 1e-5) trains through it too.  Not built yet: the vae3d DECODER's backward (its
-MemoryEfficientAttnVideoBlock needs a temporal-attention and a LayerNorm backward), spatial tiling / temporal windows under autograd (one window, one tile per call: the training crops of the
+padding, asymmetric Downsample3D pads, eps 1e-5) trains through it too, and so does its DECODER (vae_models.py:960-1002): the temporal half of MemoryEfficientAttnVideoBlock
+has its own backward kernel (`cvvae_temporal_attention_bwd`), its LayerNorm runs on the GroupNorm kernels (one group, rows = tokens).
+Not built yet: spatial tiling / temporal windows under autograd (one window, one tile per call: the training crops of the
 reference's configs fit one).
 """
 from typing import Dict, List, Optional, Tuple
@@ -139,6 +140,25 @@ def sd3_upsample_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict
     return ops.upsample2x_sum(gup.view(B * T, 1, 2 * H, 2 * W, C)).view(B, T, H, W, C)
 
 
+def temporal_attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[str, torch.Tensor]) -> torch.Tensor:
+    """the temporal half of MemoryEfficientAttnVideoBlock (vae_models.py:573-587, 619-629): out = x + proj_out_t(attention_t(q_t(n),
+    k_t(n), v_t(n))), n = LayerNorm(h), h = the spatial attention's output.  g = dL/dout -> dL/dh (the outer residual's gradient g is
+    added by the caller after the spatial half)."""
+    a, h, n = e["pre"], e["h"], e["n"]
+    B, T, H, W, C = h.shape
+    flat = lambda t: t.view(B, 1, 1, -1, t.shape[-1])  # noqa: E731
+    grad._linear_grads(wc, grads, a + ".proj_out_t", flat(e["o"]), flat(g))
+    g_o = grad._dgrad1x1(wc, g, a + ".proj_out_t")
+    g_q, g_k, g_v = ops.temporal_attention_bwd(e["q"], e["k"], e["v"], g_o)
+    g_n = None
+    for name, gg in ((".q_t", g_q), (".k_t", g_k), (".v_t", g_v)):
+        grad._linear_grads(wc, grads, a + name, flat(n), flat(gg))
+        g_n = grad._dgrad1x1(wc, gg, a + name, residual=g_n)
+    g_h, dg, db = ops.layernorm_bwd(h, g_n, *wc.norm(a + ".norm_t"), 1e-5)
+    grads[a + ".norm_t.weight"], grads[a + ".norm_t.bias"] = dg, db
+    return g_h
+
+
 def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False):
     """gy = dL/d(output) (NCDHW) of engine.sd3_encoder / engine.sd3_decoder run with `tape` -> (dL/d(input) NCDHW or None,
     {parameter name: fp32 gradient})."""
@@ -159,11 +179,15 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
     grads[last["norm"] + ".weight"], grads[last["norm"] + ".bias"] = ops.gn_bwd_params(x, g, tabs, *no, silu=True)
     g = ops.gn_bwd_input(x, g, tabs, *no, silu=True)
     gx = None
+    outer = None  # gradient of the outer residual of a spatial-temporal attention block, added after its spatial half
     for e in reversed(tape[:-1]):
         if e["op"] == "resnet3d":
             g = sd3_resnet_backward(wc, g, e, grads)
+        elif e["op"] == "attn_t":
+            outer, g = g, temporal_attention_backward(wc, g, e, grads)
         elif e["op"] == "attn":
-            g = grad.attention_backward(wc, g, e, grads)
+            g = grad.attention_backward(wc, g, e, grads, add_extra=outer)
+            outer = None
         elif e["op"] == "down3d":
             xin = e["x"]
             _conv_param_grads(wc, grads, e["pre"], xin, g, K333, stride=e["stride"], pad=e["pad"], pad_mode_t=e["mode_t"],

@@ -262,6 +262,7 @@ class Encoder(_Net):
 
 class Decoder(_Net):
     _program = staticmethod(engine.v3_decoder)
+    _trainable = True
 
     def __init__(self, ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4, causal=False, **_):
         super().__init__()

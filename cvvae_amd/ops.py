@@ -696,6 +696,34 @@ def temporal_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> tor
     return out
 
 
+def temporal_attention_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, go: torch.Tensor):
+    """gradients (gq, gk, gv) of temporal_attention(q, k, v) given go = dL/d(out); all NDHWC [B,T,H,W,C], T <= 8"""
+    lib = L.load()
+    _need_gpu(q)
+    assert q.dim() == 5 and all(t.is_contiguous() and t.shape == q.shape and t.dtype == q.dtype for t in (q, k, v, go))
+    B, T, H, W, C = q.shape
+    gq, gk, gv = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+    L.check(lib.cvvae_temporal_attention_bwd(_dt(q.dtype), q.data_ptr(), k.data_ptr(), v.data_ptr(), go.data_ptr(), B, T, H * W, C,
+                                             gq.data_ptr(), gk.data_ptr(), gv.data_ptr(), _stream(q)), "cvvae_temporal_attention_bwd")
+    return gq, gk, gv
+
+
+def layernorm_bwd(x: torch.Tensor, gy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
+    """backward of layernorm(x) over the last axis: (dL/dx, d gamma, d beta).  A LayerNorm over C is a one-group GroupNorm whose
+    rows are the tokens, so this is gn_stats + gn_bwd_input + gn_bwd_params on the [tokens,1,1,1,C] view (tokens <= 65535: the
+    kernels' grid y; the temporal attention of the vae3d decoder sits at latent resolution)."""
+    C = x.shape[-1]
+    n = x.numel() // C
+    assert x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape and n <= 65535, (tuple(x.shape), n)
+    x5, g5 = x.view(n, 1, 1, 1, C), gy.view(n, 1, 1, 1, C)
+    one = torch.ones(C, dtype=torch.float32, device=x.device)
+    zero = torch.zeros(C, dtype=torch.float32, device=x.device)
+    tabs = gn_stats(x5, one, zero, eps, groups=1)
+    gx = gn_bwd_input(x5, g5, tabs, gamma, beta, silu=False, groups=1)
+    dg, db = gn_bwd_params(x5, g5, tabs, gamma, beta, silu=False)
+    return gx.view(x.shape), dg, db
+
+
 def ncdhw_to_ndhwc(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:
     """x: [B,C,T,H,W] (fp16/bf16/fp32) -> [B,T,H,W,cpad] `dtype`, pad channels zero."""
     lib = L.load()

@@ -342,6 +342,15 @@ int cvvae_channel_sums(int32_t dtype, const void* x, const void* g, int64_t g_pi
                        float* sum2, void* workspace, void* stream);
 
 /*
+ * Backward of cvvae_temporal_attention (MemoryEfficientAttnVideoBlock.attention_t, models/vae_models.py:573-587; the vae3d decoder's
+ * mid block): given go = dL/d(out), the gradients of q, k, v (all NDHWC [B][T][S pixels][C] of `dtype`), per pixel over its T <= 8
+ * frames: dS = scale * P o (dP - rowsum(P o dP)) with P = softmax(q k^T * scale), dP = go v^T, scale = C^-1/2;
+ * gq = dS k, gk = dS^T q, gv = P^T go.  Replaces aten::_scaled_dot_product_attention's backward.  T > 8: CVVAE_EUNSUPPORTED.
+ */
+int cvvae_temporal_attention_bwd(int32_t dtype, const void* q, const void* k, const void* v, const void* go, int32_t B, int32_t T,
+                                 int64_t S, int32_t C, void* gq, void* gk, void* gv, void* stream);
+
+/*
  * Adjoint of the padding in front of a convolution (aten::replication_pad3d_backward / constant_pad_nd's slice): gp is the gradient
  * w.r.t. the PADDED input, NDHWC [B][T + pad_t_front + pad_t_back][H + 2 pad_h][W + 2 pad_w][C]; out [B][T][H][W][C] receives, per
  * element, the sum of gp over every padded position the forward's coordinate map sends there (replicate: border elements collect

@@ -390,6 +390,23 @@ def pad_fold(gp, pad_t, pad_hw, pad_mode_t, pad_mode_hw, add=None):
     return out.contiguous().to(gp.dtype)
 
 
+def temporal_attention_bwd(q, k, v, go):
+    B, T, H, W, C = q.shape
+    t = [a.float().permute(0, 2, 3, 1, 4).reshape(-1, T, C).clone().requires_grad_(True) for a in (q, k, v)]
+    with torch.enable_grad():
+        p = torch.softmax(t[0] @ t[1].transpose(1, 2) * (C ** -0.5), -1)
+        (p @ t[2] * go.float().permute(0, 2, 3, 1, 4).reshape(-1, T, C)).sum().backward()
+    return tuple(a.grad.reshape(B, H, W, T, C).permute(0, 3, 1, 2, 4).contiguous().to(q.dtype) for a in t)
+
+
+def layernorm_bwd(x, gy, gamma, beta, eps):
+    xr = x.float().clone().requires_grad_(True)
+    g, b = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    with torch.enable_grad():
+        (F.layer_norm(xr, (x.shape[-1],), g, b, eps) * gy.float()).sum().backward()
+    return xr.grad.to(x.dtype), g.grad, b.grad
+
+
 def softmax_bwd_rows(p, gp, n_valid, alpha, ld_o=None):
     rows, ld_p = p.shape
     out = torch.zeros(rows, ld_p if ld_o is None else ld_o, dtype=p.dtype)
@@ -406,7 +423,7 @@ def upsample2x_sum(g):
 _NAMES = ["ncdhw_to_rowpack", "ndhwc_to_rowpack", "pack_weight_rowpack", "pack_weight_tapsn", "conv_out_gather", "pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
           "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "attention_d512", "temporal_attention", "ncdhw_to_ndhwc",
           "ndhwc_to_ncdhw", "blend_", "resize_frames_u8", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum",
-          "conv_wgrad", "bias_grad", "gn_bwd_params", "pad_fold"]
+          "conv_wgrad", "bias_grad", "gn_bwd_params", "pad_fold", "temporal_attention_bwd", "layernorm_bwd"]
 
 
 @contextlib.contextmanager

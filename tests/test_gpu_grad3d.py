@@ -128,6 +128,33 @@ def test_pad_fold_is_the_adjoint_of_the_padding(dtype, pad_t, mode):
     assert rel(got, ref) <= {torch.float32: 1e-6, torch.float16: 1e-3, torch.bfloat16: 8e-3}[dtype]
 
 
+@pytest.mark.parametrize("dtype", DT)
+def test_temporal_attention_and_layernorm_backward(dtype):
+    """cvvae_temporal_attention_bwd (per pixel over T <= 8 frames) and the LayerNorm backward on the GroupNorm kernels (one group,
+    rows = tokens) against autograd"""
+    from cvvae_amd import ops
+    torch.manual_seed(9)
+    tol = {torch.float32: 2e-5, torch.float16: 3e-3, torch.bfloat16: 2e-2}[dtype]
+    for (B, T, H, W, C) in [(1, 5, 6, 7, 512), (2, 8, 3, 4, 128), (1, 1, 4, 4, 256)]:
+        q, k, v, go = [torch.randn(B, T, H, W, C).to(dtype) for _ in range(4)]
+        t = [a.float().permute(0, 2, 3, 1, 4).reshape(-1, T, C).clone().requires_grad_(True) for a in (q, k, v)]
+        p = torch.softmax(t[0] @ t[1].transpose(1, 2) * (C ** -0.5), -1)
+        (p @ t[2] * go.float().permute(0, 2, 3, 1, 4).reshape(-1, T, C)).sum().backward()
+        ref = [a.grad.reshape(B, H, W, T, C).permute(0, 3, 1, 2, 4) for a in t]
+        got = ops.temporal_attention_bwd(q.cuda(), k.cuda(), v.cuda(), go.cuda())
+        e = [rel(a, b) for a, b in zip(got, ref)]
+        _log(f"[temporal attention bwd {str(dtype)[6:]} T{T} {H}x{W} C{C}] gq {e[0]:.2e} gk {e[1]:.2e} gv {e[2]:.2e}")
+        assert max(e) <= tol, e
+        x = (torch.randn(B, T, H, W, C) * 1.3 + 0.5).to(dtype)
+        gamma, beta = (torch.randn(C) * 0.4 + 1.0).requires_grad_(True), (torch.randn(C) * 0.2).requires_grad_(True)
+        xr = x.float().clone().requires_grad_(True)
+        (F.layer_norm(xr, (C,), gamma, beta, 1e-5) * go.float()).sum().backward()
+        gx, dg, db = ops.layernorm_bwd(x.cuda(), go.cuda(), gamma.detach().cuda(), beta.detach().cuda(), 1e-5)
+        e = (rel(gx, xr.grad), rel(dg, gamma.grad), rel(db, beta.grad))
+        _log(f"[layernorm bwd {str(dtype)[6:]} tokens {B * T * H * W} C{C}] gx {e[0]:.2e} d gamma {e[1]:.2e} d beta {e[2]:.2e}")
+        assert e[0] <= tol and max(e[1:]) <= 2e-4, e
+
+
 SMALL = dict(block_out_channels=[128, 256, 512], layers_per_block=1)
 
 
@@ -231,6 +258,36 @@ def test_vae3d_encoder_backward_vs_autograd_of_the_oracle(dtype):
     _log(f"[vae3d encoder backward {str(dtype)[6:]}] forward rel {rel(ya, yr):.2e}; dL/dx rel {e_x:.2e}; parameters: worst {errs[0][0]:.2e} "
          f"({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e} ({len(names)} tensors)")
     assert e_x <= NET_IN_TOL[dtype], e_x
+    assert errs[0][0] <= NET_W_TOL[dtype], errs[:5]
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_vae3d_decoder_backward_vs_autograd_of_the_oracle(dtype):
+    """the SD2.1-compatible family's Decoder (vae_models.py:960-1002): mid block with the spatial-temporal attention block
+    (LayerNorm + per-pixel attention over time, one outer residual), Upsample3D with zero H / W padding in both kinds"""
+    import cvvae_amd
+    over = dict(ch=128, ch_mult=(1, 2, 4), num_res_blocks=1)
+    m = cvvae_amd.CVVAEModel(**over)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 10)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(dtype).cuda()
+    dec = m.decoder.train()
+    ref_sd = {k: v.to(dtype).float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    z = seeded_input((1, 4, 3, 8, 8), 15).to(dtype)
+    zr = z.float().clone().requires_grad_(True)
+    yr = O.v3_decoder(zr, ref_sd, dict(over))
+    cot = seeded_input(tuple(yr.shape), 7).to(dtype)
+    (yr * cot.float()).sum().backward()
+    za = z.cuda().requires_grad_(True)
+    ya = dec(za)
+    (ya.float() * cot.cuda().float()).sum().backward()
+    e_z = rel(za.grad, zr.grad)
+    names = [n for n, _ in dec.named_parameters()]
+    scale = max(float(ref_sd["decoder." + n].grad.norm()) for n in names)
+    errs = sorted(((rel(p.grad, ref_sd["decoder." + n].grad, 1e-3 * scale), n) for n, p in dec.named_parameters()), reverse=True)
+    _log(f"[vae3d decoder backward {str(dtype)[6:]}] forward rel {rel(ya, yr):.2e}; dL/dz rel {e_z:.2e}; parameters: worst {errs[0][0]:.2e} "
+         f"({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e} ({len(names)} tensors)")
+    assert e_z <= NET_IN_TOL[dtype], e_z
     assert errs[0][0] <= NET_W_TOL[dtype], errs[:5]
 
 

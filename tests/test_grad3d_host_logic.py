@@ -126,5 +126,33 @@ def test_vae3d_encoder_backward_wiring(shape, causal):
         for n, p in enc.named_parameters():
             assert p.grad is not None and p.grad.shape == p.shape, n
             assert _rel(p.grad, ref_sd["encoder." + n].grad, 1e-4 * scale) < 2e-4, (n, _rel(p.grad, ref_sd["encoder." + n].grad))
-        # the decoder of this family has no backward yet: train() + grad mode stays the inference pass
-        assert not getattr(type(m.decoder), "_trainable", False)
+
+
+@pytest.mark.parametrize("zshape", [(1, 4, 3, 4, 6), (2, 4, 1, 4, 4)])
+def test_vae3d_decoder_backward_wiring(zshape):
+    """the SD2.1-compatible family's Decoder (vae_models.py:960-1002): the spatial-temporal attention block of its mid block (no
+    inner residual; LayerNorm + per-pixel attention over time), Upsample3D with zero H / W padding in both kinds, norm_out"""
+    import cvvae_amd
+    over = dict(ch=128, ch_mult=(1, 2, 2), num_res_blocks=1)
+    m = cvvae_amd.CVVAEModel(**over)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 10)
+    m.load_state_dict(sd, strict=True)
+    dec = m.decoder
+    ref_sd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    z = seeded_input(zshape, 15)
+    zr = z.clone().requires_grad_(True)
+    yr = O.v3_decoder(zr, ref_sd, dict(over))
+    cot = seeded_input(tuple(yr.shape), 7)
+    (yr * cot).sum().backward()
+    with emu_ops.patched(whole_model=True):
+        dec.train()
+        za = z.clone().requires_grad_(True)
+        ya = dec(za)
+        assert ya.requires_grad and torch.allclose(ya.detach(), yr.detach(), rtol=1e-4, atol=1e-5), float((ya - yr).abs().max())
+        (ya * cot).sum().backward()
+        assert _rel(za.grad, zr.grad) < 1e-4, _rel(za.grad, zr.grad)
+        names = [n for n, _ in dec.named_parameters()]
+        scale = max(float(ref_sd["decoder." + n].grad.norm()) for n in names)
+        for n, p in dec.named_parameters():
+            assert p.grad is not None and p.grad.shape == p.shape, n
+            assert _rel(p.grad, ref_sd["decoder." + n].grad, 1e-4 * scale) < 2e-4, (n, _rel(p.grad, ref_sd["decoder." + n].grad))
