@@ -11,8 +11,9 @@
 //   * workgroup = 8 waves; tile = 128 output channels x 64 input channels x the KH*KW spatial taps of ONE time tap
 //     (blockIdx.z = dt): 4 x 2 x 9 accumulator fragments of 32 x 32, nine per wave (144 registers);
 //   * K panel = KP consecutive output pixels of one output row (b, t, y).  Staging: ONE task per thread and panel -- the input
-//     pixels under 8 consecutive output pixels x 8 channels (7 sW + kW sixteen-byte global loads; a wave's lanes cover whole
-//     128-byte lines), whose 8 x 8 (pixel, channel) block is transposed IN REGISTERS (static indices) and written as 16-byte rows
+//     pixels under 8 consecutive output pixels x 4 channels of a (7 sW + kW eight-byte global loads) or 8 pixels x 8 channels of
+//     gy (sixteen-byte loads): 384 + 128 tasks = every thread -- whose (pixel, channel) block is transposed IN REGISTERS (static
+//     indices) and written as 16-byte rows
 //     into CHANNEL-major LDS copies  GS[co][k]  and  XS[dy][dx][ci][k] = a[.., (x0+k)*sW + dx - pw][ci]  -- one copy per kW tap, so
 //     that every MFMA operand is an ALIGNED ds_read_b128 of 8 consecutive k (row pitch KP*2+16 bytes: conflict-free for the reads
 //     and for the 16-byte writes); strides and both padding flavours live in the staging's coordinate map.  (The first version
@@ -69,8 +70,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   constexpr int XS_BYTES = NSP * CI * ROWP, GS_BYTES = CO * ROWP;
   constexpr int KB = KP / 8;              // 8-pixel k blocks per panel
   constexpr int NL = 7 * SW + KHW;        // input pixels one x task loads: the 8 outputs' taps along W
-  constexpr int CH = XP ? 4 : 8;          // channels per staging task = one 16-byte load per pixel (8 x 16 bit, or 4 floats)
-  constexpr int NCX = CI / CH, NCG = CO / CH;       // channel groups of the x / g tile
+  // channels per staging task.  x tasks take 4 (one 8-byte load per pixel for 16-bit models, 16 bytes of floats for fp32 ones): with 3
+  // input rows that makes 384 x tasks + 128 g tasks (8 channels, 16-byte loads) = one task for EVERY thread of the workgroup
+  // (8-channel x tasks left three of the eight waves idle while the others staged)
+  constexpr int CHX = 4, CHG = XP ? 4 : 8;
+  constexpr int NCX = CI / CHX, NCG = CO / CHG;       // channel groups of the x / g tile
   constexpr int NXT = KHW * KB * NCX, NGT = KB * NCG;  // staging tasks per panel: x (dy, k block, channel group), g (k block, group)
   static_assert(NXT + NGT <= 512, "one staging task per thread");
   static_assert(NPART * (XS_BYTES + GS_BYTES) <= 160 * 1024, "LDS budget");
@@ -98,13 +102,29 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
   // ---- staging: ONE task per thread and panel.  Threads [0, NXT): x task (dy, k block kb, channel group): the NL input pixels
-  //      under the 8 output pixels of the block, CH channels each (one 16-byte load per pixel; consecutive lanes = consecutive
-  //      channel groups of a pixel, i.e. whole 128-byte lines); the 8 x CH (pixel, channel) block is transposed IN REGISTERS (static
-  //      indices: free) and written as 16-byte rows  XS[dy][dx][channel][8 consecutive k]  -- one row per channel and kW tap.
+  //      under the 8 output pixels of the block, CHX channels each; the 8 x CH (pixel, channel) block is transposed IN REGISTERS
+  //      (static indices: free) and written as 16-byte rows  XS[dy][dx][channel][8 consecutive k]  -- one row per channel and kW tap.
   //      Threads [NXT, NXT + NGT): g task (k block, channel group) the same way into GS[channel][k].
+  //      Task -> lane order: 16 consecutive lanes are 4 k blocks x 4 channel groups (4-channel tasks) or 8 k blocks x 2 groups
+  //      (8-channel tasks) -- rows 4 (8) apart are 16 (32) banks apart at this row pitch, so the 16 sixteen-byte writes of a quarter
+  //      wave tile all 64 banks (channel-group-fastest order was 4- to 8-way conflicted).
   const bool is_x = tid < NXT, is_g = tid >= NXT && tid < NXT + NGT;
-  const int xt_cg = tid % NCX, xt_kb = (tid / NCX) % KB, xt_dy = (tid / NCX) / KB;
-  const int gt = tid - NXT, gt_cg = gt % NCG, gt_kb = gt / NCG;
+  auto decode = [](int t, int ch, int nc, int& kb, int& cg, int& rest) {
+    const int kl = ch == 4 ? 2 : 3, cl = ch == 4 ? 2 : 1;   // low bits of kb / cg inside a 16-lane group
+    const int kbl = t & ((1 << kl) - 1), cgl = (t >> kl) & ((1 << cl) - 1);
+    int r = t >> 4;
+    const int nkh = KB >> kl > 0 ? KB >> kl : 1, nch = nc >> cl;
+    const int kbh = r % nkh;
+    r /= nkh;
+    kb = kbh * (1 << kl) + kbl;
+    cg = (r % nch) * (1 << cl) + cgl;
+    rest = r / nch;
+  };
+  static_assert(KB >= 8 || (KB == 4 && CHG == 4), "k blocks per panel vs the lane order of the 8-channel tasks");
+  int xt_kb, xt_cg, xt_dy, gt_kb, gt_cg, gt_rest;
+  decode(tid, CHX, NCX, xt_kb, xt_cg, xt_dy);
+  decode(tid - NXT, CHG, NCG, gt_kb, gt_cg, gt_rest);
+  (void)gt_rest;
   constexpr int NREG = NL > 8 ? NL : 8;
   uint4 raw[NREG];
   auto load_panel = [&](long long pi) {
@@ -115,7 +135,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
       bool zrow = false;
       const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zrow);
       const int ys = map_coord(yo * p.sH + xt_dy - p.ph, p.Hi, p.mode_hw, zrow);
-      const int c = ci0 + xt_cg * CH;
+      const int c = ci0 + xt_cg * CHX;
       const TIO* rowp = ap + (((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi * p.a_ps + c;
       const int xb = (x0 + xt_kb * 8) * SW - p.pw;  // unpadded input column of pixel 0 of my block
 #pragma unroll
@@ -123,11 +143,18 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
         bool zero = zrow;
         const int xsrc = map_coord(xb + i, p.Wi, p.mode_hw, zero);
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (!zero && c < p.Cin) r = *reinterpret_cast<const uint4*>(rowp + (long long)xsrc * p.a_ps);
+        if (!zero && c < p.Cin) {
+          if constexpr (XP) {
+            r = *reinterpret_cast<const uint4*>(rowp + (long long)xsrc * p.a_ps);   // 4 floats
+          } else {
+            const uint2 v2 = *reinterpret_cast<const uint2*>(rowp + (long long)xsrc * p.a_ps);  // 4 x 16 bit
+            r = make_uint4(v2.x, v2.y, 0u, 0u);
+          }
+        }
         raw[i] = r;
       }
     } else if (is_g) {
-      const int c = co0 + gt_cg * CH;
+      const int c = co0 + gt_cg * CHG;
       const TIO* rowp = gp + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * p.g_ps + c;
       const int kx = x0 + gt_kb * 8;
 #pragma unroll
@@ -160,9 +187,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
     }
   };
   // pixels first, first + step, ..., first + 7 step of px -> CH channel rows of 8 consecutive k each (16-byte LDS writes)
-  auto put_block = [&](const uint4 (&px)[NREG], int first, int step, char* dst) {
+  auto put_block = [&](auto nch_tag, const uint4 (&px)[NREG], int first, int step, char* dst) {
+    constexpr int NCH = decltype(nch_tag)::value;
 #pragma unroll
-    for (int j = 0; j < CH; ++j) {
+    for (int j = 0; j < NCH; ++j) {
       uint4 o;
       o.x = pair16(px[first], px[first + step], j);
       o.y = pair16(px[first + 2 * step], px[first + 3 * step], j);
@@ -177,15 +205,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
       convert(std::integral_constant<int, NL>{}, hi, lo);
 #pragma unroll
       for (int dx = 0; dx < KHW; ++dx) {
-        char* dst = xs + ((xt_dy * KHW + dx) * CI + xt_cg * CH) * ROWP + xt_kb * 16;
-        put_block(hi, dx, SW, dst);
-        if constexpr (XP) put_block(lo, dx, SW, dst + XS_BYTES);
+        char* dst = xs + ((xt_dy * KHW + dx) * CI + xt_cg * CHX) * ROWP + xt_kb * 16;
+        put_block(std::integral_constant<int, CHX>{}, hi, dx, SW, dst);
+        if constexpr (XP) put_block(std::integral_constant<int, CHX>{}, lo, dx, SW, dst + XS_BYTES);
       }
     } else if (is_g) {
       convert(std::integral_constant<int, 8>{}, hi, lo);
-      char* dst = gs + (gt_cg * CH) * ROWP + gt_kb * 16;
-      put_block(hi, 0, 1, dst);
-      if constexpr (XP) put_block(lo, 0, 1, dst + GS_BYTES);
+      char* dst = gs + (gt_cg * CHG) * ROWP + gt_kb * 16;
+      put_block(std::integral_constant<int, CHG>{}, hi, 0, 1, dst);
+      if constexpr (XP) put_block(std::integral_constant<int, CHG>{}, lo, 0, 1, dst + GS_BYTES);
     }
   };
 
