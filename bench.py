@@ -778,6 +778,16 @@ def main():
             "latent_max_abs_per_batch_item": [float(f"{v:.3e}") for v in r["latent_max_abs_per_batch_item"]],
             "north_star_tolerance": "|delta| <= 1e-3 on latents", "meets_north_star_tolerance": bool(r["latent_max_abs"] <= 1e-3),
         }
+    if rank == 0 and cfg4 and not args.no_parity and os.path.isfile(os.path.join(P.GOLDEN_DIR, "cfg4_sd3_t129_720x1280_enc.npz")):
+        # cfg 4's own fixture: the WHOLE clip's posterior mean (8 windows x 6 blended tiles) from the reference's modules, encode side
+        vae.enable_hip_graphs(False)
+        r = P.measure_encode(vae, "cfg4_sd3_t129_720x1280_enc")
+        out["parity"] = {
+            "against": "tests/golden/cfg4_sd3_t129_720x1280_enc.npz = the reference's own modules, CPU fp32: encode of the whole "
+                       "[1,3,129,720,1280] clip (posterior mean sampled at stride 2), single-process wrapper",
+            "latent_max_abs": float(f"{r['latent_max_abs']:.3e}"), "latent_mean_abs": float(f"{r['latent_mean_abs']:.3e}"),
+            "north_star_tolerance": "|delta| <= 1e-3 on latents", "meets_north_star_tolerance": bool(r["latent_max_abs"] <= 1e-3),
+        }
     if vq is not None:
         del vae
         torch.cuda.empty_cache()

@@ -66,6 +66,8 @@ PROTOTYPES = {
     "cvvae_gn_silu_apply": (_i32, [_i32, _vp, _i32, _i64, _i32, _i64, _vp, _vp, _i32, _vp, _vp]),
     "cvvae_gn_bwd_workspace_bytes": (_i64, [_i32, _i32, _i64]),
     "cvvae_gn_bwd_input": (_i32, [_i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "cvvae_gn_bwd_params_workspace_bytes": (_i64, [_i32, _i32, _i64, _i32]),
+    "cvvae_gn_bwd_input_params": (_i32, [_i32, _vp, _vp, _vp, _i32, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_softmax_bwd_rows": (_i32, [_i32, _vp, _i64, _vp, _i64, _i64, _i32, _f32, _vp, _i64, _vp]),
     "cvvae_upsample2x_sum": (_i32, [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_conv_wgrad_workspace_bytes": (_i64, [ctypes.POINTER(ConvDesc)]),

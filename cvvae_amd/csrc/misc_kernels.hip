@@ -643,11 +643,14 @@ __device__ __forceinline__ void gn_bwd_load_tab(GnBwdTab& t, const float* __rest
   }
 }
 
-template <typename T>
+// PARAMS: also the per-channel sums of the affine gradients  d beta = sum gy act'(a),  d gamma = sum gy act'(a) xh  (the kernel forms
+// gy act'(a) anyway: training the norm costs no extra pass over x and gy), one [C][2] table per (row, split) in `wsp`
+template <typename T, bool PARAMS = false>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict__ x, const T* __restrict__ gy, long long S, int C,
                                                             int G, int nsplit, const float* __restrict__ rs,
                                                             const float* __restrict__ nm, const float* __restrict__ gamma,
-                                                            const float* __restrict__ beta, int silu, float* __restrict__ ws) {
+                                                            const float* __restrict__ beta, int silu, float* __restrict__ ws,
+                                                            float* __restrict__ wsp = nullptr) {
   const int split = blockIdx.x, row = blockIdx.y, tid = threadIdx.x;
   const int cv = C >> 3, ppp = 256 / cv;
   const int myv = tid % cv, mypl = tid / cv;
@@ -658,6 +661,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
   GnBwdTab t;
   gn_bwd_load_tab(t, rs, nm, gamma, beta, row, C, myv * 8);
   float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f};
+  float pb[PARAMS ? 8 : 1], pg[PARAMS ? 8 : 1];
+#pragma unroll
+  for (int j = 0; j < (PARAMS ? 8 : 1); ++j) pb[j] = pg[j] = 0.f;
   const T* xb = x + (long long)row * S * C + myv * 8;
   const T* gb = gy + (long long)row * S * C + myv * 8;
   for (long long px = p0 + mypl; px < p1; px += ppp) {
@@ -668,9 +674,33 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
     for (int j = 0; j < 8; ++j) {
       const float xh = __builtin_fmaf(f[j], t.rs[j], t.nm[j]);
       const float a = __builtin_fmaf(xh, t.ga[j], t.be[j]);
-      const float gh = g[j] * (silu ? silu_grad_f(a) : 1.0f) * t.ga[j];
+      const float gact = g[j] * (silu ? silu_grad_f(a) : 1.0f);
+      const float gh = gact * t.ga[j];
       a1[j >> 2] += gh;
       a2[j >> 2] += gh * xh;
+      if constexpr (PARAMS) {
+        pb[j] += gact;
+        pg[j] += gact * xh;
+      }
+    }
+  }
+  if constexpr (PARAMS) {  // per channel: the pixel lanes of its vector, in index order
+    __shared__ float shp[256][17];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      shp[tid][j] = pb[j];
+      shp[tid][8 + j] = pg[j];
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+      float s1 = 0.f, s2 = 0.f;
+      for (int pl = 0; pl < ppp; ++pl) {
+        s1 += shp[pl * cv + (c >> 3)][c & 7];
+        s2 += shp[pl * cv + (c >> 3)][8 + (c & 7)];
+      }
+      float* o = wsp + (((long long)row * nsplit + split) * C + c) * 2;
+      o[0] = s1;
+      o[1] = s2;
     }
   }
   __shared__ float sh1[256][2], sh2[256][2];
@@ -783,10 +813,45 @@ static inline int gn_bwd_splits(long long S) {  // >= 2048 pixels per split: the
   const long long n = (S + 2047) / 2048;
   return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
 }
+// sum1[c], sum2[c] = sums over `nparts` [C][2] tables (a block = 32 channels x 8 part lanes, parts summed in a fixed order)
+__global__ __launch_bounds__(256) void gn_params_final_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ o1,
+                                                              float* __restrict__ o2) {
+  __shared__ float sh[8][32][2];
+  const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float a1 = 0.f, a2 = 0.f;
+  if (c < C)
+    for (int i = pl; i < nparts; i += 8) {
+      const float2 v = *reinterpret_cast<const float2*>(ws + ((long long)i * C + c) * 2);
+      a1 += v.x;
+      a2 += v.y;
+    }
+  sh[pl][cl][0] = a1;
+  sh[pl][cl][1] = a2;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      s1 += sh[k][cl][0];
+      s2 += sh[k][cl][1];
+    }
+    o1[c] = s1;
+    o2[c] = s2;
+  }
+}
+
 template <typename T>
 static void gn_bwd_launch(const void* x, const void* gy, const void* add, int rows, long long S, int C, int G, const float* rs,
-                          const float* nm, const float* gamma, const float* beta, int silu, void* gx, float* ws, hipStream_t s) {
+                          const float* nm, const float* gamma, const float* beta, int silu, void* gx, float* ws, hipStream_t s,
+                          float* dgamma = nullptr, float* dbeta = nullptr) {
   const int nsplit = gn_bwd_splits(S);
+  if (dgamma) {  // training the norm: the affine sums ride on the reduction pass (tables behind the group sums in the workspace)
+    float* wsp = ws + (long long)rows * nsplit * G * 2;
+    hipLaunchKernelGGL((gn_bwd_reduce_kernel<T, true>), dim3(nsplit, rows), dim3(256), 0, s, (const T*)x, (const T*)gy, S, C, G, nsplit,
+                       rs, nm, gamma, beta, silu, ws, wsp);
+    hipLaunchKernelGGL(gn_params_final_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const float*)wsp, rows * nsplit, C, dbeta, dgamma);
+  } else
   hipLaunchKernelGGL(gn_bwd_reduce_kernel<T>, dim3(nsplit, rows), dim3(256), 0, s, (const T*)x, (const T*)gy, S, C, G, nsplit, rs, nm,
                      gamma, beta, silu, ws);
   long long blocks = (S * (C / 8) + 255) / 256;
@@ -1426,6 +1491,29 @@ int cvvae_gn_finalize_frames(const float* partials, int32_t rows, int32_t frames
 int64_t cvvae_gn_bwd_workspace_bytes(int32_t rows, int32_t groups, int64_t S) {
   if (rows <= 0 || groups <= 0 || S <= 0) return 0;
   return (int64_t)rows * gn_bwd_splits(S) * groups * 2 * (int64_t)sizeof(float);
+}
+
+int64_t cvvae_gn_bwd_params_workspace_bytes(int32_t rows, int32_t groups, int64_t S, int32_t C) {
+  if (rows <= 0 || groups <= 0 || S <= 0 || C <= 0) return 0;
+  return (int64_t)rows * gn_bwd_splits(S) * (groups + C) * 2 * (int64_t)sizeof(float);
+}
+
+int cvvae_gn_bwd_input_params(int32_t dtype, const void* x, const void* gy, const void* add, int32_t rows, int64_t S, int32_t C,
+                              int32_t groups, const float* rstd, const float* nmean, const float* gamma, const float* beta,
+                              int32_t silu, void* gx, float* dgamma, float* dbeta, void* workspace, void* stream) {
+  if (!x || !gy || !gx || !rstd || !nmean || !gamma || !beta || !workspace || !dgamma || !dbeta || rows <= 0 || S <= 0 || C <= 0)
+    return CVVAE_EINVAL;
+  if (groups <= 0 || groups > 64 || C % groups || (C / groups) % 4 || C % 8 || C > 2048 || 256 % (C / 8)) return CVVAE_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == CVVAE_BF16)
+    gn_bwd_launch<__bf16>(x, gy, add, rows, S, C, groups, rstd, nmean, gamma, beta, silu, gx, (float*)workspace, s, dgamma, dbeta);
+  else if (dtype == CVVAE_F16)
+    gn_bwd_launch<_Float16>(x, gy, add, rows, S, C, groups, rstd, nmean, gamma, beta, silu, gx, (float*)workspace, s, dgamma, dbeta);
+  else if (dtype == CVVAE_F32)
+    gn_bwd_launch<float>(x, gy, add, rows, S, C, groups, rstd, nmean, gamma, beta, silu, gx, (float*)workspace, s, dgamma, dbeta);
+  else
+    return CVVAE_EINVAL;
+  CHECK_LAUNCH();
 }
 
 int cvvae_gn_bwd_input(int32_t dtype, const void* x, const void* gy, const void* add, int32_t rows, int64_t S, int32_t C,

@@ -106,9 +106,10 @@ def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Optiona
         _linear_grads(wc, grads, q, n, g_q)
         _linear_grads(wc, grads, k, n, g_k)
         _linear_grads(wc, grads, v, n, g_v)
-        dg, db = ops.gn_bwd_params(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, per_frame=True)
-        grads[norm + ".weight"], grads[norm + ".bias"] = dg, db
-    # (add_extra: a block without its own residual -- vae3d's spatial-temporal attention -- passes the gradient of the outer one)
+        # (add_extra: a block without its own residual -- vae3d's spatial-temporal attention -- passes the gradient of the outer one)
+        gx, grads[norm + ".weight"], grads[norm + ".bias"] = ops.gn_bwd_input_params(
+            x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, add=g if e["residual"] else add_extra, per_frame=True)
+        return gx
     return ops.gn_bwd_input(x, g_n.view(B, T, H, W, C), tabs, *wc.norm(norm), silu=False, add=g if e["residual"] else add_extra,
                             per_frame=True)
 

@@ -97,8 +97,7 @@ def sd3_resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[s
     g_a2 = ops.conv(g, wc.conv_dgrad(pre + ".conv2", K133), pad=P2D, pad_mode_hw=ZERO)
     tabs2 = grad._unit_tabs(wc, h, e["hp"], eps)
     n2 = wc.norm(pre + ".norm2")
-    grads[pre + ".norm2.weight"], grads[pre + ".norm2.bias"] = ops.gn_bwd_params(h, g_a2, tabs2, *n2, silu=True)
-    g_h = ops.gn_bwd_input(h, g_a2, tabs2, *n2, silu=True)
+    g_h, grads[pre + ".norm2.weight"], grads[pre + ".norm2.bias"] = ops.gn_bwd_input_params(h, g_a2, tabs2, *n2, silu=True)
     del g_a2
     # conv1: 3x3x3 over a1 = silu(norm1(x))
     a1 = ops.gn_silu_apply(x, e["g1"])
@@ -114,8 +113,8 @@ def sd3_resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[s
         skip = g
     tabs1 = grad._unit_tabs(wc, x, e["xp"], eps)
     n1 = wc.norm(pre + ".norm1")
-    grads[pre + ".norm1.weight"], grads[pre + ".norm1.bias"] = ops.gn_bwd_params(x, g_a1, tabs1, *n1, silu=True)
-    return ops.gn_bwd_input(x, g_a1, tabs1, *n1, silu=True, add=skip)
+    gx, grads[pre + ".norm1.weight"], grads[pre + ".norm1.bias"] = ops.gn_bwd_input_params(x, g_a1, tabs1, *n1, silu=True, add=skip)
+    return gx
 
 
 def _unshuffle_time(g: torch.Tensor) -> torch.Tensor:
@@ -176,8 +175,7 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
     g = dgrad333(wc, g, "conv_out", pad, mt, mhw, tuple(x.shape[:4]))
     tabs = grad._unit_tabs(wc, x, last["xp"], last["eps"])
     no = wc.norm(last["norm"])
-    grads[last["norm"] + ".weight"], grads[last["norm"] + ".bias"] = ops.gn_bwd_params(x, g, tabs, *no, silu=True)
-    g = ops.gn_bwd_input(x, g, tabs, *no, silu=True)
+    g, grads[last["norm"] + ".weight"], grads[last["norm"] + ".bias"] = ops.gn_bwd_input_params(x, g, tabs, *no, silu=True)
     gx = None
     outer = None  # gradient of the outer residual of a spatial-temporal attention block, added after its spatial half
     for e in reversed(tape[:-1]):

@@ -552,6 +552,30 @@ def gn_bwd_input(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Tensor, to
     return out
 
 
+def gn_bwd_input_params(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Tensor, torch.Tensor], gamma: torch.Tensor,
+                        beta: torch.Tensor, silu: bool, add: Optional[torch.Tensor] = None, per_frame: bool = False,
+                        groups: int = 32) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """gn_bwd_input for a trainable norm: (dL/dx, d gamma, d beta) in one reduction + one apply pass (cvvae_gn_bwd_input_params)"""
+    lib = L.load()
+    _need_gpu(x)
+    assert x.dim() == 5 and x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape and gy.dtype == x.dtype
+    B, T, H, W, C = x.shape
+    rows, S = (B * T, H * W) if per_frame else (B, T * H * W)
+    rs, nm = tabs
+    assert rs.dtype == torch.float32 and tuple(rs.shape) == (rows, C) and rs.is_contiguous() and nm.is_contiguous()
+    if add is not None:
+        assert add.shape == x.shape and add.dtype == x.dtype and add.is_contiguous()
+    out = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device)
+    db = torch.empty(C, dtype=torch.float32, device=x.device)
+    ws = torch.empty(max(int(lib.cvvae_gn_bwd_params_workspace_bytes(rows, groups, S, C)), 16), dtype=torch.uint8, device=x.device)
+    L.check(lib.cvvae_gn_bwd_input_params(_dt(x.dtype), x.data_ptr(), gy.data_ptr(), add.data_ptr() if add is not None else None, rows,
+                                          S, C, groups, rs.data_ptr(), nm.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                          1 if silu else 0, out.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), _stream(x)),
+            "cvvae_gn_bwd_input_params")
+    return out, dg, db
+
+
 def conv_wgrad(a: torch.Tensor, gy: torch.Tensor, k: Tuple[int, int, int], *, stride=(1, 1, 1),
                pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO, cin: Optional[int] = None,
                cout: Optional[int] = None) -> torch.Tensor:

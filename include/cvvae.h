@@ -293,6 +293,17 @@ int cvvae_gn_bwd_input(int32_t dtype, const void* x, const void* gy, const void*
                        void* gx, void* workspace, void* stream);
 
 /*
+ * cvvae_gn_bwd_input_params: cvvae_gn_bwd_input for a TRAINABLE norm -- the same input gradient, plus the affine gradients
+ * dgamma[c] = sum gy act'(a) xh, dbeta[c] = sum gy act'(a) over rows x S (fp32 [C]); the sums ride on the reduction pass of the input
+ * gradient (it forms gy act'(a) anyway: no extra pass over x and gy; cvvae_channel_sums computes the same from scratch).
+ * workspace: cvvae_gn_bwd_params_workspace_bytes(rows, groups, S, C) bytes.
+ */
+int64_t cvvae_gn_bwd_params_workspace_bytes(int32_t rows, int32_t groups, int64_t S, int32_t C);
+int cvvae_gn_bwd_input_params(int32_t dtype, const void* x, const void* gy, const void* add, int32_t rows, int64_t S, int32_t C,
+                              int32_t groups, const float* rstd, const float* nmean, const float* gamma, const float* beta,
+                              int32_t silu, void* gx, float* dgamma, float* dbeta, void* workspace, void* stream);
+
+/*
  * Gradient of the row softmax of the attention blocks (aten::_softmax_backward_data + the score scale):
  * gs[r][j] = alpha * p[r][j] * (gp[r][j] - sum_k p[r][k] * gp[r][k]) for j < n_valid, 0 for n_valid <= j < ld_o.
  * p: probabilities [rows][ld_p] of `dtype` (cvvae_softmax_rows' output), gp: fp32 [rows][ld_g], gs: [rows][ld_o] of `dtype`.

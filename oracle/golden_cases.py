@@ -49,9 +49,13 @@ BIG_CASES = {
 # ENCODE-ONLY fixtures at full size (the training-side latent pre-compute of BASELINE cfg 5: batch-8 T=33 512x512 encode; the
 # fixture is a B = 2 slice of the 8 -- batch items are independent network calls, two of them pin the batch indexing -- with both
 # 17-frame windows of every clip): the posterior mean in full, the log-variance at stride 2 over H and W
-# name -> (family, config overrides, input shape, weight seed, input seed)
+# name -> (family, config overrides, input shape, weight seed, input seed[, stride s of the stored posterior mean over H and W --
+# latent frame t sampled at rows (t % s)::s, columns (3t % s)::s as recon_subsample does; default 1 = in full])
 ENC_CASES = {
     "cfg5slice_sd3_b2_t33_512_enc": ("sd3", {}, (2, 3, 33, 512, 512), 0, 25),
+    # BASELINE cfg 4 WHOLE: T = 129 at 720x1280 = 8 temporal windows x 6 blended spatial tiles (48 encoder calls): the full
+    # window / tile / blend wrapper at the size it was written for
+    "cfg4_sd3_t129_720x1280_enc": ("sd3", {}, (1, 3, 129, 720, 1280), 0, 26, 2),
 }
 
 

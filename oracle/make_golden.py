@@ -115,7 +115,8 @@ def main_big(only=None):
         zc = mnp.shape[1] // 2
         # fixtures stay small: above 4 MB the posterior mean is kept in full and the log-variance at stride 2 over H and W
         mom_kw = dict(moments=mnp) if mnp.nbytes <= (4 << 20) else dict(
-            moments_mean=mnp[:, :zc].copy(), moments_logvar_sub=mnp[:, zc:, :, ::2, ::2].copy(),
+            moments_mean=(mnp[:, :zc].copy() if ms == 1 else recon_subsample(mnp[:, :zc], ms).copy()), mean_stride=np.int64(ms),
+            moments_logvar_sub=(mnp[:, zc:, :, ::2, ::2].copy() if ms == 1 else recon_subsample(mnp[:, zc:], 2 * ms).copy()),
             moments_shape=np.asarray(mnp.shape, dtype=np.int64))
         np.savez_compressed(
             os.path.join(out_dir, name + ".npz"),
@@ -142,7 +143,10 @@ def main_enc(only=None):
     ref = load_reference()
     torch.set_grad_enabled(False)
     out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
-    for name, (family, over, shape, wseed, xseed) in ENC_CASES.items():
+    from oracle.golden_cases import recon_subsample
+    for name, case in ENC_CASES.items():
+        family, over, shape, wseed, xseed = case[:5]
+        ms = case[5] if len(case) > 5 else 1
         if only and name not in only:
             continue
         cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
@@ -157,7 +161,8 @@ def main_enc(only=None):
         wsum = float(sum(v.double().abs().sum() for v in sd.values()))
         np.savez_compressed(
             os.path.join(out_dir, name + ".npz"),
-            moments_mean=mnp[:, :zc].copy(), moments_logvar_sub=mnp[:, zc:, :, ::2, ::2].copy(),
+            moments_mean=(mnp[:, :zc].copy() if ms == 1 else recon_subsample(mnp[:, :zc], ms).copy()), mean_stride=np.int64(ms),
+            moments_logvar_sub=(mnp[:, zc:, :, ::2, ::2].copy() if ms == 1 else recon_subsample(mnp[:, zc:], 2 * ms).copy()),
             moments_shape=np.asarray(mnp.shape, dtype=np.int64),
             moments_mean_f64=np.float64(mnp.astype(np.float64).mean()),
             weight_abs_sum=np.float64(wsum), n_tensors=np.int64(len(sd)),

@@ -97,7 +97,8 @@ def measure_encode(model, name: str, golden_dir: str = GOLDEN_DIR, latents=None)
     """encode-only fixtures (golden_cases.ENC_CASES: BASELINE cfg 5's batch slice) against the reference's `moments`:
     `model.encode(x).latent_dist.parameters` (mean and log-variance), or -- `latents` given: the latent pre-compute entry point
     bench.py times, x -> posterior MODE -- the posterior mean alone."""
-    family, over, shape, wseed, xseed = ENC_CASES[name]
+    family, over, shape, wseed, xseed = ENC_CASES[name][:5]
+    ms = ENC_CASES[name][5] if len(ENC_CASES[name]) > 5 else 1  # stride of the stored mean (per-frame phase: recon_subsample)
     gold = np.load(os.path.join(golden_dir, name + ".npz"))
     x = seeded_input(shape, xseed).to(model.dtype).to(model.device)
     mshape = tuple(int(v) for v in gold["moments_shape"])
@@ -110,8 +111,9 @@ def measure_encode(model, name: str, golden_dir: str = GOLDEN_DIR, latents=None)
         mom = model.encode(x).latent_dist.parameters.float().cpu().numpy()
         assert tuple(mom.shape) == mshape, (mom.shape, mshape)
         mean = mom[:, :zc]
-        dl = np.abs(mom[:, zc:, :, ::2, ::2] - gold["moments_logvar_sub"])
-    dm = np.abs(mean - gold["moments_mean"])
+        lv = mom[:, zc:, :, ::2, ::2] if ms == 1 else recon_subsample(mom[:, zc:], 2 * ms)
+        dl = np.abs(lv - gold["moments_logvar_sub"])
+    dm = np.abs((mean if ms == 1 else recon_subsample(mean, ms)) - gold["moments_mean"])
     out = {"case": name, "shape": list(shape), "latent_max_abs": float(dm.max()), "latent_mean_abs": float(dm.mean()),
            "latent_max_abs_per_batch_item": [float(dm[b].max()) for b in range(dm.shape[0])]}
     if dl is not None:

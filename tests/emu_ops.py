@@ -376,6 +376,11 @@ def gn_bwd_params(x, gy, tabs, gamma, beta, silu, per_frame=False):
     return (ga * xh).sum((0, 1)), ga.sum((0, 1))
 
 
+def gn_bwd_input_params(x, gy, tabs, gamma, beta, silu, add=None, per_frame=False, groups=32):
+    dg, db = gn_bwd_params(x, gy, tabs, gamma, beta, silu, per_frame=per_frame)
+    return gn_bwd_input(x, gy, tabs, gamma, beta, silu, add=add, per_frame=per_frame, groups=groups), dg, db
+
+
 def pad_fold(gp, pad_t, pad_hw, pad_mode_t, pad_mode_hw, add=None):
     """adjoint of _pad3 (cvvae_pad_fold): autograd of the padding itself"""
     B, Tp, Hp, Wp, C = gp.shape
@@ -423,7 +428,7 @@ def upsample2x_sum(g):
 _NAMES = ["ncdhw_to_rowpack", "ndhwc_to_rowpack", "pack_weight_rowpack", "pack_weight_tapsn", "conv_out_gather", "pack_weight", "pack_weight_tfolds", "pack_weight_t1", "pack_weight_upfold", "pack_weight_batched", "gn_stats",
           "gn_finalize", "gn_silu_apply", "conv", "softmax_rows", "transpose", "layernorm", "attention_d512", "temporal_attention", "ncdhw_to_ndhwc",
           "ndhwc_to_ncdhw", "blend_", "resize_frames_u8", "frames_u8_to_ndhwc", "ncdhw_to_frames_u8", "gn_bwd_input", "softmax_bwd_rows", "upsample2x_sum",
-          "conv_wgrad", "bias_grad", "gn_bwd_params", "pad_fold", "temporal_attention_bwd", "layernorm_bwd"]
+          "conv_wgrad", "bias_grad", "gn_bwd_params", "gn_bwd_input_params", "pad_fold", "temporal_attention_bwd", "layernorm_bwd"]
 
 
 @contextlib.contextmanager

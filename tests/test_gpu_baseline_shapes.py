@@ -103,7 +103,7 @@ def test_cfg5_batch_slice_encode_golden(dtype, mode, golden_dir):
     if not os.path.isfile(os.path.join(golden_dir, name + ".npz")):
         pytest.skip(f"fixture {name}.npz not generated")
     from oracle.golden_cases import ENC_CASES
-    family, over, shape, wseed, xseed = ENC_CASES[name]
+    family, over, shape, wseed, xseed = ENC_CASES[name][:5]
     m = _model(family, over, dtype, wseed)
     if mode is not None:
         m.fp32_mode = mode
@@ -127,5 +127,39 @@ def test_cfg5_batch_slice_encode_golden(dtype, mode, golden_dir):
         assert rr["latent_max_abs"] <= t["latent_max"], line
         assert rr["latent_mean_abs"] <= t["latent_mean"], line
     assert r2["latent_max_abs"] == r["latent_max_abs"]  # the pre-compute entry point returns the same posterior mean
+    if dtype == torch.float32:
+        assert r["latent_max_abs"] <= 1.0e-3
+
+
+@pytest.mark.parametrize("dtype,mode", MODES, ids=["float16", "bfloat16", "float32", "float32-fast"])
+def test_cfg4_whole_clip_encode_golden(dtype, mode, golden_dir):
+    """BASELINE cfg 4 WHOLE (T = 129 at 720x1280): all 8 temporal windows x 6 blended spatial tiles of the encode wrapper -- 48
+    encoder calls, the latent-frame drops between windows, both blend directions at full size -- against the reference's own
+    modules (oracle/make_golden.py enc; the posterior mean stored at stride 2 with a per-frame phase).  Bands: cfg 3's reference
+    noise (same tile sizes) with the sqrt(2 ln N) growth of a maximum over 6x more values."""
+    name = "cfg4_sd3_t129_720x1280_enc"
+    if not os.path.isfile(os.path.join(golden_dir, name + ".npz")):
+        pytest.skip(f"fixture {name}.npz not generated")
+    from oracle.golden_cases import ENC_CASES
+    family, over, shape, wseed, xseed = ENC_CASES[name][:5]
+    m = _model(family, over, dtype, wseed)
+    if mode is not None:
+        m.fp32_mode = mode
+    r = P.measure_encode(m, name, golden_dir)
+    if mode is not None:
+        t = TOL_F32[mode]
+    else:
+        e = P.reference_self_noise("cfg3_sd3_t17_512", TAG[dtype], golden_dir)
+        if e is None or "shape" not in e:
+            e = dict(P.REFERENCE_SELF_NOISE[TAG[dtype]])
+            e["latent_max"] *= 1.35
+        t = dict(latent_max=K_MAX * 1.10 * e["latent_max"], latent_mean=K_MEAN * e["latent_mean"])
+    tag = TAG[dtype] + ("q" if mode == "fast" else "")
+    line = (f"{name:28s} {tag:5s} latent max|d| {r['latent_max_abs']:.3e} mean|d| {r['latent_mean_abs']:.3e} (sampled at stride 2)   "
+            f"[band: max {t['latent_max']:.3e} mean {t['latent_mean']:.3e}]")
+    print("\n" + line)
+    _log(line)
+    assert r["latent_max_abs"] <= t["latent_max"], line
+    assert r["latent_mean_abs"] <= t["latent_mean"], line
     if dtype == torch.float32:
         assert r["latent_max_abs"] <= 1.0e-3

@@ -107,6 +107,11 @@ def test_bias_and_groupnorm_affine_gradients(dtype):
         tabs = ops.gn_stats(xd, one, zero, 1e-6, per_frame=per_frame)
         dg, db = ops.gn_bwd_params(xd, gy.cuda(), tabs, gamma.detach().cuda(), beta.detach().cuda(), silu, per_frame=per_frame)
         bg = ops.bias_grad(gy.cuda())
+        # the fused form (affine sums on the input gradient's reduction pass) against the separate kernels
+        gx_ref = ops.gn_bwd_input(xd, gy.cuda(), tabs, gamma.detach().cuda(), beta.detach().cuda(), silu, per_frame=per_frame)
+        gx2, dg2, db2 = ops.gn_bwd_input_params(xd, gy.cuda(), tabs, gamma.detach().cuda(), beta.detach().cuda(), silu, per_frame=per_frame)
+        assert torch.equal(gx2, gx_ref) and rel(dg2, dg) <= 1e-5 and rel(db2, db) <= 1e-5, (rel(dg2, dg), rel(db2, db))
+        assert rel(dg2, gamma.grad) <= 2e-4 and rel(db2, beta.grad) <= 2e-4
         e = (rel(dg, gamma.grad), rel(db, beta.grad), rel(bg, gy.float().reshape(-1, C).sum(0)))
         _log(f"[affine grads {str(dtype)[6:]} C{C} {T}x{H}x{W} per_frame={per_frame}] d gamma {e[0]:.2e} d beta {e[1]:.2e} bias {e[2]:.2e}")
         assert max(e) <= 2e-4, e  # (fp32 sums of 16-bit-exact products; GroupNorm statistics from the kernel's own pass)
