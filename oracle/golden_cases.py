@@ -58,6 +58,14 @@ ENC_CASES = {
     "cfg4_sd3_t129_720x1280_enc": ("sd3", {}, (1, 3, 129, 720, 1280), 0, 26, 2),
 }
 
+# DECODE-ONLY fixtures at full size: a SEEDED latent (the decoder is judged on a given input; it need not be an encoder's output)
+# through the whole decode wrapper; the reconstruction is stored at stride s over H and W with recon_subsample's per-frame phase.
+# name -> (family, config overrides, latent shape, weight seed, latent seed, recon stride s)
+DEC_CASES = {
+    # BASELINE cfg 4's decode side WHOLE: 33 latent frames at 90x160 -> 129 frames at 720x1280: 8 temporal windows x 6 blended tiles
+    "cfg4_sd3_z33_90x160_dec": ("sd3", {}, (1, 16, 33, 90, 160), 0, 27, 16),
+}
+
 
 def recon_subsample(recon, s: int):
     """recon [B,C,T,H,W] (numpy or torch) -> [B,C,T,H/s,W/s]: frame t sampled at rows (t % s)::s, columns (3t % s)::s"""

@@ -172,8 +172,44 @@ def main_enc(only=None):
               f"({torch.get_num_threads()} threads)", flush=True)
 
 
+def main_dec(only=None):
+    """decode-only fixtures at full size (BASELINE cfg 4's decode side) from the reference's own modules"""
+    import time
+
+    from oracle.golden_cases import DEC_CASES, recon_subsample
+
+    ref = load_reference()
+    torch.set_grad_enabled(False)
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, (family, over, zshape, wseed, zseed, s) in DEC_CASES.items():
+        if only and name not in only:
+            continue
+        cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
+        model = cls(**over).eval()
+        sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+        model.load_state_dict(sd, strict=True)
+        z = seeded_input(zshape, zseed)
+        t0 = time.time()
+        recon = model.decode(z).sample
+        t1 = time.time()
+        r64 = recon.double()
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        np.savez_compressed(
+            os.path.join(out_dir, name + ".npz"),
+            recon_sub=recon_subsample(recon, s).numpy().astype(np.float32), recon_shape=np.asarray(recon.shape, dtype=np.int64),
+            recon_stride=np.int64(s), recon_mean=np.float64(r64.mean()), recon_sqmean=np.float64((r64 * r64).mean()),
+            recon_frame_mean=r64.mean(dim=(0, 1, 3, 4)).numpy(),
+            weight_abs_sum=np.float64(wsum), n_tensors=np.int64(len(sd)),
+            ref_cpu_seconds=np.asarray([t1 - t0]), ref_cpu_threads=np.int64(torch.get_num_threads()),
+        )
+        print(f"{name}: latent {tuple(zshape)} recon {tuple(recon.shape)} wsum {wsum:.6f} reference CPU fp32 decode {t1 - t0:.1f}s "
+              f"({torch.get_num_threads()} threads)", flush=True)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "enc":
+    if len(sys.argv) > 1 and sys.argv[1] == "dec":
+        main_dec(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "enc":
         main_enc(sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "constraint":
         main_constraint()

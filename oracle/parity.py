@@ -8,7 +8,7 @@ import os
 import numpy as np
 import torch
 
-from .golden_cases import BIG_CASES, CASES, ENC_CASES, recon_subsample
+from .golden_cases import BIG_CASES, CASES, DEC_CASES, ENC_CASES, recon_subsample
 from .seeded import seeded_input, seeded_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -119,6 +119,23 @@ def measure_encode(model, name: str, golden_dir: str = GOLDEN_DIR, latents=None)
     if dl is not None:
         out["moments_max_abs"] = float(max(dm.max(), dl.max()))
     return out
+
+
+@torch.no_grad()
+def measure_decode(model, name: str, golden_dir: str = GOLDEN_DIR) -> dict:
+    """decode-only fixtures (golden_cases.DEC_CASES): `model.decode(z).sample` of the seeded latent against the reference's
+    reconstruction, sampled at the fixture's stride (per-frame phase), plus the fp64 mean of the whole reconstruction"""
+    family, over, zshape, wseed, zseed, s = DEC_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    z = seeded_input(zshape, zseed).to(model.dtype).to(model.device)
+    rec = model.decode(z).sample.float().cpu()
+    assert tuple(rec.shape) == tuple(int(v) for v in gold["recon_shape"]), (tuple(rec.shape), gold["recon_shape"])
+    r, g = recon_subsample(rec, s).numpy(), gold["recon_sub"]
+    mse = float(((r - g).astype(np.float64) ** 2).mean())
+    return {"case": name, "shape": list(zshape), "recon_max_abs": float(np.abs(r - g).max()),
+            "recon_psnr_db": float(10 * np.log10(4.0 / max(mse, 1e-30))),
+            "recon_mean_delta": float(abs(rec.double().mean().item() - float(gold["recon_mean"]))),
+            "recon_sampled_fraction": round(1.0 / (s * s), 4)}
 
 
 def fmt(tag: str, m: dict) -> str:

@@ -163,3 +163,30 @@ def test_cfg4_whole_clip_encode_golden(dtype, mode, golden_dir):
     assert r["latent_mean_abs"] <= t["latent_mean"], line
     if dtype == torch.float32:
         assert r["latent_max_abs"] <= 1.0e-3
+
+
+@pytest.mark.parametrize("dtype,mode", MODES, ids=["float16", "bfloat16", "float32", "float32-fast"])
+def test_cfg4_whole_clip_decode_golden(dtype, mode, golden_dir):
+    """BASELINE cfg 4's decode side WHOLE: a seeded 33-frame latent at 90x160 -> 129 frames at 720x1280 through the decode wrapper
+    (8 temporal windows of 5 latent frames x 6 blended latent tiles, the pixel-frame drops between windows) against the
+    reference's own modules (oracle/make_golden.py dec; the reconstruction stored at stride 16 with a per-frame phase)."""
+    name = "cfg4_sd3_z33_90x160_dec"
+    if not os.path.isfile(os.path.join(golden_dir, name + ".npz")):
+        pytest.skip(f"fixture {name}.npz not generated")
+    from oracle.golden_cases import DEC_CASES
+    family, over, zshape, wseed, zseed, s = DEC_CASES[name]
+    m = _model(family, over, dtype, wseed)
+    if mode is not None:
+        m.fp32_mode = mode
+    r = P.measure_decode(m, name, golden_dir)
+    if mode is not None:
+        psnr = TOL_F32[mode]["psnr"]
+    else:
+        e = P.reference_self_noise("cfg3_sd3_t17_512", TAG[dtype], golden_dir)
+        psnr = (e["recon_psnr_db"] if e is not None and "shape" in e else P.REFERENCE_SELF_NOISE[TAG[dtype]]["recon_psnr_db"]) - PSNR_SLACK - 1.0
+    tag = TAG[dtype] + ("q" if mode == "fast" else "")
+    line = (f"{name:28s} {tag:5s} recon max|d| {r['recon_max_abs']:.3e} PSNR {r['recon_psnr_db']:.2f} dB  mean delta {r['recon_mean_delta']:.2e} "
+            f"(1/{s * s} of the pixels)   [band: PSNR {psnr:.1f} dB]")
+    print("\n" + line)
+    _log(line)
+    assert r["recon_psnr_db"] >= psnr, line
