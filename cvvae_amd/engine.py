@@ -26,6 +26,8 @@ class WeightCache:
     def __init__(self, module: torch.nn.Module):
         self.m = module
         self._c: Dict[str, tuple] = {}
+        self._names: Dict[str, tuple] = {}      # parameter name -> (owning submodule's _parameters dict, leaf name): see p()
+        self._absent: set = set()               # names has() found missing (the module structure is fixed per class)
         # fp32 models: pack multi-tap conv weights in the fast layout (CVVAE_F32Q: fp16 MFMA + bf8 correction MFMA, DESIGN.md
         # section 4) instead of the three-MFMA split-precision one; set through the model's `fp32_mode`
         self.fast = False
@@ -42,11 +44,28 @@ class WeightCache:
     def _q(self) -> str:
         return "#q" if self.fast else ""
 
+    def p(self, name: str) -> torch.nn.Parameter:
+        """the module tree's parameter `name`, as nn.Module.get_parameter -- which walks the dotted path on every call (7 us each,
+        ~4 lookups per conv launch: 2.7 ms of host time per encode + decode, more than the GPU time of an image-mode pass).  The
+        path is resolved once to (the owning submodule's _parameters dict, leaf); the dict is read on every call, so a parameter
+        replaced inside its submodule (load_state_dict, .to(), .cuda(), assignment) is always the current one."""
+        hit = self._names.get(name)
+        if hit is None:
+            path, _, leaf = name.rpartition(".")
+            sub = self.m.get_submodule(path) if path else self.m
+            if sub._parameters.get(leaf) is None:
+                raise AttributeError(f"{type(self.m).__name__} has no parameter {name}")
+            hit = self._names[name] = (sub._parameters, leaf)
+        par = hit[0].get(hit[1])
+        if par is None:
+            raise AttributeError(f"{type(self.m).__name__} has no parameter {name}")
+        return par
+
     def act_bound(self, norm_pre: str, sigmas: float = 8.0) -> float:
         """upper bound of |SiLU(gamma n + beta)| for a normalised n within `sigmas`: sigmas max|gamma| + max|beta| (one host sync per
         GroupNorm, cached with its parameters).  Elements beyond it lose only their fp6 CORRECTION terms (include/cvvae.h)."""
-        g = self.m.get_parameter(norm_pre + ".weight")
-        b = self.m.get_parameter(norm_pre + ".bias")
+        g = self.p(norm_pre + ".weight")
+        b = self.p(norm_pre + ".bias")
         key = self._key(g, b)
         tag = norm_pre + "#bound"
         hit = self._c.get(tag)
@@ -69,8 +88,8 @@ class WeightCache:
         wscale (fp32 models): pack with this power-of-two scale (a fused shortcut shares its conv's accumulators);
         act_norm: the GroupNorm whose output (+ SiLU) this stride-1 conv consumes through its prologue -- fast fp32 models then take
         the fp6-correction form with the bound derived from that norm's affine"""
-        w = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        w = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(w, b)
         q6 = (self.fast and self.fast6 and act_norm is not None and w.dtype == torch.float32 and wscale is None
               and tuple(k) in ((3, 3, 3), (1, 3, 3)) and self.act_bound(act_norm) > 0.0)
@@ -100,7 +119,7 @@ class WeightCache:
         """The weights of the INPUT-GRADIENT convolution of a stride-1, zero-padded conv (or linear layer) `pre`: taps flipped,
         Cin and Cout exchanged, no bias -- conv(gy, conv_dgrad(pre)) with the forward's padding is autograd's grad_input
         (cvvae_amd/grad.py).  k: the forward kernel, (1,1,1) for nn.Linear / 1x1 weights."""
-        w = self.m.get_parameter(pre + ".weight")
+        w = self.p(pre + ".weight")
         key = self._key(w)
         tag = f"{pre}#dgrad"
         hit = self._c.get(tag)
@@ -116,8 +135,8 @@ class WeightCache:
 
     def conv_upfold(self, pre: str, tfold: int = 0, time_folds: bool = False) -> ops.PackedConv:
         """Upsample3D conv weights folded into the four 3x2x2 (tfold: 1x2x2) phase kernels (ops.pack_weight_upfold)."""
-        w = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        w = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(w, b)
         tag = f"{pre}#upfold{tfold}{'tf' if time_folds else ''}" + self._q()
         hit = self._c.get(tag)
@@ -130,8 +149,8 @@ class WeightCache:
     def conv_upfold2d(self, pre: str) -> ops.PackedConv:
         """Upsample2D conv weights [Cout, Cin, 3, 3] as the four folded 1x2x2 phase kernels: the 2-D weight is the centre time tap
         of an otherwise zero 3x3x3 weight (pack_weight_upfold tfold 2 = centre tap only)."""
-        w = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        w = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(w, b)
         tag = f"{pre}#upfold2d" + self._q()
         hit = self._c.get(tag)
@@ -148,8 +167,8 @@ class WeightCache:
 
     def conv_rowpack(self, pre: str, time_folds: bool = False) -> ops.PackedConv:
         """the networks' first layer ([Cout, 3, 3, 3, 3]) as the (3,3,1) conv over the row-packed input (ops.pack_weight_rowpack)"""
-        w = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        w = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(w, b)
         tag = f"{pre}#rowpack{'tf' if time_folds else ''}"
         hit = self._c.get(tag)
@@ -161,8 +180,8 @@ class WeightCache:
 
     def conv_tapsn(self, pre: str, time_folds: bool = False):
         """the decoders' last layer as the taps-in-N (3,1,1) conv (ops.pack_weight_tapsn) + its fp32 bias"""
-        w = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        w = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(w, b)
         tag = f"{pre}#tapsn{'tf' if time_folds else ''}"
         hit = self._c.get(tag)
@@ -177,8 +196,8 @@ class WeightCache:
 
     def conv_t1(self, pre: str, mode: str, cin_pad: Optional[int] = None) -> ops.PackedConv:
         """3 x kH x kW weights as the single-frame (T = 1) input sees them: time taps summed ('sum') or centre tap ('center')."""
-        w = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        w = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(w, b)
         tag = f"{pre}#t1{mode}" + self._q()
         hit = self._c.get(tag)
@@ -208,9 +227,9 @@ class WeightCache:
             # entries are refreshed lazily, on access: one packed BEFORE a load_state_dict / in-place edit still holds the OLD
             # weights, and exporting it under the fingerprint of the CURRENT parameters would hand a later process stale
             # weights that pass the import check.  Only entries whose key still matches the live parameters are exported.
-            if ent[0] != self._key(*[self.m.get_parameter(n) for n in names]):
+            if ent[0] != self._key(*[self.p(n) for n in names]):
                 continue
-            out[tag] = {"names": list(names), "fp": [self._fingerprint(self.m.get_parameter(n)) for n in names],
+            out[tag] = {"names": list(names), "fp": [self._fingerprint(self.p(n)) for n in names],
                         "pw": {f.name: getattr(ent[1], f.name) for f in dataclasses.fields(ent[1])}}
         return out
 
@@ -220,7 +239,7 @@ class WeightCache:
         n = 0
         for tag, e in blob.items():
             try:
-                ps = [self.m.get_parameter(nm) for nm in e["names"]]
+                ps = [self.p(nm) for nm in e["names"]]
             except AttributeError:
                 continue
             if [self._fingerprint(p) for p in ps] != [tuple(fp) if not isinstance(fp, tuple) else fp for fp in e["fp"]]:
@@ -234,7 +253,7 @@ class WeightCache:
 
     def bias_sum(self, pre_a: str, pre_b: str) -> torch.Tensor:
         """fp32 b_a + b_b padded to a multiple of 32: the bias of a conv with a fused 1x1 shortcut"""
-        ba, bb = self.m.get_parameter(pre_a + ".bias"), self.m.get_parameter(pre_b + ".bias")
+        ba, bb = self.p(pre_a + ".bias"), self.p(pre_b + ".bias")
         key = self._key(ba, bb)
         tag = f"{pre_a}+{pre_b}#bias"
         hit = self._c.get(tag)
@@ -246,8 +265,8 @@ class WeightCache:
         return out
 
     def norm(self, pre: str) -> Tuple[torch.Tensor, torch.Tensor]:
-        g = self.m.get_parameter(pre + ".weight")
-        b = self.m.get_parameter(pre + ".bias")
+        g = self.p(pre + ".weight")
+        b = self.p(pre + ".bias")
         key = self._key(g, b)
         hit = self._c.get(pre)
         if hit is not None and hit[0] == key:
@@ -257,10 +276,13 @@ class WeightCache:
         return val
 
     def has(self, name: str) -> bool:
+        if name in self._absent:
+            return False
         try:
-            self.m.get_parameter(name)
+            self.p(name)
             return True
         except AttributeError:
+            self._absent.add(name)
             return False
 
 
@@ -316,7 +338,7 @@ def _shortcut_scale_fits(wc: WeightCache, sc_name: str, pw2, dtype) -> bool:
     must stay finite (max |w_sc| * scale < 2^15 leaves headroom for the rounding); otherwise the block runs unfused."""
     if dtype != torch.float32:
         return True
-    w = wc.m.get_parameter(sc_name + ".weight")
+    w = wc.p(sc_name + ".weight")
     key = wc._key(w)
     hit = wc._c.get(sc_name + "#absmax")
     if hit is None or hit[0] != key:
@@ -332,7 +354,7 @@ def _fused_prologue(x: torch.Tensor, k: Tuple[int, int, int], cout: int) -> bool
 
 
 def _cout(wc: "WeightCache", pre: str) -> int:
-    return int(wc.m.get_parameter(pre + ".weight").shape[0])
+    return int(wc.p(pre + ".weight").shape[0])
 
 
 def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
@@ -492,7 +514,7 @@ def rowpack_conv_in() -> bool:
 def encoder_conv_in(wc: WeightCache, x: torch.Tensor, cfg: dict, dtype: torch.dtype, pad, mode_t, mode_hw):
     """conv_in of both encoders: x NCDHW (or the padded NDHWC clip of encode_frames_u8) -> (h NDHWC, GroupNorm partials)"""
     nd = bool(cfg.get("ndhwc_in"))
-    cin = wc.m.get_parameter("conv_in.weight").shape[1]
+    cin = wc.p("conv_in.weight").shape[1]
     if (rowpack_conv_in() and x.shape[1 if nd else 2] > 1 and dtype in (torch.float16, torch.bfloat16) and cin <= 4
             and pad[2] == (1, 1) and (x.dtype == dtype or not nd)):
         # (the device-side pixel path hands over its padded NDHWC clip: same values, hence the same bits as the NCDHW entry)
@@ -513,7 +535,7 @@ def tapsn_conv_out() -> bool:
 
 def decoder_conv_out(wc: WeightCache, h: torch.Tensor, g, pad, mode_t, mode_hw, u8: bool = False):
     """norm_out + SiLU + conv_out of both decoders -> pixels NCDHW (or, u8: the scripts' uint8 frames [T,H,W,3], one clip)"""
-    w = wc.m.get_parameter("conv_out.weight")
+    w = wc.p("conv_out.weight")
     if (tapsn_conv_out() and 9 * w.shape[0] <= 32 and w.shape[0] == 3
             and pad[1] == (1, 1) and pad[2] == (1, 1) and h.shape[-1] % 32 == 0):
         pw, bias = wc.conv_tapsn("conv_out", time_folds=mode_t == REP and fold_time())
@@ -581,7 +603,7 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list
     """Encoder3D.forward, vae_models3d_sd3.py:162-208.  x: NCDHW (any float dtype) -> moments NCDHW.
     tape: a list that receives what the backward pass of the TRAINABLE encoder (grad3d.sd3_encoder_backward) reads again; the
     launches are the inference pass's own (same bits)."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
     pad = PC if causal else P1
@@ -608,7 +630,7 @@ def sd3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list
 def sd3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
     """Decoder3D.forward, vae_models3d_sd3.py:323-388.  z: NCDHW latents -> pixels NCDHW.
     tape: receives what grad3d.sd3_decoder_backward reads again (training the decoder; the launches are the inference pass's)."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     causal = cfg["causal"]
     boc = cfg["block_out_channels"]
     pad = PC if causal else P1
@@ -656,7 +678,7 @@ def constraint_decoder2d(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Opti
     z NCDHW [b,c,t,h,w] -> pixels [b,3,t,8h,8w], every frame decoded on its own ("b c t h w -> (b t) c h w": frames are the
     batch rows here, so every GroupNorm is per frame as in the reference).  tape: a list that receives what the input-gradient
     pass of the frozen decoder (grad.constraint_decoder2d_backward) reads again."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     boc = cfg["block_out_channels"]
     B, zin, T = z.shape[0], z.shape[1], z.shape[2]
     cpad = ops.round_up(zin, 32)
@@ -705,7 +727,7 @@ def ldm2d_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     through conv_in -> levels of ResnetBlocks (GroupNorm eps 1e-6 + swish + 3x3, 1x1 nin_shortcut) with Downsample (zero pad
     right / bottom, 3x3 stride 2) -> mid (block_1, single-head attn_1, block_2) -> norm_out + swish + conv_out -> quant_conv 1x1.
     x NCDHW [b,c,t,h,w] -> moments [b,2z,t,h/f,w/f]."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     B, T = x.shape[0], x.shape[2]
     nlev = len(cfg["ch_mult"])
     h = _frames_in(x, 32, dtype)
@@ -721,7 +743,7 @@ def ldm2d_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict) -> torch.Tensor:
     h, hp = spatial_attention(wc, h, a + ".norm", a + ".q", a + ".k", a + ".v", a + ".proj_out", 1e-6, True, gn_out=G32, xp=hp)
     h, hp = c2d_resnet(wc, h, hp, "mid.block_2", sc=".nin_shortcut")
     g = _norm(wc, h, hp, "norm_out", 1e-6)
-    zc = wc.m.get_parameter("conv_out.weight").shape[0]
+    zc = wc.p("conv_out.weight").shape[0]
     m = ops.conv(h, wc.conv("conv_out", (1, 3, 3)), pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g,
                  cout_pad=ops.round_up(zc, 128) if wc.has("quant_conv.weight") else None,
                  out_mode=L.OUT_NDHWC if wc.has("quant_conv.weight") else L.OUT_NCDHW)
@@ -736,7 +758,7 @@ def ldm2d_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict) -> torch.Tensor:
     """DecoderWith3DWrapper.forward over Decoder.forward (model.py:728-772, 820-830): post_quant_conv 1x1 -> conv_in -> mid ->
     levels (num_res_blocks + 1 ResnetBlocks, Upsample = nearest x2 + 3x3) from the coarsest -> norm_out + swish + conv_out.
     z NCDHW [b,zc,t,h,w] -> pixels [b,out_ch,t,f*h,f*w]."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     B, T = z.shape[0], z.shape[2]
     nlev = len(cfg["ch_mult"])
     if wc.has("post_quant_conv.weight"):
@@ -784,7 +806,7 @@ def v3_resnet(wc: WeightCache, x: torch.Tensor, xp, pre: str, causal: bool, want
 
 def v3_encoder(wc: WeightCache, x: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
     """Encoder.forward, vae_models.py:790-823.  tape: see sd3_encoder (grad3d.py trains this network too)."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])
@@ -830,7 +852,7 @@ def v3_attn_spatial_temporal(wc: WeightCache, x: torch.Tensor, a: str, xp=None, 
 
 def v3_decoder(wc: WeightCache, z: torch.Tensor, cfg: dict, tape: Optional[list] = None) -> torch.Tensor:
     """Decoder.forward, vae_models.py:960-1002.  tape: see sd3_decoder."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     causal = cfg["causal"]
     pad, mt, mhw = _v3_pad(causal)
     nlev = len(cfg["ch_mult"])

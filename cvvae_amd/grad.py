@@ -62,7 +62,7 @@ def resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict) -> torch.Tensor:
 
 def _linear_grads(wc: WeightCache, grads: dict, pre: str, a: torch.Tensor, g: torch.Tensor):
     """parameter gradients of y = linear(a) (nn.Linear / 1x1 conv `pre`) given g = dL/dy: dW = g^T a on the wgrad kernel, db = sum g"""
-    w = wc.m.get_parameter(pre + ".weight")
+    w = wc.p(pre + ".weight")
     a5, g5 = a.reshape(a.shape[0], 1, 1, -1, a.shape[-1]), g.reshape(g.shape[0], 1, 1, -1, g.shape[-1])
     grads[pre + ".weight"] = ops.conv_wgrad(a5.contiguous(), g5.contiguous(), K1, cin=w.shape[1], cout=w.shape[0]).reshape(w.shape)
     if wc.has(pre + ".bias"):
@@ -116,7 +116,7 @@ def attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Optiona
 
 def constraint_decoder2d_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor) -> torch.Tensor:
     """gy = dL/d(output) [b,3,t,H,W] of engine.constraint_decoder2d(wc, z, cfg, tape) -> dL/dz [b,c,t,h,w]."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     last = tape[-1]
     assert last["op"] == "out"
     B, T, zin = last["B"], last["T"], last["zin"]

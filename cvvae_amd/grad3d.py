@@ -47,7 +47,7 @@ FULL = ((2, 2), (2, 2), (2, 2))  # zero padding of the full correlation of a 3x3
 
 def _conv_param_grads(wc: WeightCache, grads: Dict[str, torch.Tensor], pre: str, a: torch.Tensor, g: torch.Tensor, k, **geom):
     """dW, db of `pre` (a conv over operand a with output gradient g)"""
-    w = wc.m.get_parameter(pre + ".weight")
+    w = wc.p(pre + ".weight")
     grads[pre + ".weight"] = ops.conv_wgrad(a, g, k, cin=w.shape[1], cout=w.shape[0], **geom).reshape(w.shape)
     if wc.has(pre + ".bias"):
         grads[pre + ".bias"] = ops.bias_grad(g, cout=w.shape[0])
@@ -161,12 +161,12 @@ def temporal_attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads
 def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False):
     """gy = dL/d(output) (NCDHW) of engine.sd3_encoder / engine.sd3_decoder run with `tape` -> (dL/d(input) NCDHW or None,
     {parameter name: fp32 gradient})."""
-    dtype = wc.m.get_parameter("conv_in.weight").dtype
+    dtype = wc.p("conv_in.weight").dtype
     grads: Dict[str, torch.Tensor] = {}
     last = tape[-1]
     assert last["op"] == "out3d"
     pad, mt, mhw = last["pad"], last["mode_t"], last["mode_hw"]
-    cout = wc.m.get_parameter("conv_out.weight").shape[0]
+    cout = wc.p("conv_out.weight").shape[0]
     g = ops.ncdhw_to_ndhwc(gy.contiguous(), ops.round_up(cout, 16), dtype)                      # [B,T',h,w,Cpad], pad channels zero
     x = last["x"]
     a = ops.gn_silu_apply(x, last["g"])
@@ -199,7 +199,7 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
             if need_input_grad:
                 # (conv_in's weights as a 128 -> 3-channel transposed kernel; the gradient tensor is channel-padded to 8)
                 gi = dgrad333(wc, g, "conv_in", e["pad"], e["mode_t"], e["mode_hw"], tuple(xin.shape[:4]))
-                gx = ops.ndhwc_to_ncdhw(gi, wc.m.get_parameter("conv_in.weight").shape[1])
+                gx = ops.ndhwc_to_ncdhw(gi, wc.p("conv_in.weight").shape[1])
         elif e["op"] == "dec_in":    # the decoder's first layer over the (channel-padded NDHWC) latent
             xin = e["x"]
             _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
