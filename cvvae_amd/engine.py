@@ -80,7 +80,7 @@ class WeightCache:
         return hit[1]
 
     def _key(self, *ps):
-        return tuple((p.data_ptr(), p._version, p.dtype, str(p.device)) for p in ps if p is not None)
+        return tuple((p.data_ptr(), p._version, p.dtype, p.device) for p in ps if p is not None)
 
     def conv(self, pre: str, k: Tuple[int, int, int], cin_pad: Optional[int] = None, time_folds: bool = False,
              wscale: Optional[float] = None, act_norm: Optional[str] = None) -> ops.PackedConv:

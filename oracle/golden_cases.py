@@ -68,9 +68,11 @@ DEC_CASES = {
 
 
 def recon_subsample(recon, s: int):
-    """recon [B,C,T,H,W] (numpy or torch) -> [B,C,T,H/s,W/s]: frame t sampled at rows (t % s)::s, columns (3t % s)::s"""
+    """recon [B,C,T,H,W] (numpy or torch) -> [B,C,T,H//s,W//s]: frame t sampled at rows (t % s)::s, columns (3t % s)::s (cropped to
+    the common H//s x W//s when s does not divide the frame: the phases would otherwise differ in length)"""
     import numpy as np
-    frames = [recon[:, :, t, (t % s)::s, ((3 * t) % s)::s] for t in range(recon.shape[2])]
+    hs, ws = recon.shape[3] // s, recon.shape[4] // s
+    frames = [recon[:, :, t, (t % s)::s, ((3 * t) % s)::s][..., :hs, :ws] for t in range(recon.shape[2])]
     if hasattr(recon, "numpy"):
         import torch
         return torch.stack(frames, dim=2)

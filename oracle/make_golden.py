@@ -157,6 +157,7 @@ def main_enc(only=None):
         t0 = time.time()
         mnp = model.encode(x).latent_dist.parameters.numpy().astype(np.float32)
         t1 = time.time()
+        np.save(os.path.join(os.path.dirname(HERE), "gpurun_out", name + "_raw_moments.npy"), mnp)  # (hours of CPU: keep the raw result)
         zc = mnp.shape[1] // 2
         wsum = float(sum(v.double().abs().sum() for v in sd.values()))
         np.savez_compressed(
