@@ -45,7 +45,7 @@ struct WgradArgs {
   int To, Ho, Wo, Cout;
   long long g_ps;
   int kT, sT, sH, sW, pt, ph, pw, mode_t, mode_hw;
-  int nslab, rows_total, n_ci_blk;
+  int nslab, rows_total, n_ci_blk, n_coci, n_members;
   int Coutp, Cinp;  // padded to multiples of 128 / 64: the partial buffer's channel extents
 };
 
@@ -83,9 +83,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   char* const gs = smem + NPART * XS_BYTES;    // [part][co][ROWP]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int slab = blockIdx.x;
-  const int co_blk = blockIdx.y / p.n_ci_blk, ci_blk = blockIdx.y % p.n_ci_blk;
-  const int dt = blockIdx.z;
+  // XCD-aware block map (consecutive block ids run on the 8 XCDs round-robin, each with its own L2): the n = n_co * n_ci * kT
+  // workgroups that share a slab -- they read the same gy rows and the same / neighbouring a rows -- are consecutive ON ONE XCD
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int member = idx % p.n_members, slab = (idx / p.n_members) * 8 + xcd;
+  if (slab >= p.nslab) return;
+  const int coci = member % p.n_coci, dt = member / p.n_coci;
+  const int co_blk = coci / p.n_ci_blk, ci_blk = coci % p.n_ci_blk;
   const int co0 = co_blk * CO, ci0 = ci_blk * CI;
   // the panels of all output rows, cut into nslab contiguous runs (a flattened 1x1 layer is ONE long row)
   const int npanel_row = (p.Wo + KP - 1) / KP;
@@ -303,7 +307,10 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
   p.mode_t = d->pad_mode_t; p.mode_hw = d->pad_mode_hw;
   p.nslab = nslab; p.rows_total = d->B * d->To * d->Ho; p.n_ci_blk = n_ci;
   p.Coutp = n_co * 128; p.Cinp = n_ci * 64;
-  hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3(nslab, n_co * n_ci, d->kT), dim3(512), 0, s, p);
+  p.n_coci = n_co * n_ci;
+  p.n_members = n_co * n_ci * d->kT;
+  const int nslab8 = (nslab + 7) / 8 * 8;  // (blocks of the padding slabs exit at once)
+  hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p);
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const int ntaps = d->kT * d->kH * d->kW;
