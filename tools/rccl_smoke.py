@@ -13,12 +13,11 @@ def worker():
     import bench
     import cvvae_amd
     from cvvae_amd import dist as D
-    from oracle import parity as P
     world, rank, lr = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
     torch.cuda.set_device(lr)
     dist = bench.init_rccl(torch, world, rank, lr, seconds=120)
-    m = cvvae_amd.CVVAESD3Model()
-    P.load_seeded(m, 0)
+    torch.manual_seed(0)
+    m = cvvae_amd.CVVAESD3Model()  # (the classes initialise their parameters with PyTorch's default-init statistics)
     m = m.to(torch.bfloat16).cuda().eval()
     T = bench.temporal_shard_T(world)
     xf, xl = bench.temporal_shard_input(T, 96, 128, world, rank, torch.bfloat16, "cuda")

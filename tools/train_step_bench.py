@@ -26,7 +26,6 @@ def main():
     args = ap.parse_args()
     import cvvae_amd
     from cvvae_amd import ops
-    from oracle import parity as P
     dtype = {"bf16": torch.bfloat16, "f16": torch.float16, "f32": torch.float32}[args.dtype]
     out = {"dtype": args.dtype, "clip": [1, 3, args.T, args.H, args.W]}
     # ---- the weight-gradient kernel alone (bf16 / fp16 operands; fp32 = three bf16 MFMAs per product)
@@ -56,8 +55,8 @@ def main():
                              "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500.0, 4)})
         del a, g
     # ---- one training step of both networks
-    m = cvvae_amd.CVVAESD3Model()
-    P.load_seeded(m, 0)
+    torch.manual_seed(0)
+    m = cvvae_amd.CVVAESD3Model()  # (the classes initialise their parameters with PyTorch's default-init statistics)
     m = m.to(dtype).cuda().train()
     x = (torch.rand((1, 3, args.T, args.H, args.W)) * 2 - 1).to(dtype).cuda()
     zc = m.encoder.conv_out.weight.shape[0] // 2
