@@ -738,7 +738,9 @@ def layernorm_bwd(x: torch.Tensor, gy: torch.Tensor, gamma: torch.Tensor, beta: 
     kernels' grid y; the temporal attention of the vae3d decoder sits at latent resolution)."""
     C = x.shape[-1]
     n = x.numel() // C
-    assert x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape and n <= 65535, (tuple(x.shape), n)
+    assert x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape, (tuple(x.shape), tuple(gy.shape))
+    if n > 65535:
+        raise NotImplementedError(f"layernorm_bwd: {n} tokens exceed the 65535 rows one launch of the GroupNorm kernels takes")
     x5, g5 = x.view(n, 1, 1, 1, C), gy.view(n, 1, 1, 1, C)
     one = torch.ones(C, dtype=torch.float32, device=x.device)
     zero = torch.zeros(C, dtype=torch.float32, device=x.device)
