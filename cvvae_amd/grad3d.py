@@ -45,12 +45,25 @@ K1 = (1, 1, 1)
 FULL = ((2, 2), (2, 2), (2, 2))  # zero padding of the full correlation of a 3x3x3 kernel
 
 
-def _conv_param_grads(wc: WeightCache, grads: Dict[str, torch.Tensor], pre: str, a: torch.Tensor, g: torch.Tensor, k, **geom):
-    """dW, db of `pre` (a conv over operand a with output gradient g)"""
+def _conv_param_grads(wc: WeightCache, grads: Optional[Dict[str, torch.Tensor]], pre: str, a, g: torch.Tensor, k, **geom):
+    """dW, db of `pre` (a conv over operand a with output gradient g); grads None = a frozen network: nothing to do.
+    a: the operand, or a callable that produces it (so that a frozen pass does not re-create operands it never reads)"""
+    if grads is None:
+        return
+    if callable(a):
+        a = a()
     w = wc.p(pre + ".weight")
     grads[pre + ".weight"] = ops.conv_wgrad(a, g, k, cin=w.shape[1], cout=w.shape[0], **geom).reshape(w.shape)
     if wc.has(pre + ".bias"):
         grads[pre + ".bias"] = ops.bias_grad(g, cout=w.shape[0])
+
+
+def _gn_backward(grads, name: str, x, g, tabs, affine, silu: bool, add=None):
+    """input gradient of act(GroupNorm(x)) (+ add), and -- trainable network -- the norm's affine gradients into `grads`"""
+    if grads is None:
+        return ops.gn_bwd_input(x, g, tabs, *affine, silu=silu, add=add)
+    gx, grads[name + ".weight"], grads[name + ".bias"] = ops.gn_bwd_input_params(x, g, tabs, *affine, silu=silu, add=add)
+    return gx
 
 
 def dgrad333(wc: WeightCache, g: torch.Tensor, pre: str, pad, mode_t: int, mode_hw: int, in_shape, stride=(1, 1, 1),
@@ -91,30 +104,27 @@ def sd3_resnet_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict[s
     pad, mt, mhw, eps = e["pad"], e["mode_t"], e["mode_hw"], e["eps"]
     B, T, H, W, _ = x.shape
     # conv2: per-frame 3x3, zero padding, over a2 = silu(norm2(h))
-    a2 = ops.gn_silu_apply(h, e["g2"])
-    _conv_param_grads(wc, grads, pre + ".conv2", a2, g, K133, pad=P2D)
-    del a2
+    _conv_param_grads(wc, grads, pre + ".conv2", lambda: ops.gn_silu_apply(h, e["g2"]), g, K133, pad=P2D)
     g_a2 = ops.conv(g, wc.conv_dgrad(pre + ".conv2", K133), pad=P2D, pad_mode_hw=ZERO)
     tabs2 = grad._unit_tabs(wc, h, e["hp"], eps)
     n2 = wc.norm(pre + ".norm2")
-    g_h, grads[pre + ".norm2.weight"], grads[pre + ".norm2.bias"] = ops.gn_bwd_input_params(h, g_a2, tabs2, *n2, silu=True)
+    g_h = _gn_backward(grads, pre + ".norm2", h, g_a2, tabs2, n2, True)
     del g_a2
     # conv1: 3x3x3 over a1 = silu(norm1(x))
-    a1 = ops.gn_silu_apply(x, e["g1"])
-    _conv_param_grads(wc, grads, pre + ".conv1", a1, g_h, K333, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
-    del a1
+    _conv_param_grads(wc, grads, pre + ".conv1", lambda: ops.gn_silu_apply(x, e["g1"]), g_h, K333, pad=pad, pad_mode_t=mt,
+                      pad_mode_hw=mhw)
     g_a1 = dgrad333(wc, g_h, pre + ".conv1", pad, mt, mhw, (B, T, H, W))
     # skip branch
     sc = pre + e["sc"]
     if wc.has(sc + ".weight"):
-        grad._linear_grads(wc, grads, sc, x.view(B, 1, 1, -1, x.shape[-1]), g.view(B, 1, 1, -1, g.shape[-1]))
+        if grads is not None:
+            grad._linear_grads(wc, grads, sc, x.view(B, 1, 1, -1, x.shape[-1]), g.view(B, 1, 1, -1, g.shape[-1]))
         skip = grad._dgrad1x1(wc, g, sc)
     else:
         skip = g
     tabs1 = grad._unit_tabs(wc, x, e["xp"], eps)
     n1 = wc.norm(pre + ".norm1")
-    gx, grads[pre + ".norm1.weight"], grads[pre + ".norm1.bias"] = ops.gn_bwd_input_params(x, g_a1, tabs1, *n1, silu=True, add=skip)
-    return gx
+    return _gn_backward(grads, pre + ".norm1", x, g_a1, tabs1, n1, True, add=skip)
 
 
 def _unshuffle_time(g: torch.Tensor) -> torch.Tensor:
@@ -132,9 +142,9 @@ def sd3_upsample_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads: Dict
     x, pre, pad = e["x"], e["pre"], e["pad"]
     B, T, H, W, C = x.shape
     gc = _unshuffle_time(g) if e["up_time"] else g
-    a_up = x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)                # F.interpolate(scale=(1,2,2), mode="nearest")
-    _conv_param_grads(wc, grads, pre, a_up, gc, K333, pad=pad, pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
-    del a_up
+    # (the operand: F.interpolate(scale=(1,2,2), mode="nearest") of x, materialised for the weight gradient only)
+    _conv_param_grads(wc, grads, pre, lambda: x.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3), gc, K333, pad=pad,
+                      pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
     gup = dgrad333(wc, gc, pre, pad, e["mode_t"], e["mode_hw"], (B, T, 2 * H, 2 * W))
     return ops.upsample2x_sum(gup.view(B * T, 1, 2 * H, 2 * W, C)).view(B, T, H, W, C)
 
@@ -146,36 +156,38 @@ def temporal_attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads
     a, h, n = e["pre"], e["h"], e["n"]
     B, T, H, W, C = h.shape
     flat = lambda t: t.view(B, 1, 1, -1, t.shape[-1])  # noqa: E731
-    grad._linear_grads(wc, grads, a + ".proj_out_t", flat(e["o"]), flat(g))
+    if grads is not None:
+        grad._linear_grads(wc, grads, a + ".proj_out_t", flat(e["o"]), flat(g))
     g_o = grad._dgrad1x1(wc, g, a + ".proj_out_t")
     g_q, g_k, g_v = ops.temporal_attention_bwd(e["q"], e["k"], e["v"], g_o)
     g_n = None
     for name, gg in ((".q_t", g_q), (".k_t", g_k), (".v_t", g_v)):
-        grad._linear_grads(wc, grads, a + name, flat(n), flat(gg))
+        if grads is not None:
+            grad._linear_grads(wc, grads, a + name, flat(n), flat(gg))
         g_n = grad._dgrad1x1(wc, gg, a + name, residual=g_n)
     g_h, dg, db = ops.layernorm_bwd(h, g_n, *wc.norm(a + ".norm_t"), 1e-5)
-    grads[a + ".norm_t.weight"], grads[a + ".norm_t.bias"] = dg, db
+    if grads is not None:
+        grads[a + ".norm_t.weight"], grads[a + ".norm_t.bias"] = dg, db
     return g_h
 
 
-def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False):
+def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False, need_params: bool = True):
     """gy = dL/d(output) (NCDHW) of engine.sd3_encoder / engine.sd3_decoder run with `tape` -> (dL/d(input) NCDHW or None,
-    {parameter name: fp32 gradient})."""
+    {parameter name: fp32 gradient}).  need_params = False (a FROZEN network whose input needs a gradient): the weight-gradient,
+    bias and affine launches are skipped and the dict comes back empty."""
     dtype = wc.p("conv_in.weight").dtype
-    grads: Dict[str, torch.Tensor] = {}
+    grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
     last = tape[-1]
     assert last["op"] == "out3d"
     pad, mt, mhw = last["pad"], last["mode_t"], last["mode_hw"]
     cout = wc.p("conv_out.weight").shape[0]
     g = ops.ncdhw_to_ndhwc(gy.contiguous(), ops.round_up(cout, 16), dtype)                      # [B,T',h,w,Cpad], pad channels zero
     x = last["x"]
-    a = ops.gn_silu_apply(x, last["g"])
-    _conv_param_grads(wc, grads, "conv_out", a, g, K333, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
-    del a
+    _conv_param_grads(wc, grads, "conv_out", lambda: ops.gn_silu_apply(x, last["g"]), g, K333, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
     g = dgrad333(wc, g, "conv_out", pad, mt, mhw, tuple(x.shape[:4]))
     tabs = grad._unit_tabs(wc, x, last["xp"], last["eps"])
     no = wc.norm(last["norm"])
-    g, grads[last["norm"] + ".weight"], grads[last["norm"] + ".bias"] = ops.gn_bwd_input_params(x, g, tabs, *no, silu=True)
+    g = _gn_backward(grads, last["norm"], x, g, tabs, no, True)
     gx = None
     outer = None  # gradient of the outer residual of a spatial-temporal attention block, added after its spatial half
     for e in reversed(tape[:-1]):
@@ -194,6 +206,8 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
         elif e["op"] == "up3d":
             g = sd3_upsample_backward(wc, g, e, grads)
         elif e["op"] == "conv_in":   # the encoder's first layer over the clip
+            if grads is None and not need_input_grad:
+                continue
             xin = e["x"] if e["ndhwc_in"] else ops.ncdhw_to_ndhwc(e["x"], 16, dtype)           # [B,T,H,W,16], channels 3.. zero
             _conv_param_grads(wc, grads, "conv_in", xin, g, K333, pad=e["pad"], pad_mode_t=e["mode_t"], pad_mode_hw=e["mode_hw"])
             if need_input_grad:
@@ -208,7 +222,7 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
                 gx = ops.ndhwc_to_ncdhw(gi, e["zin"])
         else:
             raise AssertionError(e["op"])
-    return gx, grads
+    return gx, (grads if grads is not None else {})
 
 
 sd3_encoder_backward = sd3_net_backward  # (the encoder's tape through the common walker)
@@ -233,7 +247,8 @@ class Net3DFn(torch.autograd.Function):
     def backward(ctx, gy: torch.Tensor):
         net = ctx.net
         with torch.cuda.device(gy.device):
-            gx, grads = sd3_net_backward(net._cache(), ctx.tape, gy, need_input_grad=ctx.need_x)
+            gx, grads = sd3_net_backward(net._cache(), ctx.tape, gy, need_input_grad=ctx.need_x,
+                                         need_params=any(req for _, req, _ in ctx.pmeta))
         out = []
         for name, (dt, req, shape) in zip(ctx.names, ctx.pmeta):
             gq = grads.get(name)

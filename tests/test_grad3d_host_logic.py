@@ -156,3 +156,29 @@ def test_vae3d_decoder_backward_wiring(zshape):
         for n, p in dec.named_parameters():
             assert p.grad is not None and p.grad.shape == p.shape, n
             assert _rel(p.grad, ref_sd["decoder." + n].grad, 1e-4 * scale) < 2e-4, (n, _rel(p.grad, ref_sd["decoder." + n].grad))
+
+
+def test_frozen_network_gives_the_input_gradient_only():
+    """a network whose parameters are frozen but whose input needs a gradient (the decoder under a latent-space loss): the same
+    input gradient, no parameter gradients, and none of the weight-gradient / bias / affine launches"""
+    import cvvae_amd
+    from cvvae_amd import ops
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 8)
+    m.load_state_dict(sd, strict=True)
+    dec = m.decoder.train().requires_grad_(False)
+    ref_sd = {k: v.float() for k, v in sd.items() if k.startswith("decoder.")}
+    z = seeded_input((1, 16, 3, 4, 6), 13)
+    zr = z.clone().requires_grad_(True)
+    yr = O.sd3_decoder(zr, ref_sd, dict(block_out_channels=SMALL["block_out_channels"], layers_per_block=1))
+    cot = seeded_input(tuple(yr.shape), 5)
+    (yr * cot).sum().backward()
+    calls = []
+    with emu_ops.patched(whole_model=True):
+        for name in ("conv_wgrad", "bias_grad", "gn_bwd_input_params", "gn_bwd_params"):
+            setattr(ops, name, (lambda n: (lambda *a, **k: calls.append(n)))(name))
+        za = z.clone().requires_grad_(True)
+        (dec(za) * cot).sum().backward()
+    assert not calls, calls
+    assert _rel(za.grad, zr.grad) < 1e-4
+    assert all(p.grad is None for p in dec.parameters())
