@@ -666,21 +666,36 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const T* __restrict_
   for (int j = 0; j < (PARAMS ? 8 : 1); ++j) pb[j] = pg[j] = 0.f;
   const T* xb = x + (long long)row * S * C + myv * 8;
   const T* gb = gy + (long long)row * S * C + myv * 8;
-  for (long long px = p0 + mypl; px < p1; px += ppp) {
-    float f[8], g[8];
-    ld8<T>(xb + px * C, f);
-    ld8<T>(gb + px * C, g);
+  // four pixels per trip: their 16-byte loads are issued together (one pixel per trip was latency bound: ~2 TB/s on the
+  // million-pixel tensors of a training step); lanes past the end re-read pixel px with a zeroed gradient
+  constexpr int U = 4;
+  for (long long px = p0 + mypl; px < p1; px += U * ppp) {
+    float f[U][8], g[U][8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float xh = __builtin_fmaf(f[j], t.rs[j], t.nm[j]);
-      const float a = __builtin_fmaf(xh, t.ga[j], t.be[j]);
-      const float gact = g[j] * (silu ? silu_grad_f(a) : 1.0f);
-      const float gh = gact * t.ga[j];
-      a1[j >> 2] += gh;
-      a2[j >> 2] += gh * xh;
-      if constexpr (PARAMS) {
-        pb[j] += gact;
-        pg[j] += gact * xh;
+    for (int u = 0; u < U; ++u) {
+      const bool ok = px + u * ppp < p1;
+      const long long q = ok ? px + u * ppp : px;
+      ld8<T>(xb + q * C, f[u]);
+      ld8<T>(gb + q * C, g[u]);
+      if (!ok) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[u][j] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = __builtin_fmaf(f[u][j], t.rs[j], t.nm[j]);
+        const float a = __builtin_fmaf(xh, t.ga[j], t.be[j]);
+        const float gact = g[u][j] * (silu ? silu_grad_f(a) : 1.0f);
+        const float gh = gact * t.ga[j];
+        a1[j >> 2] += gh;
+        a2[j >> 2] += gh * xh;
+        if constexpr (PARAMS) {
+          pb[j] += gact;
+          pg[j] += gact * xh;
+        }
       }
     }
   }
@@ -729,17 +744,29 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
                                                            const float* __restrict__ ws) {
   const int row = blockIdx.y, tid = threadIdx.x;
-  __shared__ float c1[64], c2[64];
-  if (tid < G) {
+  __shared__ float c1[64], c2[64], q1[256], q2[256];
+  {  // group g = tid % G, split lane l = tid / G sums splits l, l + lanes, ...; the lanes are then added in index order
+    const int lanes = 256 / G, g = tid % G, l = tid / G;
     float s1 = 0.f, s2 = 0.f;
-    for (int sp = 0; sp < nsplit; ++sp) {
-      const float* o = ws + (((long long)row * nsplit + sp) * G + tid) * 2;
-      s1 += o[0];
-      s2 += o[1];
+    if (l < lanes)
+      for (int sp = l; sp < nsplit; sp += lanes) {
+        const float2 o = *reinterpret_cast<const float2*>(ws + (((long long)row * nsplit + sp) * G + g) * 2);
+        s1 += o.x;
+        s2 += o.y;
+      }
+    q1[tid] = s1;
+    q2[tid] = s2;
+    __syncthreads();
+    if (tid < G) {
+      s1 = 0.f; s2 = 0.f;
+      for (int k = 0; k < lanes; ++k) {
+        s1 += q1[k * G + tid];
+        s2 += q2[k * G + tid];
+      }
+      const float invd = 1.0f / ((float)(C / G) * (float)S);
+      c1[tid] = s1 * invd;
+      c2[tid] = s2 * invd;
     }
-    const float invd = 1.0f / ((float)(C / G) * (float)S);
-    c1[tid] = s1 * invd;
-    c2[tid] = s2 * invd;
   }
   __syncthreads();
   const int cv = C >> 3;
@@ -807,11 +834,11 @@ __global__ __launch_bounds__(256) void upsample2x_sum_kernel(const T* __restrict
   }
 }
 
-static inline int gn_bwd_splits(long long S) {  // >= 2048 pixels per split: the per-split reduction stays a small share
-  // (up to 512 splits: a 5-D GroupNorm has ONE row per sample, and 64 workgroups left three quarters of the CUs idle on the
+static inline int gn_bwd_splits(long long S) {  // >= 512 pixels per split (a 147 k-pixel tensor at 2048 had 72 workgroups for 256 CUs)
+  // (up to 1024 splits: a 5-D GroupNorm has ONE row per sample, and 64 workgroups left three quarters of the CUs idle on the
   //  million-pixel tensors of a training step -- 372 us per call, profiles/r4_train_step_kernel_stats_v2.txt)
-  const long long n = (S + 2047) / 2048;
-  return (int)(n < 1 ? 1 : (n > 512 ? 512 : n));
+  const long long n = (S + 511) / 512;
+  return (int)(n < 1 ? 1 : (n > 1024 ? 1024 : n));
 }
 // sum1[c], sum2[c] = sums over `nparts` [C][2] tables (a block = 32 channels x 8 part lanes, parts summed in a fixed order)
 __global__ __launch_bounds__(256) void gn_params_final_kernel(const float* __restrict__ ws, int nparts, int C, float* __restrict__ o1,

@@ -266,16 +266,37 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
 // dW[co][ci][tap] = sum over slabs (index order) of part[slab][tap][co][ci]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int ntaps, int Coutp, int Cinp,
                                                            int Cout, int Cin, float* __restrict__ dw) {
-  const long long n = (long long)Cout * Cin * ntaps;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
-    const int tap = (int)(i % ntaps);
-    const long long r = i / ntaps;
-    const int ci = (int)(r % Cin), co = (int)(r / Cin);
-    const float* s = part + ((long long)tap * Coutp + co) * Cinp + ci;
-    const long long slab_stride = (long long)ntaps * Coutp * Cinp;
-    float acc = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) acc += s[sl * slab_stride];
-    dw[i] = acc;
+  // One thread = four consecutive input channels of one (tap, co): the slab reads are 16-byte and coalesced (the partial
+  // buffer is ~100x the weight tensor; an earlier revision indexed by OUTPUT element -- tap fastest -- and read 4 bytes per
+  // 128-byte line).  The 4-byte stores into [Cout][Cin][taps] are scattered, but they are 1/nslab of the traffic.
+  const int c4 = Cinp >> 2;
+  const long long n4 = (long long)ntaps * Coutp * c4;
+  const long long slab_stride4 = n4;  // float4 units
+  const float4* __restrict__ part4 = reinterpret_cast<const float4*>(part);
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    const int ci = (int)(i % c4) * 4;
+    const long long r = i / c4;
+    const int co = (int)(r % Coutp), tap = (int)(r / Coutp);
+    if (co >= Cout || ci >= Cin) continue;
+    const float4* s = part4 + i;
+    float4 acc = {0.f, 0.f, 0.f, 0.f};
+    int sl = 0;
+    for (; sl + 8 <= nslab; sl += 8) {  // eight loads in flight, summed in slab order (deterministic)
+      float4 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s[(sl + u) * slab_stride4];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; sl < nslab; ++sl) {
+      const float4 v = s[sl * slab_stride4];
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float* o = dw + ((long long)co * Cin + ci) * ntaps + tap;
+    o[0] = acc.x;
+    if (ci + 1 < Cin) o[ntaps] = acc.y;
+    if (ci + 2 < Cin) o[2 * ntaps] = acc.z;
+    if (ci + 3 < Cin) o[3 * ntaps] = acc.w;
   }
 }
 
@@ -314,8 +335,8 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
   int rc = (int)hipGetLastError();
   if (rc) return rc;
   const int ntaps = d->kT * d->kH * d->kW;
-  long long blocks = ((long long)d->Cout * d->Cin * ntaps + 255) / 256;
-  if (blocks > 4096) blocks = 4096;
+  long long blocks = ((long long)ntaps * p.Coutp * (p.Cinp / 4) + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp,
                      d->Cout, d->Cin, dw);
   return (int)hipGetLastError();
@@ -361,22 +382,37 @@ __global__ __launch_bounds__(256) void chan_sums_kernel(const T* __restrict__ x,
     tbe[j] = ok ? beta[c] : 0.f;
   }
   if (mypl < ppp && myv * 8 < C) {
-    for (long long px = p0 + mypl; px < p1; px += ppp) {
-      float f[8], gg[8];
-      ld8<T>(g + ((long long)row * S + px) * g_ps + myv * 8, gg);
-      if (x != nullptr) {
-        ld8<T>(x + ((long long)row * S + px) * (long long)C + myv * 8, f);
+    // four pixels per trip: their 16-byte loads are issued together (one pixel per trip left ~4 MB in flight on the chip --
+    // latency bound at ~2 TB/s); lanes past the end re-read pixel px with a zeroed gradient
+    constexpr int U = 4;
+    for (long long px = p0 + mypl; px < p1; px += U * ppp) {
+      float f[U][8], gg[U][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float xh = __builtin_fmaf(f[j], trs[j], tnm[j]);
-          const float a = __builtin_fmaf(xh, tga[j], tbe[j]);
-          const float ga = gg[j] * (silu ? silu_grad2_f(a) : 1.0f);
-          s1[j] += ga;
-          s2[j] += ga * xh;
+      for (int u = 0; u < U; ++u) {
+        const bool ok = px + u * ppp < p1;
+        const long long q = ok ? px + u * ppp : px;
+        ld8<T>(g + ((long long)row * S + q) * g_ps + myv * 8, gg[u]);
+        if (x != nullptr) ld8<T>(x + ((long long)row * S + q) * (long long)C + myv * 8, f[u]);
+        if (!ok) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gg[u][j] = 0.f;
         }
-      } else {
+      }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s1[j] += gg[j];
+      for (int u = 0; u < U; ++u) {
+        if (x != nullptr) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = __builtin_fmaf(f[u][j], trs[j], tnm[j]);
+            const float a = __builtin_fmaf(xh, tga[j], tbe[j]);
+            const float ga = gg[u][j] * (silu ? silu_grad2_f(a) : 1.0f);
+            s1[j] += ga;
+            s2[j] += ga * xh;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) s1[j] += gg[u][j];
+        }
       }
     }
   }
@@ -410,12 +446,21 @@ __global__ __launch_bounds__(256) void chan_sums_final_kernel(const float* __res
   const int cl = threadIdx.x & 31, pl = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + cl;
   float a1 = 0.f, a2 = 0.f;
-  if (c < C)
-    for (int i = pl; i < nparts; i += 8) {
+  if (c < C) {
+    int i = pl;
+    for (; i + 24 < nparts; i += 32) {  // four loads in flight, added in index order
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float2*>(ws + ((long long)(i + 8 * u) * C + c) * 2);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a1 += v[u].x; a2 += v[u].y; }
+    }
+    for (; i < nparts; i += 8) {
       const float2 v = *reinterpret_cast<const float2*>(ws + ((long long)i * C + c) * 2);
       a1 += v.x;
       a2 += v.y;
     }
+  }
   sh[pl][cl][0] = a1;
   sh[pl][cl][1] = a2;
   __syncthreads();
@@ -431,9 +476,16 @@ __global__ __launch_bounds__(256) void chan_sums_final_kernel(const float* __res
   }
 }
 
-static inline int chan_sums_splits(long long S, int rows) {
-  long long n = (S + 1023) / 1024;
-  const long long cap = rows > 0 ? (1024 + rows - 1) / rows : 1024;
+static inline int chan_sums_splits(long long S, int rows, int C) {
+  // ~32 pixels per thread (8 trips of 4): a workgroup covers 256 / (C / 8) pixels per step, so wide tensors take short splits
+  // (at a fixed 1024 pixels per split a 512-channel tensor gave each thread 256 dependent trips and a 147 k-pixel one 144
+  // workgroups for 256 CUs)
+  const int cv = (C + 7) >> 3;
+  const int ppp = 256 / cv > 0 ? 256 / cv : 1;
+  long long per = 32ll * ppp;
+  if (per < 128) per = 128;
+  long long n = (S + per - 1) / per;
+  const long long cap = rows > 0 ? (2048 + rows - 1) / rows : 2048;
   if (n > cap) n = cap;
   return (int)(n < 1 ? 1 : n);
 }
@@ -660,7 +712,7 @@ int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, in
 
 int64_t cvvae_channel_sums_workspace_bytes(int32_t rows, int64_t S, int32_t C) {
   if (rows <= 0 || S <= 0 || C <= 0) return CVVAE_EINVAL;
-  return (int64_t)rows * chan_sums_splits(S, rows) * C * 2 * (int64_t)sizeof(float);
+  return (int64_t)rows * chan_sums_splits(S, rows, C) * C * 2 * (int64_t)sizeof(float);
 }
 
 // x == NULL: sum1[c] = sum over rows x S pixels of g (a bias gradient); else the GroupNorm affine gradients
@@ -673,7 +725,7 @@ int cvvae_channel_sums(int32_t dtype, const void* x, const void* g, int64_t g_pi
     return CVVAE_EINVAL;
   if (x && (!rstd || !nmean || !gamma || !beta || !sum2 || g_pix_stride != C)) return CVVAE_EINVAL;
   if ((C >> 3) > 256) return CVVAE_EUNSUPPORTED;
-  const int nsplit = chan_sums_splits(S, rows);
+  const int nsplit = chan_sums_splits(S, rows, C);
   float* ws = (float*)workspace;
   switch (dtype) {
     case CVVAE_BF16:

@@ -6,6 +6,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 import torch
 
@@ -23,6 +24,7 @@ def main():
     ap.add_argument("--W", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--cprofile", default=None, help="write a cProfile listing of one more step (host side) to this file")
     args = ap.parse_args()
     import cvvae_amd
     from cvvae_amd import ops
@@ -64,6 +66,7 @@ def main():
     def step():
         t = [ev() for _ in range(4)]
         m.zero_grad(set_to_none=True)
+        host.append(time.perf_counter())
         t[0].record()
         mom = m.encoder(x)
         z = mom[:, :zc].contiguous()
@@ -73,13 +76,29 @@ def main():
         loss = (xrec.float() - x.float()).pow(2).mean()
         loss.backward()
         t[3].record()
+        host.append(time.perf_counter())
         torch.cuda.synchronize()
+        host.append(time.perf_counter())
         return [t[i].elapsed_time(t[i + 1]) for i in range(3)], float(loss)
+    host = []
     step()
     ts = [step() for _ in range(args.steps)]
     enc_f = sum(t[0][0] for t in ts) / len(ts)
     dec_f = sum(t[0][1] for t in ts) / len(ts)
     bwd = sum(t[0][2] for t in ts) / len(ts)
+    h = host[3:]  # (step 0 = warm-up): per step [start, everything launched, GPU drained]
+    host_launch = sum(h[i + 1] - h[i] for i in range(0, len(h), 3)) / len(ts) * 1e3
+    host_wait = sum(h[i + 2] - h[i + 1] for i in range(0, len(h), 3)) / len(ts) * 1e3
+    if args.cprofile:
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        step()
+        pr.disable()
+        with open(args.cprofile, "w") as f:
+            pstats.Stats(pr, stream=f).sort_stats("tottime").print_stats(45)
+            pstats.Stats(pr, stream=f).sort_stats("cumtime").print_stats(45)
     with torch.no_grad():
         m.eval()
         e0, e1 = ev(), ev()
@@ -93,6 +112,7 @@ def main():
     out["train_step"] = {"encoder_forward_taped_ms": round(enc_f, 2), "decoder_forward_taped_ms": round(dec_f, 2),
                          "backward_ms": round(bwd, 2), "inference_forward_ms": round(inf, 2),
                          "backward_over_forward": round(bwd / (enc_f + dec_f), 2), "loss": ts[-1][1],
+                         "host_launch_ms": round(host_launch, 2), "host_wait_for_gpu_ms": round(host_wait, 2),
                          "parameters_with_grad": ngrad, "parameters": sum(1 for _ in m.parameters()),
                          "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
     print(json.dumps(out))
