@@ -21,7 +21,9 @@ vae3d_sd3 family:
   Upsample3D          (decoder) the adjoint of the time shuffle + frame drop (index plumbing), the 27-tap conv's gradients over the
                       nearest-upsampled operand, then `cvvae_upsample2x_sum`
 
-`Net3DFn` makes a taped forward + this backward ONE autograd node whose inputs are the clip (or latent) and the module's parameters,
+`run_trainable` makes a taped forward + this backward TWO autograd nodes over the clip (or latent) and the module's parameters --
+`Net3DBodyFn` (everything up to the last GroupNorm's input) and `Net3DTailFn` (GroupNorm + SiLU + conv_out: what
+`torch.autograd.grad(loss, get_last_layer())` of the reference's adversarial loss needs, without the body's backward) --
 so `loss(x, decoder(encoder(x)), constraint_decoder(z)).backward()` fills `<net>.<param>.grad` (modeling._Net.forward takes this path
 for a module in train() mode under grad mode).  Gradients are carried in the module's dtype with fp32 accumulation inside every
 kernel; parameter gradients are accumulated in fp32 and cast to the parameter's dtype at the end.  The walker takes every layer's
@@ -171,26 +173,30 @@ def temporal_attention_backward(wc: WeightCache, g: torch.Tensor, e: dict, grads
     return g_h
 
 
-def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False, need_params: bool = True):
-    """gy = dL/d(output) (NCDHW) of engine.sd3_encoder / engine.sd3_decoder run with `tape` -> (dL/d(input) NCDHW or None,
-    {parameter name: fp32 gradient}).  need_params = False (a FROZEN network whose input needs a gradient): the weight-gradient,
-    bias and affine launches are skipped and the dict comes back empty."""
-    dtype = wc.p("conv_in.weight").dtype
-    grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
-    last = tape[-1]
+def tail_backward(wc: WeightCache, last: dict, gy: torch.Tensor, grads: Optional[Dict[str, torch.Tensor]], need_input_grad: bool = True):
+    """backward of a network's last two layers (the `out3d` tape entry: GroupNorm + SiLU + conv_out): gy = dL/d(output) (NCDHW) ->
+    dL/dh for the entry's NDHWC input h (None when not needed and the norm is frozen); conv_out / norm gradients into `grads`"""
     assert last["op"] == "out3d"
+    dtype = wc.p("conv_in.weight").dtype
     pad, mt, mhw = last["pad"], last["mode_t"], last["mode_hw"]
     cout = wc.p("conv_out.weight").shape[0]
     g = ops.ncdhw_to_ndhwc(gy.contiguous(), ops.round_up(cout, 16), dtype)                      # [B,T',h,w,Cpad], pad channels zero
     x = last["x"]
     _conv_param_grads(wc, grads, "conv_out", lambda: ops.gn_silu_apply(x, last["g"]), g, K333, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
+    if not need_input_grad and grads is None:
+        return None
     g = dgrad333(wc, g, "conv_out", pad, mt, mhw, tuple(x.shape[:4]))
     tabs = grad._unit_tabs(wc, x, last["xp"], last["eps"])
     no = wc.norm(last["norm"])
-    g = _gn_backward(grads, last["norm"], x, g, tabs, no, True)
+    return _gn_backward(grads, last["norm"], x, g, tabs, no, True)
+
+
+def body_backward(wc: WeightCache, tape: List[dict], g: torch.Tensor, grads: Optional[Dict[str, torch.Tensor]], need_input_grad: bool):
+    """the tape without its `out3d` entry, walked backwards from g = dL/dh (NDHWC) -> dL/d(input) NCDHW or None"""
+    dtype = wc.p("conv_in.weight").dtype
     gx = None
     outer = None  # gradient of the outer residual of a spatial-temporal attention block, added after its spatial half
-    for e in reversed(tape[:-1]):
+    for e in reversed(tape):
         if e["op"] == "resnet3d":
             g = sd3_resnet_backward(wc, g, e, grads)
         elif e["op"] == "attn_t":
@@ -222,6 +228,16 @@ def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_i
                 gx = ops.ndhwc_to_ncdhw(gi, e["zin"])
         else:
             raise AssertionError(e["op"])
+    return gx
+
+
+def sd3_net_backward(wc: WeightCache, tape: List[dict], gy: torch.Tensor, need_input_grad: bool = False, need_params: bool = True):
+    """gy = dL/d(output) (NCDHW) of engine.sd3_encoder / engine.sd3_decoder run with `tape` -> (dL/d(input) NCDHW or None,
+    {parameter name: fp32 gradient}).  need_params = False (a FROZEN network whose input needs a gradient): the weight-gradient,
+    bias and affine launches are skipped and the dict comes back empty."""
+    grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
+    g = tail_backward(wc, tape[-1], gy, grads)
+    gx = body_backward(wc, tape[:-1], g, grads, need_input_grad)
     return gx, (grads if grads is not None else {})
 
 
@@ -229,39 +245,79 @@ sd3_encoder_backward = sd3_net_backward  # (the encoder's tape through the commo
 sd3_decoder_backward = sd3_net_backward
 
 
-class Net3DFn(torch.autograd.Function):
-    """(x, *parameters) -> Encoder3D(x) / Decoder3D(z): the inference launches with a tape; backward = sd3_net_backward (input and
-    parameter gradients, all on the HIP kernels)"""
+def _grads_out(names, pmeta, grads):
+    out = []
+    for name, (dt, req, shape) in zip(names, pmeta):
+        gq = grads.get(name)
+        out.append(gq.reshape(shape).to(dt) if (req and gq is not None) else None)
+    return out
+
+
+# A network is TWO autograd nodes: the body (everything up to the input h of the last GroupNorm) and the tail (GroupNorm + SiLU +
+# conv_out).  The reference's adversarial loss asks for  torch.autograd.grad(loss, decoder.get_last_layer(), retain_graph=True)  twice
+# per step (`calculate_adaptive_weight`, lvdm/modules/autoencoding/losses/discriminator_loss.py:211-220; get_last_layer =
+# conv_out.weight, vae_models3d_sd3.py:390-391): with the tail as its own node the engine runs ONLY the tail's backward for those
+# calls (one weight gradient, one input gradient, one GroupNorm backward) instead of the whole network's.  The forward is still ONE
+# pass of the inference program: the body node runs it, hands the tail's input h out as its output and parks y for the tail node.
+TAIL_PREFIXES = ("conv_out", "conv_norm_out", "norm_out")
+
+
+def _is_tail(name: str) -> bool:
+    return name.rsplit(".", 1)[0] in TAIL_PREFIXES
+
+
+class Net3DBodyFn(torch.autograd.Function):
+    """(x, *body parameters) -> h, the NDHWC input of the network's last GroupNorm (the whole inference program runs here, with a
+    tape; its output y waits in `box` for Net3DTailFn); backward = body_backward"""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, net, names: Tuple[str, ...], *params) -> torch.Tensor:
+    def forward(ctx, x: torch.Tensor, net, names: Tuple[str, ...], box: dict, *params) -> torch.Tensor:
         tape: List[dict] = []
         with torch.cuda.device(x.device):
             y = type(net)._program(net._cache(), x.detach(), dict(net._cfg), tape)
-        ctx.net, ctx.tape, ctx.names = net, tape, names
+        assert tape[-1]["op"] == "out3d" and tape[-1]["norm"] in TAIL_PREFIXES, tape[-1]["op"]
+        box["y"], box["last"] = y, tape[-1]
+        ctx.net, ctx.tape, ctx.names = net, tape[:-1], names
         ctx.x_dtype, ctx.need_x = x.dtype, x.requires_grad
         ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
-        return y
+        # (a view: autograd owns the returned tensor object, the tape keeps reading the same storage)
+        return tape[-1]["x"].view_as(tape[-1]["x"])
+
+    @staticmethod
+    def backward(ctx, gh: torch.Tensor):
+        need_params = any(req for _, req, _ in ctx.pmeta)
+        grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
+        with torch.cuda.device(gh.device):
+            gx = body_backward(ctx.net._cache(), ctx.tape, gh.contiguous(), grads, ctx.need_x)
+        return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads or {}))
+
+
+class Net3DTailFn(torch.autograd.Function):
+    """(h, *tail parameters) -> y (already computed by the body node's pass); backward = tail_backward"""
+
+    @staticmethod
+    def forward(ctx, h: torch.Tensor, net, names: Tuple[str, ...], box: dict, *params) -> torch.Tensor:
+        ctx.net, ctx.last, ctx.names = net, box.pop("last"), names
+        ctx.need_h = h.requires_grad
+        ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
+        return box.pop("y")
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
-        net = ctx.net
+        need_params = any(req for _, req, _ in ctx.pmeta)
+        grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
         with torch.cuda.device(gy.device):
-            gx, grads = sd3_net_backward(net._cache(), ctx.tape, gy, need_input_grad=ctx.need_x,
-                                         need_params=any(req for _, req, _ in ctx.pmeta))
-        out = []
-        for name, (dt, req, shape) in zip(ctx.names, ctx.pmeta):
-            gq = grads.get(name)
-            out.append(gq.reshape(shape).to(dt) if (req and gq is not None) else None)
-        return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, *out)
-
-
-Encoder3DFn = Net3DFn
+            gh = tail_backward(ctx.net._cache(), ctx.last, gy, grads, need_input_grad=ctx.need_h)
+        return (gh if ctx.need_h else None, None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads or {}))
 
 
 def run_trainable(net, x: torch.Tensor, kwargs: dict) -> torch.Tensor:
-    """modeling._Net.forward for a module in train() mode under grad mode: one autograd node over (x, parameters)"""
+    """modeling._Net.forward for a module in train() mode under grad mode: two autograd nodes over (x, parameters) -- body and tail"""
     if kwargs:
         raise NotImplementedError(f"training-mode forward takes no extra arguments (got {sorted(kwargs)})")
     named = [(n, p) for n, p in net.named_parameters()]
-    return Net3DFn.apply(x, net, tuple(n for n, _ in named), *[p for _, p in named])
+    body = [(n, p) for n, p in named if not _is_tail(n)]
+    tail = [(n, p) for n, p in named if _is_tail(n)]
+    box: dict = {}
+    h = Net3DBodyFn.apply(x, net, tuple(n for n, _ in body), box, *[p for _, p in body])
+    return Net3DTailFn.apply(h, net, tuple(n for n, _ in tail), box, *[p for _, p in tail])

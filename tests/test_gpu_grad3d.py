@@ -324,3 +324,36 @@ def test_training_step_chain_through_the_frozen_constraint_decoder(dtype):
     _log(f"[training chain {str(dtype)[6:]}] loss(constraint_decoder(encoder(x))): xrec rel {rel(y, yr):.2e}; encoder parameter "
          f"gradients worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
     assert errs[0][0] <= 2 * NET_W_TOL[dtype], errs[:5]
+
+
+def test_last_layer_gradient_probe_before_the_backward():
+    """torch.autograd.grad(loss, decoder.get_last_layer(), retain_graph=True) -- the reference's adaptive adversarial weight,
+    lvdm/modules/autoencoding/losses/discriminator_loss.py:211-220 -- runs the tail node alone (GroupNorm + SiLU + conv_out), twice,
+    then the step's real backward: the probe equals the conv_out.weight gradient of a full backward on the same cotangent, bit for
+    bit (same launches), and the full backward after the probes still fills every parameter"""
+    import cvvae_amd
+    from cvvae_amd import ops
+    dtype = torch.bfloat16
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 8)
+    m.load_state_dict(sd, strict=True)
+    dec = m.decoder.to(dtype).cuda().train()
+    z = seeded_input((1, 16, 3, 8, 12), 13).to(dtype).cuda()
+    calls = []
+    real = ops.conv_wgrad
+    ops.conv_wgrad = lambda *a, **k: (calls.append(1), real(*a, **k))[1]
+    try:
+        y = dec(z.clone().requires_grad_(True))
+        cot = seeded_input(tuple(y.shape), 5).cuda().to(y.dtype)
+        loss = (y.float() * cot.float()).sum()
+        g1 = torch.autograd.grad(loss, dec.get_last_layer(), retain_graph=True)[0]
+        assert len(calls) == 1, len(calls)
+        g2 = torch.autograd.grad(loss, dec.get_last_layer(), retain_graph=True)[0]
+        assert torch.equal(g1, g2)
+        loss.backward()
+    finally:
+        ops.conv_wgrad = real
+    assert torch.equal(dec.conv_out.weight.grad, g1)
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in dec.parameters())
+    _log(f"[last-layer probe] conv_out.weight gradient alone: 1 weight-gradient launch (a full backward: {len(calls) - 2}); "
+        f"probe == full backward's conv_out.weight.grad bit for bit")

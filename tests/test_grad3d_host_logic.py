@@ -182,3 +182,43 @@ def test_frozen_network_gives_the_input_gradient_only():
     assert not calls, calls
     assert _rel(za.grad, zr.grad) < 1e-4
     assert all(p.grad is None for p in dec.parameters())
+
+
+def test_last_layer_gradient_runs_only_the_tail():
+    """the reference's adaptive adversarial weight asks  torch.autograd.grad(loss, decoder.get_last_layer(), retain_graph=True)  twice
+    per step before the real backward (lvdm/modules/autoencoding/losses/discriminator_loss.py:211-220): the tail (GroupNorm + SiLU +
+    conv_out) is its own autograd node, so those calls launch ONE weight gradient -- and the full backward afterwards still gives
+    every gradient (retain_graph: the tape is not consumed)"""
+    import cvvae_amd
+    from cvvae_amd import ops
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 8)
+    m.load_state_dict(sd, strict=True)
+    dec = m.decoder.train()
+    ref_sd = {k: v.float().clone().requires_grad_(True) for k, v in sd.items() if k.startswith("decoder.")}
+    z = seeded_input((1, 16, 3, 4, 6), 13)
+    zr = z.clone().requires_grad_(True)
+    yr = O.sd3_decoder(zr, ref_sd, dict(block_out_channels=SMALL["block_out_channels"], layers_per_block=1))
+    cot = seeded_input(tuple(yr.shape), 5)
+    cot2 = seeded_input(tuple(yr.shape), 6)
+    ref_last = torch.autograd.grad((yr * cot2).sum(), ref_sd["decoder.conv_out.weight"], retain_graph=True)[0]
+    (yr * cot).sum().backward()
+    with emu_ops.patched(whole_model=True):
+        calls = []
+        real_wgrad = ops.conv_wgrad
+        ops.conv_wgrad = lambda *a, **k: (calls.append("conv_wgrad"), real_wgrad(*a, **k))[1]
+        za = z.clone().requires_grad_(True)
+        ya = dec(za)
+        last = dec.get_last_layer()
+        assert last is dec.conv_out.weight
+        g1 = torch.autograd.grad((ya * cot2).sum(), last, retain_graph=True)[0]
+        assert calls == ["conv_wgrad"], calls                     # the tail's weight gradient and nothing of the body
+        g2 = torch.autograd.grad((ya * cot2).sum(), last, retain_graph=True)[0]
+        assert torch.equal(g1, g2) and len(calls) == 2
+        assert _rel(g1, ref_last) < 2e-4
+        (ya * cot).sum().backward()                                # the step's real backward, after the two probes
+    assert _rel(za.grad, zr.grad) < 1e-4
+    scale = max(float(v.grad.norm()) for v in ref_sd.values())
+    for n, p in dec.named_parameters():
+        assert p.grad is not None, n
+        assert _rel(p.grad, ref_sd["decoder." + n].grad, 1e-4 * scale) < 2e-4, n
