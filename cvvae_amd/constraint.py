@@ -73,6 +73,8 @@ class Decoder(_Net):
                 raise NotImplementedError("only the frozen decoder's input gradient is built (the reference calls "
                                           "constraint_decoder.requires_grad_(False)); weight gradients are not")
             from .grad import ConstraintDecoderFn
+            from .modeling import _autocast_dtype
+            self._cache().compute_dtype = _autocast_dtype(z) if self.conv_in.weight.dtype == torch.float32 else None
             return ConstraintDecoderFn.apply(z, self)
         return _Net.forward(self, z)
 

@@ -40,6 +40,11 @@ class WeightCache:
         # default-initialised norms (8) and on spread affines up to ~14 (tests/test_gpu_fast_fp32.py); norms whose bound exceeds this
         # cap keep the bf8 form, which needs no scale.  (No real checkpoint can be measured here: DESIGN.md section 4.)
         self.fp6_bound_cap = float(os.environ.get("CVVAE_F32_FP6_CAP", "16"))
+        # torch.autocast over an fp32 model (mixed-precision training / inference: fp32 master weights, 16-bit compute): p() then hands
+        # out 16-bit COPIES of the weight tensors (dim >= 2: conv kernels, linear layers), refreshed in place when the master changes;
+        # biases and norm affines stay the fp32 masters (the kernels take them as fp32 anyway).  Set by modeling._Net.forward.
+        self.compute_dtype: Optional[torch.dtype] = None
+        self._cast: Dict[str, list] = {}        # name -> [16-bit copy, key of the master it was made from]
 
     def _q(self) -> str:
         return "#q" if self.fast else ""
@@ -59,6 +64,18 @@ class WeightCache:
         par = hit[0].get(hit[1])
         if par is None:
             raise AttributeError(f"{type(self.m).__name__} has no parameter {name}")
+        cd = self.compute_dtype
+        if cd is not None and par.dtype == torch.float32 and par.dim() >= 2:
+            mkey = (par.data_ptr(), par._version, par.device)
+            c = self._cast.get(name)
+            if c is None or c[0].dtype != cd or c[0].device != par.device or c[0].shape != par.shape:
+                c = self._cast[name] = [par.detach().to(cd), mkey]
+            elif c[1] != mkey:
+                # in place: the copy keeps its storage and its _version moves on, so every packed form keyed on (data_ptr, _version)
+                # is rebuilt -- a fresh tensor could land on the freed copy's address with _version 0 and look unchanged
+                c[0].copy_(par.detach())
+                c[1] = mkey
+            return c[0]
         return par
 
     def act_bound(self, norm_pre: str, sigmas: float = 8.0) -> float:
@@ -291,7 +308,7 @@ def switches_key(wc=None) -> tuple:
     so that flipping one in a live process re-captures instead of replaying the other setting's graph"""
     return (fold_upsample(), fold_t1(), fuse_shortcut(), fold_time(), rowpack_conv_in(), tapsn_conv_out(), fused_attention(),
             per_frame_stats_from_records(), os.environ.get("CVVAE_PREPASS", "auto"), os.environ.get("CVVAE_CONV_FORCE", ""),
-            None if wc is None else (wc.fast, wc.fast6, wc.fp6_bound_cap))
+            None if wc is None else (wc.fast, wc.fast6, wc.fp6_bound_cap, str(wc.compute_dtype)))
 
 
 def fold_upsample() -> bool:

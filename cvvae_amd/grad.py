@@ -147,6 +147,7 @@ class ConstraintDecoderFn(torch.autograd.Function):
         with torch.cuda.device(z.device):
             y = engine.constraint_decoder2d(net._cache(), z.detach(), net._cfg, tape)
         ctx.net, ctx.tape, ctx.zdtype = net, tape, z.dtype
+        ctx.cd = net._cache().compute_dtype  # (torch.autocast: the backward thread runs outside the context -- same weights, same dtype)
         return y
 
     @staticmethod
@@ -155,5 +156,6 @@ class ConstraintDecoderFn(torch.autograd.Function):
         # the tape (block inputs, statistics records, attention operands) is kept until autograd frees the node, so a second
         # backward through it (retain_graph=True, two losses) walks the same tape and gives the same bits
         with torch.cuda.device(gy.device):
+            net._cache().compute_dtype = ctx.cd
             gz = constraint_decoder2d_backward(net._cache(), tape, gy)
         return gz.to(ctx.zdtype), None

@@ -278,6 +278,7 @@ class Net3DBodyFn(torch.autograd.Function):
         assert tape[-1]["op"] == "out3d" and tape[-1]["norm"] in TAIL_PREFIXES, tape[-1]["op"]
         box["y"], box["last"] = y, tape[-1]
         ctx.net, ctx.tape, ctx.names = net, tape[:-1], names
+        ctx.cd = box["cd"] = net._cache().compute_dtype  # (autocast: the backward runs outside the context -- same 16-bit weight copies)
         ctx.x_dtype, ctx.need_x = x.dtype, x.requires_grad
         ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
         # (a view: autograd owns the returned tensor object, the tape keeps reading the same storage)
@@ -288,6 +289,7 @@ class Net3DBodyFn(torch.autograd.Function):
         need_params = any(req for _, req, _ in ctx.pmeta)
         grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
         with torch.cuda.device(gh.device):
+            ctx.net._cache().compute_dtype = ctx.cd
             gx = body_backward(ctx.net._cache(), ctx.tape, gh.contiguous(), grads, ctx.need_x)
         return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads or {}))
 
@@ -297,7 +299,7 @@ class Net3DTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, h: torch.Tensor, net, names: Tuple[str, ...], box: dict, *params) -> torch.Tensor:
-        ctx.net, ctx.last, ctx.names = net, box.pop("last"), names
+        ctx.net, ctx.last, ctx.names, ctx.cd = net, box.pop("last"), names, box.pop("cd")
         ctx.need_h = h.requires_grad
         ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
         return box.pop("y")
@@ -307,6 +309,7 @@ class Net3DTailFn(torch.autograd.Function):
         need_params = any(req for _, req, _ in ctx.pmeta)
         grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
         with torch.cuda.device(gy.device):
+            ctx.net._cache().compute_dtype = ctx.cd
             gh = tail_backward(ctx.net._cache(), ctx.last, gy, grads, need_input_grad=ctx.need_h)
         return (gh if ctx.need_h else None, None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads or {}))
 

@@ -56,6 +56,21 @@ def _resnet(cin: int, cout: int, shortcut_name: str, shortcut_k: Tuple[int, ...]
     return m
 
 
+def _autocast_dtype(x: torch.Tensor) -> Optional[torch.dtype]:
+    """the active GPU autocast dtype (float16 / bfloat16), or None outside torch.autocast"""
+    try:
+        on = torch.is_autocast_enabled("cuda")
+    except TypeError:  # older signature
+        on = torch.is_autocast_enabled()
+    if not on:
+        return None
+    try:
+        dt = torch.get_autocast_dtype("cuda")
+    except AttributeError:
+        dt = torch.get_autocast_gpu_dtype()
+    return dt if dt in (torch.float16, torch.bfloat16) else None
+
+
 class _Net(nn.Module):
     """Base of the four encoder/decoder modules: parameters + a WeightCache + `forward` on NCDHW tensors."""
 
@@ -92,6 +107,9 @@ class _Net(nn.Module):
 
     def forward(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         self._check_input(x)
+        # torch.autocast over an fp32 model (the reference's trainer with precision 16 / bf16: fp32 master weights, 16-bit compute;
+        # main.py:905-912): the pass runs on 16-bit copies of the weights and returns the autocast dtype, as F.conv3d would
+        self._cache().compute_dtype = _autocast_dtype(x) if self.conv_in.weight.dtype == torch.float32 else None
         if (self._trainable and self.training and torch.is_grad_enabled()
                 and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             # training the codec itself (lvdm/models/autoencoder.py:1057-1090 runs the 3-D networks under autograd): the same

@@ -222,3 +222,52 @@ def test_last_layer_gradient_runs_only_the_tail():
     for n, p in dec.named_parameters():
         assert p.grad is not None, n
         assert _rel(p.grad, ref_sd["decoder." + n].grad, 1e-4 * scale) < 2e-4, n
+
+
+def test_autocast_runs_an_fp32_model_on_16_bit_weight_copies():
+    """torch.autocast over an fp32 model (the reference's trainer at precision 16 / bf16, main.py:905-912: fp32 master weights, 16-bit
+    compute): the pass runs on 16-bit COPIES of the weight tensors (biases and norm affines stay fp32), returns the autocast dtype,
+    the gradients come back in fp32 for the masters, the backward -- which autograd runs OUTSIDE the autocast context -- uses the same
+    copies, and an optimizer step on the masters refreshes the copies.  Checked against a model that HOLDS those 16-bit weights."""
+    import copy
+
+    import cvvae_amd
+    from cvvae_amd import modeling
+    m = cvvae_amd.CVVAESD3Model(**SMALL)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 7)
+    m.load_state_dict(sd, strict=True)
+    m16 = copy.deepcopy(m)
+    for p in m16.parameters():
+        if p.dim() >= 2:
+            p.data = p.data.to(torch.bfloat16)
+    x = seeded_input((1, 3, 5, 16, 24), 11)
+    saved = modeling._autocast_dtype
+    with emu_ops.patched(whole_model=True):
+        enc, enc16 = m.encoder.train(), m16.encoder.train()
+        xa = x.to(torch.bfloat16).requires_grad_(True)
+        y16 = enc16(xa)
+        cot = seeded_input(tuple(y16.shape), 4)
+        (y16.float() * cot).sum().backward()
+        try:
+            modeling._autocast_dtype = lambda x: torch.bfloat16      # "inside torch.autocast(dtype=bfloat16)"
+            xb = x.clone().requires_grad_(True)
+            y = enc(xb)
+            assert y.dtype == torch.bfloat16 and torch.equal(y, y16)
+            assert enc.conv_in.weight.dtype == torch.float32           # the masters are untouched
+            modeling._autocast_dtype = lambda x: None                 # autograd's backward thread: no autocast state
+            (y.float() * cot).sum().backward()
+            assert xb.grad.dtype == torch.float32 and torch.equal(xb.grad.to(torch.bfloat16), xa.grad)
+            for (n, p), (_, q) in zip(enc.named_parameters(), enc16.named_parameters()):
+                assert p.grad is not None and p.grad.dtype == torch.float32, n
+                assert torch.equal(p.grad.to(q.grad.dtype), q.grad), n   # (16-bit holder: its gradient is this one, rounded)
+            with torch.no_grad():                                      # an optimizer step on the fp32 masters
+                for p, q in zip(enc.parameters(), enc16.parameters()):
+                    p.add_(1e-3 * p.grad / (p.grad.abs().max() + 1e-12))
+                    q.copy_(p)
+            modeling._autocast_dtype = lambda x: torch.bfloat16
+            y2 = enc(x)
+            assert torch.equal(y2, enc16(x.to(torch.bfloat16))) and not torch.equal(y2, y)
+            modeling._autocast_dtype = lambda x: None                 # outside autocast: the fp32 model again
+            assert enc.eval()(x).dtype == torch.float32
+        finally:
+            modeling._autocast_dtype = saved

@@ -24,6 +24,9 @@ def main():
     ap.add_argument("--W", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f16", "f32"])
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--autocast", default=None, choices=["bf16", "f16"],
+                    help="with --dtype f32: run the step under torch.autocast (fp32 master weights, 16-bit launches) and nudge the "
+                         "masters between steps as an optimizer would (so every step re-casts and re-packs the weights)")
     ap.add_argument("--cprofile", default=None, help="write a cProfile listing of one more step (host side) to this file")
     args = ap.parse_args()
     import cvvae_amd
@@ -68,10 +71,11 @@ def main():
         m.zero_grad(set_to_none=True)
         host.append(time.perf_counter())
         t[0].record()
-        mom = m.encoder(x)
-        z = mom[:, :zc].contiguous()
-        t[1].record()
-        xrec = m.decoder(z)
+        with torch.autocast("cuda", dtype=acd or torch.bfloat16, enabled=acd is not None):
+            mom = m.encoder(x)
+            z = mom[:, :zc].contiguous()
+            t[1].record()
+            xrec = m.decoder(z)
         t[2].record()
         loss = (xrec.float() - x.float()).pow(2).mean()
         loss.backward()
@@ -79,8 +83,15 @@ def main():
         host.append(time.perf_counter())
         torch.cuda.synchronize()
         host.append(time.perf_counter())
+        if acd is not None:
+            with torch.no_grad():  # (an SGD-sized nudge of the masters: the next step sees changed weights)
+                for p in m.parameters():
+                    p.add_(p.grad, alpha=-1e-6)
+            torch.cuda.synchronize()
         return [t[i].elapsed_time(t[i + 1]) for i in range(3)], float(loss)
     host = []
+    acd = {"bf16": torch.bfloat16, "f16": torch.float16, None: None}[args.autocast]
+    out["autocast"] = args.autocast
     step()
     ts = [step() for _ in range(args.steps)]
     enc_f = sum(t[0][0] for t in ts) / len(ts)
@@ -99,7 +110,7 @@ def main():
         with open(args.cprofile, "w") as f:
             pstats.Stats(pr, stream=f).sort_stats("tottime").print_stats(45)
             pstats.Stats(pr, stream=f).sort_stats("cumtime").print_stats(45)
-    with torch.no_grad():
+    with torch.no_grad(), torch.autocast("cuda", dtype=acd or torch.bfloat16, enabled=acd is not None):
         m.eval()
         e0, e1 = ev(), ev()
         m.decoder(m.encoder(x)[:, :zc].contiguous())
