@@ -270,3 +270,54 @@ def test_sharding_on_a_subgroup():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(a and b for _, a, b in res), res
+
+
+def _worker_ddp(rank, world, port, q):
+    """the trainable encoder (kernels emulated on the CPU) under DistributedDataParallel, as the reference's trainer wraps its
+    autoencoder (`strategy: ddp`): each rank a different clip; the gradients DDP leaves in .grad must be the MEAN over the ranks
+    of the single-process gradients -- i.e. the parameter gradients our autograd nodes return go through AccumulateGrad and DDP's
+    bucket all-reduce like any other"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import cvvae_amd
+        from oracle.seeded import seeded_input, seeded_state_dict
+        from tests import emu_ops
+        torch.set_num_threads(2)
+        small = dict(block_out_channels=[128, 256], layers_per_block=1)
+        m = cvvae_amd.CVVAESD3Model(**small)
+        m.load_state_dict(seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 7), strict=True)
+        enc = m.encoder.train()
+        xs = [seeded_input((1, 3, 3, 8, 8), 20 + r) for r in range(world)]
+        with emu_ops.patched(whole_model=True):
+            # single-process reference: gradient of each rank's loss, averaged
+            ref = {n: torch.zeros_like(p) for n, p in enc.named_parameters()}
+            for xr in xs:
+                enc.zero_grad(set_to_none=True)
+                enc(xr).float().pow(2).mean().backward()
+                for n, p in enc.named_parameters():
+                    ref[n] += p.grad / world
+            enc.zero_grad(set_to_none=True)
+            ddp = torch.nn.parallel.DistributedDataParallel(enc)
+            ddp(xs[rank]).float().pow(2).mean().backward()
+            worst = max(float((p.grad - ref[n]).abs().max() / ref[n].abs().max().clamp_min(1e-20)) for n, p in enc.named_parameters())
+            have = all(p.grad is not None for p in enc.parameters())
+        q.put((rank, have, worst))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_trainable_encoder_under_ddp_over_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ddp, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, have, worst in res:
+        assert have and worst < 1e-5, (rank, have, worst)
