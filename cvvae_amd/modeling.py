@@ -113,7 +113,7 @@ class _Net(nn.Module):
         if (self._trainable and self.training and torch.is_grad_enabled()
                 and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
             # training the codec itself (lvdm/models/autoencoder.py:1057-1090 runs the 3-D networks under autograd): the same
-            # launches with a tape, one autograd node over (x, parameters).  eval() mode / no_grad: the inference pass below
+            # launches with a tape, two autograd nodes (body + tail) over (x, parameters).  eval() mode / no_grad: the inference pass below
             from . import grad3d
             return grad3d.run_trainable(self, x, kwargs)
         with torch.no_grad():
@@ -186,7 +186,7 @@ def _sd3_mid(c: int, attention: bool) -> nn.Module:
 
 class Encoder3D(_Net):
     _program = staticmethod(engine.sd3_encoder)
-    _trainable = True  # train() mode under grad mode: the taped pass + grad3d.sd3_encoder_backward as one autograd node
+    _trainable = True  # train() mode under grad mode: the taped pass + grad3d's body / tail backward as two autograd nodes
 
     def __init__(self, in_channels=3, out_channels=16, block_out_channels=(128, 256, 512, 512), layers_per_block=2,
                  double_z=True, mid_block_add_attention=True, causal=True, **_):
