@@ -67,6 +67,28 @@ DEC_CASES = {
 }
 
 
+# BACKWARD fixtures at the size tools/train_step_bench.py times (round 5): the reference's OWN Encoder3D / Decoder3D (the full
+# 4-level, layers_per_block = 2 networks of CVVAESD3Model) under torch.autograd on one 17-frame 256x256 crop, loss = <output, seeded
+# cotangent>.  Stored: the forward output and dL/d(input) at stride s (recon_subsample's per-frame phase), and per parameter tensor
+# the gradient's L2 norm plus a seeded sample of <= 4096 elements (grad_sample_index).
+# name -> (family, config overrides, pixel shape, weight seed, input seed, cotangent seeds (enc, dec), latent seed, strides (dx, dz))
+GRAD_CASES = {
+    "grad_sd3_t17_256": ("sd3", {}, (1, 3, 17, 256, 256), 0, 31, (32, 33), 34, (4, 1)),
+}
+
+
+def grad_sample_index(name: str, numel: int, n: int = 4096):
+    """the flat indices of parameter `name`'s stored gradient sample: all of them for tensors of <= n elements, else n seeded ones"""
+    import zlib
+
+    import torch
+    if numel <= n:
+        return torch.arange(numel)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(zlib.crc32(name.encode()) + 977)
+    return torch.randint(0, numel, (n,), generator=g)
+
+
 def recon_subsample(recon, s: int):
     """recon [B,C,T,H,W] (numpy or torch) -> [B,C,T,H//s,W//s]: frame t sampled at rows (t % s)::s, columns (3t % s)::s (cropped to
     the common H//s x W//s when s does not divide the frame: the phases would otherwise differ in length)"""

@@ -207,8 +207,71 @@ def main_dec(only=None):
               f"({torch.get_num_threads()} threads)", flush=True)
 
 
+def main_grad(only=None):
+    """BACKWARD fixtures from the reference's own Encoder3D / Decoder3D under torch.autograd (golden_cases.GRAD_CASES): the
+    training step of /root/reference/lvdm/models/autoencoder.py:1057-1090 differentiates exactly these modules
+    (models/vae_models3d_sd3.py:162-208, 323-388).  eval() mode: the modules' torch.utils.checkpoint wrapping (train() mode)
+    recomputes the same ops and gives the same gradients; dropout is 0."""
+    import time
+
+    from oracle.golden_cases import GRAD_CASES, grad_sample_index, recon_subsample
+
+    ref = load_reference()
+    out_dir = os.path.join(os.path.dirname(HERE), "tests", "golden")
+    for name, (family, over, shape, wseed, xseed, cseeds, zseed, strides) in GRAD_CASES.items():
+        if only and name not in only:
+            continue
+        cls = ref.CVVAESD3Model if family == "sd3" else ref.CVVAEModel
+        model = cls(**over).eval()
+        sd = seeded_state_dict({k: v.shape for k, v in model.state_dict().items()}, wseed)
+        model.load_state_dict(sd, strict=True)
+        wsum = float(sum(v.double().abs().sum() for v in sd.values()))
+        out = dict(weight_abs_sum=np.float64(wsum), n_tensors=np.int64(len(sd)), ref_cpu_threads=np.int64(torch.get_num_threads()))
+        secs = []
+        for part, net, inp, cseed, s in (
+                ("enc", model.encoder, seeded_input(shape, xseed), cseeds[0], strides[0]),
+                ("dec", model.decoder, None, cseeds[1], strides[1])):
+            if inp is None:  # the decoder is differentiated at a SEEDED latent of the encoder's output geometry
+                zc = out["enc_out_shape"][1] // 2 if family == "sd3" else out["enc_out_shape"][1] // 2
+                inp = seeded_input((shape[0], int(zc)) + tuple(int(v) for v in out["enc_out_shape"][2:]), zseed)
+            for p in net.parameters():
+                p.grad = None
+            x = inp.clone().requires_grad_(True)
+            t0 = time.time()
+            y = net(x)
+            cot = seeded_input(tuple(y.shape), cseed)
+            (y * cot).sum().backward()
+            secs.append(time.time() - t0)
+            out[part + "_out_shape"] = np.asarray(y.shape, dtype=np.int64)
+            yd = y.detach()
+            out[part + "_out_sub"] = (recon_subsample(yd, 4) if part == "dec" else yd).numpy().astype(np.float32)
+            out[part + "_out_stride"] = np.int64(4 if part == "dec" else 1)
+            gx = x.grad.detach()
+            out[part + "_gin_sub"] = (recon_subsample(gx, s) if s > 1 else gx).numpy().astype(np.float32)
+            out[part + "_gin_stride"] = np.int64(s)
+            out[part + "_gin_norm"] = np.float64(gx.double().norm())
+            names = sorted(n for n, _ in net.named_parameters())
+            pars = dict(net.named_parameters())
+            norms, samples = [], []
+            for n in names:
+                g = pars[n].grad.detach().flatten()
+                norms.append(float(g.double().norm()))
+                samples.append(g[grad_sample_index(n, g.numel())].numpy().astype(np.float32))
+            out[part + "_param_names"] = np.asarray(names)
+            out[part + "_param_grad_norm"] = np.asarray(norms, dtype=np.float64)
+            out[part + "_param_grad_sample"] = np.concatenate(samples)
+            out[part + "_param_sample_len"] = np.asarray([len(v) for v in samples], dtype=np.int64)
+            print(f"{name} {part}: in {tuple(inp.shape)} out {tuple(y.shape)} |dL/din| {float(gx.norm()):.4e} {len(names)} parameter "
+                  f"tensors, reference CPU fp32 forward+backward {secs[-1]:.1f}s ({torch.get_num_threads()} threads)", flush=True)
+            del y, x, cot
+        out["ref_cpu_seconds"] = np.asarray(secs)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **out)
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "dec":
+    if len(sys.argv) > 1 and sys.argv[1] == "grad":
+        main_grad(sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "dec":
         main_dec(sys.argv[2:])
     elif len(sys.argv) > 1 and sys.argv[1] == "enc":
         main_enc(sys.argv[2:])
