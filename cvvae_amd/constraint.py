@@ -74,8 +74,8 @@ class Decoder(_Net):
                                           "constraint_decoder.requires_grad_(False)); weight gradients are not")
             from .grad import ConstraintDecoderFn
             from .modeling import _autocast_dtype
-            self._cache().compute_dtype = _autocast_dtype(z) if self.conv_in.weight.dtype == torch.float32 else None
-            return ConstraintDecoderFn.apply(z, self)
+            with self._cache().computing_in(_autocast_dtype(z) if self.conv_in.weight.dtype == torch.float32 else None):
+                return ConstraintDecoderFn.apply(z, self)
         return _Net.forward(self, z)
 
     def forward(self, sample: torch.Tensor, latent_embeds=None) -> torch.Tensor:

@@ -111,6 +111,7 @@ def _run_windows(fn, x: torch.Tensor, stride: int, first_is_global_first: bool) 
     return torch.cat(outs, dim=2)
 
 
+@torch.no_grad()  # (inference entry points: a module left in train() mode must not take the taped training path here)
 def _sharded(model, x: torch.Tensor, T_total: int, encode: bool, time_sharded: bool, gather: bool, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     stride = model.encode_n_frames_a_time if encode else model.decode_n_frames_a_time
@@ -165,6 +166,7 @@ def decode_windows_sharded(model, z: torch.Tensor, T_total: Optional[int] = None
     return _sharded(model, z, z.shape[2] if T_total is None else T_total, False, time_sharded, gather, group)
 
 
+@torch.no_grad()  # (inference entry points: a module left in train() mode must not take the taped training path here)
 def codec_step_time_sharded(model, x_local: torch.Tensor, T_total: int, group=None):
     """encode + decode of ONE clip whose frames arrive sharded on time (rank r holds `owned_frames(T_total, 16, world, r)`):
     the step `bench.py --gpus N` times and the gloo / RCCL tests check.
@@ -249,6 +251,7 @@ def unit_plan(model, shape, encode: bool, world: int):
     return wins, grid, units, owner, wowner
 
 
+@torch.no_grad()  # (inference entry points: a module left in train() mode must not take the taped training path here)
 def _units_sharded(model, x: torch.Tensor, encode: bool, gather: bool, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     wins, grid, units, owner, wowner = unit_plan(model, x.shape, encode, world)

@@ -49,6 +49,53 @@ class WeightCache:
     def _q(self) -> str:
         return "#q" if self.fast else ""
 
+    # ---- staleness.  Every cached form is keyed on its source parameters' (data_ptr, _version, dtype, device): load_state_dict,
+    #      optimizer steps, .to() / .cuda() and assignment all move the key.  A write through `.data` does NOT (`p.data.copy_(...)`
+    #      leaves `p._version` alone) -- which is exactly how the reference's EMA swaps weights for validation / log_images
+    #      (LitEma.copy_to / restore, /root/reference/lvdm/modules/ema.py:61-86).  Three answers, cheapest first:
+    #        * invalidate(): drop everything (the caller knows it wrote through .data): `model.refresh_weights()`;
+    #        * guard(): one fused device-side checksum over the masters, compared with the last one -- run by the TRAINING path
+    #          (grad3d.run_trainable) before every taped pass, where a sync per step is free; opt-in for inference (`weight_guard`);
+    #        * nothing, for the inference path's default: its weights come from from_pretrained / load_state_dict.
+    def invalidate(self):
+        """forget every packed / converted form (call after writing parameters through `.data`, e.g. an EMA swap)"""
+        self._c.clear()
+        for c in self._cast.values():
+            c[1] = None  # the 16-bit copies keep their storage and are refreshed in place on the next p()
+        self._sum = None
+
+    def guard(self) -> bool:
+        """compare a checksum (per-tensor L1 and L2 norms, one fused launch each, ONE host sync) of the module's parameters with the
+        one taken at the previous call; on a difference drop every cached form.  Returns True when the cache was dropped."""
+        ps = [p.detach() for p in self.m.parameters()]
+        if not ps:
+            return False
+        with torch.no_grad():
+            cur = torch.stack(list(torch._foreach_norm(ps, 1)) + list(torch._foreach_norm(ps, 2))).double()
+        last = getattr(self, "_sum", None)
+        # (no previous checksum: forms packed before the first guarded pass cannot be vouched for)
+        changed = (bool(self._c) or bool(self._cast)) if last is None else (
+            last.shape != cur.shape or last.device != cur.device or not torch.equal(last, cur))
+        if changed:
+            self.invalidate()
+        self._sum = cur
+        return changed
+
+    def computing_in(self, dtype: Optional[torch.dtype]):
+        """context manager: `compute_dtype` = dtype inside, the previous value afterwards (the dtype is per PASS, not per cache: a
+        backward under autocast must not leave later export_packed / direct engine calls looking at the 16-bit copies)"""
+        wc = self
+
+        class _Ctx:
+            def __enter__(self_):
+                self_.prev = wc.compute_dtype
+                wc.compute_dtype = dtype
+
+            def __exit__(self_, *exc):
+                wc.compute_dtype = self_.prev
+                return False
+        return _Ctx()
+
     def p(self, name: str) -> torch.nn.Parameter:
         """the module tree's parameter `name`, as nn.Module.get_parameter -- which walks the dotted path on every call (7 us each,
         ~4 lookups per conv launch: 2.7 ms of host time per encode + decode, more than the GPU time of an image-mode pass).  The
@@ -237,6 +284,9 @@ class WeightCache:
         in the cache (the forms a pass actually used: run the shapes of interest once before exporting)"""
         import dataclasses
         out = {}
+        if self.compute_dtype is not None:  # (fingerprints and keys are those of the MASTER parameters, never of autocast copies)
+            with self.computing_in(None):
+                return self.export_packed()
         for tag, ent in self._c.items():
             if len(ent) < 3 or not dataclasses.is_dataclass(ent[1]):
                 continue  # norm tables / summed biases: cheaper to rebuild than to read
@@ -254,6 +304,9 @@ class WeightCache:
         """install the exported entries whose source parameters still have the recorded fingerprints (shape, dtype, three
         moments) on this module; the rest is packed on demand as usual.  Returns the number installed."""
         n = 0
+        if self.compute_dtype is not None:
+            with self.computing_in(None):
+                return self.import_packed(blob)
         for tag, e in blob.items():
             try:
                 ps = [self.p(nm) for nm in e["names"]]

@@ -155,7 +155,6 @@ class ConstraintDecoderFn(torch.autograd.Function):
         net, tape = ctx.net, ctx.tape
         # the tape (block inputs, statistics records, attention operands) is kept until autograd frees the node, so a second
         # backward through it (retain_graph=True, two losses) walks the same tape and gives the same bits
-        with torch.cuda.device(gy.device):
-            net._cache().compute_dtype = ctx.cd
+        with torch.cuda.device(gy.device), net._cache().computing_in(ctx.cd):
             gz = constraint_decoder2d_backward(net._cache(), tape, gy)
         return gz.to(ctx.zdtype), None

@@ -266,6 +266,23 @@ def _is_tail(name: str) -> bool:
     return name.rsplit(".", 1)[0] in TAIL_PREFIXES
 
 
+# The backward reads the weights LIVE (packed input-gradient forms, norm affines) instead of saving them on the tape.  PyTorch's own
+# conv backward would raise "one of the variables needed for gradient computation has been modified by an inplace operation" when
+# a parameter changes between forward and backward (an optimizer.step() under retain_graph, a GAN's generator / discriminator
+# alternation on one graph); so does this one: the parameters' (storage, version) are remembered by the forward and checked.
+def _remember_versions(ctx, params):
+    ctx.pobj = params
+    ctx.pver = [(p.data_ptr(), p._version) for p in params]
+
+
+def _check_unmodified(ctx):
+    for name, p, was in zip(ctx.names, ctx.pobj, ctx.pver):
+        if (p.data_ptr(), p._version) != was:
+            raise RuntimeError(f"parameter {name} of {type(ctx.net).__name__} was modified (in place, or replaced) between the forward "
+                               f"and this backward pass: the taped activations belong to the old weights (version {was[1]} -> "
+                               f"{p._version}).  Run the backward before optimizer.step(), or re-run the forward.")
+
+
 class Net3DBodyFn(torch.autograd.Function):
     """(x, *body parameters) -> h, the NDHWC input of the network's last GroupNorm (the whole inference program runs here, with a
     tape; its output y waits in `box` for Net3DTailFn); backward = body_backward"""
@@ -281,6 +298,7 @@ class Net3DBodyFn(torch.autograd.Function):
         ctx.cd = box["cd"] = net._cache().compute_dtype  # (autocast: the backward runs outside the context -- same 16-bit weight copies)
         ctx.x_dtype, ctx.need_x = x.dtype, x.requires_grad
         ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
+        _remember_versions(ctx, params)
         # (a view: autograd owns the returned tensor object, the tape keeps reading the same storage)
         return tape[-1]["x"].view_as(tape[-1]["x"])
 
@@ -288,8 +306,8 @@ class Net3DBodyFn(torch.autograd.Function):
     def backward(ctx, gh: torch.Tensor):
         need_params = any(req for _, req, _ in ctx.pmeta)
         grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
-        with torch.cuda.device(gh.device):
-            ctx.net._cache().compute_dtype = ctx.cd
+        _check_unmodified(ctx)
+        with torch.cuda.device(gh.device), ctx.net._cache().computing_in(ctx.cd):
             gx = body_backward(ctx.net._cache(), ctx.tape, gh.contiguous(), grads, ctx.need_x)
         return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads or {}))
 
@@ -302,23 +320,89 @@ class Net3DTailFn(torch.autograd.Function):
         ctx.net, ctx.last, ctx.names, ctx.cd = net, box.pop("last"), names, box.pop("cd")
         ctx.need_h = h.requires_grad
         ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
+        _remember_versions(ctx, params)
         return box.pop("y")
 
     @staticmethod
     def backward(ctx, gy: torch.Tensor):
         need_params = any(req for _, req, _ in ctx.pmeta)
         grads: Optional[Dict[str, torch.Tensor]] = {} if need_params else None
-        with torch.cuda.device(gy.device):
-            ctx.net._cache().compute_dtype = ctx.cd
+        _check_unmodified(ctx)
+        with torch.cuda.device(gy.device), ctx.net._cache().computing_in(ctx.cd):
             gh = tail_backward(ctx.net._cache(), ctx.last, gy, grads, need_input_grad=ctx.need_h)
         return (gh if ctx.need_h else None, None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads or {}))
 
 
+class Net3DRecomputeFn(torch.autograd.Function):
+    """(x, *parameters) -> y with NOTHING kept but x: the backward re-runs the taped pass and walks it at once -- activation
+    recomputation at network-call granularity (the reference wraps every block in torch.utils.checkpoint while training,
+    lvdm/common.py:85-104, vae_models3d_sd3.py:167-193, 333-370).  Under the tiled wrapper every (window, tile) unit is one such
+    node, so the tapes of the units exist one at a time: peak memory is ONE unit's tape instead of the clip's.  Costs one extra
+    forward pass per backward; the last-layer probes (Net3DTailFn's purpose) then cost a whole pass each: `net.recompute` is for
+    clips whose tape does not fit, not the default."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, net, names: Tuple[str, ...], *params) -> torch.Tensor:
+        with torch.cuda.device(x.device):
+            y = type(net)._program(net._cache(), x.detach(), dict(net._cfg))
+        ctx.net, ctx.names, ctx.x = net, names, x.detach()
+        ctx.cd = net._cache().compute_dtype
+        ctx.x_dtype, ctx.need_x = x.dtype, x.requires_grad
+        ctx.pmeta = [(p.dtype, p.requires_grad, tuple(p.shape)) for p in params]
+        _remember_versions(ctx, params)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: torch.Tensor):
+        _check_unmodified(ctx)
+        need_params = any(req for _, req, _ in ctx.pmeta)
+        net = ctx.net
+        with torch.cuda.device(gy.device), net._cache().computing_in(ctx.cd):
+            tape: List[dict] = []
+            type(net)._program(net._cache(), ctx.x, dict(net._cfg), tape)  # same launches, same bits as the forward's pass
+            gx, grads = sd3_net_backward(net._cache(), tape, gy.contiguous(), need_input_grad=ctx.need_x, need_params=need_params)
+            del tape
+        return (gx.to(ctx.x_dtype) if gx is not None else None, None, None, *_grads_out(ctx.names, ctx.pmeta, grads))
+
+
+class BlendFn(torch.autograd.Function):
+    """blend_v / blend_h of the tiled wrapper under autograd (modeling_vae.py:321-341): out = b with its first o rows (columns)
+    replaced by (1 - w) a[-o:] + w b[:o], w = i / o (the forward kernel on a copy of b); linear, so
+    dL/da[-o:] = (1 - w) g[:o], dL/db = g with its first o rows (columns) scaled by w."""
+
+    @staticmethod
+    def forward(ctx, a: torch.Tensor, b: torch.Tensor, o: int, axis: int) -> torch.Tensor:
+        out = b.detach().contiguous().clone()
+        with torch.cuda.device(b.device):
+            ops.blend_(a.detach().contiguous(), out, o, axis)
+        ctx.o, ctx.axis, ctx.a_shape = o, axis, tuple(a.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: torch.Tensor):
+        o, dim = ctx.o, 3 + ctx.axis
+        shape = [1] * 5
+        shape[dim] = o
+        w = (torch.arange(o, device=g.device, dtype=torch.float32) / float(o)).view(shape)
+        head = g.narrow(dim, 0, o).float()
+        ga = g.new_zeros(ctx.a_shape)
+        ga.narrow(dim, ctx.a_shape[dim] - o, o).copy_(((1.0 - w) * head).to(g.dtype))
+        gb = g.clone()
+        gb.narrow(dim, 0, o).copy_((w * head).to(g.dtype))
+        return ga, gb, None, None
+
+
 def run_trainable(net, x: torch.Tensor, kwargs: dict) -> torch.Tensor:
-    """modeling._Net.forward for a module in train() mode under grad mode: two autograd nodes over (x, parameters) -- body and tail"""
+    """modeling._Net.forward for a module in train() mode under grad mode: two autograd nodes over (x, parameters) -- body and tail
+    (or, `net.recompute`, one node that keeps only x and re-runs the taped pass in its backward)"""
     if kwargs:
         raise NotImplementedError(f"training-mode forward takes no extra arguments (got {sorted(kwargs)})")
+    # parameters written through `.data` since the last pass (EMA swaps: lvdm/modules/ema.py:61-86) do not move the cache's keys:
+    # a device-side checksum does (one sync per training pass)
+    net._cache().guard()
     named = [(n, p) for n, p in net.named_parameters()]
+    if getattr(net, "recompute", False):
+        return Net3DRecomputeFn.apply(x, net, tuple(n for n, _ in named), *[p for _, p in named])
     body = [(n, p) for n, p in named if not _is_tail(n)]
     tail = [(n, p) for n, p in named if _is_tail(n)]
     box: dict = {}

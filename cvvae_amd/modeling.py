@@ -109,15 +109,50 @@ class _Net(nn.Module):
         self._check_input(x)
         # torch.autocast over an fp32 model (the reference's trainer with precision 16 / bf16: fp32 master weights, 16-bit compute;
         # main.py:905-912): the pass runs on 16-bit copies of the weights and returns the autocast dtype, as F.conv3d would
-        self._cache().compute_dtype = _autocast_dtype(x) if self.conv_in.weight.dtype == torch.float32 else None
-        if (self._trainable and self.training and torch.is_grad_enabled()
-                and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
-            # training the codec itself (lvdm/models/autoencoder.py:1057-1090 runs the 3-D networks under autograd): the same
-            # launches with a tape, two autograd nodes (body + tail) over (x, parameters).  eval() mode / no_grad: the inference pass below
-            from . import grad3d
-            return grad3d.run_trainable(self, x, kwargs)
-        with torch.no_grad():
-            return self._forward_inference(x, **kwargs)
+        # (the dtype is set for THIS pass and restored afterwards: WeightCache.computing_in)
+        cd = self._pass_dtype(x)
+        with self._cache().computing_in(cd):
+            if (self._trainable and self.training and torch.is_grad_enabled()
+                    and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+                # training the codec itself (lvdm/models/autoencoder.py:1057-1090 runs the 3-D networks under autograd): the same
+                # launches with a tape, two autograd nodes (body + tail) over (x, parameters).  eval() mode / no_grad: the inference pass below
+                from . import grad3d
+                return grad3d.run_trainable(self, x, kwargs)
+            if self.weight_guard:
+                self.refresh_weights(only_if_changed=True)
+            with torch.no_grad():
+                return self._forward_inference(x, **kwargs)
+
+    # fp32 models only: run THIS network's passes on 16-bit copies of its weights (torch.float16 / torch.bfloat16), as under
+    # torch.autocast but without the context -- `CVVAEModel.decoder_compute_dtype` builds the mixed tolerance mode on it (fp32-fast
+    # encoder: latents inside north_star's 1e-3 bound; 16-bit decoder).  None = the parameters' own dtype.
+    compute_dtype_override: Optional[torch.dtype] = None
+    # inference passes re-check a device-side checksum of the parameters first (one sync per pass) and drop stale packed forms:
+    # for callers that write weights through `.data` (EMA swaps) and cannot call refresh_weights() themselves.  The TRAINING path
+    # (train() mode under grad mode) always checks.
+    weight_guard: bool = os.environ.get("CVVAE_WEIGHT_GUARD", "0") == "1"
+
+    def _pass_dtype(self, x: torch.Tensor) -> Optional[torch.dtype]:
+        if self.conv_in.weight.dtype != torch.float32:
+            return None
+        ac = _autocast_dtype(x)
+        return ac if ac is not None else self.compute_dtype_override
+
+    def refresh_weights(self, only_if_changed: bool = False) -> bool:
+        """Drop every packed / converted weight form and captured hipGraph of this network, so that the next pass re-reads the
+        parameters.  Needed after writing parameters through `.data` (`p.data.copy_()` does not move `p._version`, which is what the
+        cache is keyed on): the reference's EMA does exactly that (LitEma.copy_to / restore, lvdm/modules/ema.py:61-86).
+        load_state_dict, optimizer steps, .to() and assignment are seen without it.  only_if_changed: decide by a device-side
+        checksum of the parameters (one host sync).  Returns whether anything was dropped."""
+        wc = self._cache()
+        if only_if_changed:
+            dropped = wc.guard()
+        else:
+            wc.invalidate()
+            dropped = True
+        if dropped and self._graphs is not None:
+            self._graphs.clear()
+        return dropped
 
     def _forward_inference(self, x: torch.Tensor, **kwargs) -> torch.Tensor:
         # every launch of the pass goes to x's device and its current stream, whatever the caller's current device is
@@ -473,6 +508,27 @@ class _CVVAEBase(nn.Module):
 
     fp32_mode = property(_get_fp32_mode, _set_fp32_mode)
 
+    # ---- mixed tolerance mode (fp32 models): `north_star` bounds the LATENTS (|delta| <= 1e-3) and asks the frames to match "within fp16
+    #      tolerance".  The latents are the encoder's output alone, so an fp32 model can keep its encoder in the fp32 arithmetic
+    #      (`fp32_mode = "fast"`: latent max |delta| ~2e-4) and run the DECODER -- three quarters of the work -- on 16-bit copies of
+    #      its weights with 16-bit activations (`decoder_compute_dtype = torch.float16`: reconstruction ~66 dB against the reference's
+    #      fp32 frames, what the reference's own fp16 scripts deliver).  decode() then returns that dtype, as under torch.autocast.
+    def _get_decoder_compute_dtype(self) -> Optional[torch.dtype]:
+        return self.decoder.compute_dtype_override
+
+    def _set_decoder_compute_dtype(self, dt: Optional[torch.dtype]):
+        if dt not in (None, torch.float16, torch.bfloat16):
+            raise ValueError(f"decoder_compute_dtype must be None, torch.float16 or torch.bfloat16, got {dt!r}")
+        object.__setattr__(self.decoder, "compute_dtype_override", dt)
+
+    decoder_compute_dtype = property(_get_decoder_compute_dtype, _set_decoder_compute_dtype)
+
+    def refresh_weights(self, only_if_changed: bool = False) -> bool:
+        """after writing parameters through `.data` (EMA swap, manual surgery): see _Net.refresh_weights"""
+        a = self.encoder.refresh_weights(only_if_changed)
+        b = self.decoder.refresh_weights(only_if_changed)
+        return a or b
+
     def _flag_widths(self, widths):
         """widths the kernels cannot run: the model can still be built, loaded, converted and saved (parameter holder), but a
         forward pass raises NotImplementedError with this message instead of failing inside a launch."""
@@ -576,6 +632,14 @@ class _CVVAEBase(nn.Module):
     def _blend(a, b, o, axis):
         if not b.is_cuda:
             raise RuntimeError("cvvae_amd blends on the MI355X only (no CPU path)")
+        o = min(a.shape[3 + axis], b.shape[3 + axis], o)  # modeling_vae.py:322, 333
+        if o <= 0:
+            return b
+        if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+            # training through the tiled wrapper (Autoencoding3DEngine tiles under autograd, lvdm/models/autoencoder.py:809-974): the
+            # blend is linear in both tiles -- same kernel forward, the ramp's adjoint backward
+            from .grad3d import BlendFn
+            return BlendFn.apply(a, b, o, axis)
         with torch.cuda.device(b.device):
             if a.is_contiguous() and b.is_contiguous():
                 return ops.blend_(a, b, o, axis)
@@ -609,10 +673,12 @@ class _CVVAEBase(nn.Module):
         for i, cols in enumerate(rows):
             rc = []
             for j, t in enumerate(cols):
+                # (the reference blends IN PLACE, so its `rows[i - 1][j]` / `row[j - 1]` are the already blended neighbours; naming
+                #  them explicitly keeps that true for the out-of-place blend nodes of the autograd path)
                 if i > 0:
-                    t = self.blend_v(rows[i - 1][j], t, overlap_out)
+                    t = self.blend_v(res[i - 1][j], t, overlap_out)
                 if j > 0:
-                    t = self.blend_h(cols[j - 1], t, overlap_out)
+                    t = self.blend_h(rc[j - 1], t, overlap_out)
                 rc.append(t)
             res.append(rc)
         out_rows = []

@@ -565,6 +565,11 @@ def gn_bwd_input_params(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Ten
     assert rs.dtype == torch.float32 and tuple(rs.shape) == (rows, C) and rs.is_contiguous() and nm.is_contiguous()
     if add is not None:
         assert add.shape == x.shape and add.dtype == x.dtype and add.is_contiguous()
+    if C % groups or (C // groups) % 4 or C % 8 or C > 2048 or 256 % (C // 8):
+        # (both GroupNorm backward kernels map a 256-thread block onto whole rows of 8-channel lanes; the model classes admit only
+        #  widths of 128 * 2^k -- modeling._channel_constraints -- so this is a caller error, reported before the launch)
+        raise ValueError(f"GroupNorm backward: C = {C} with {groups} groups is not a width the kernels take (C/8 must divide 256, "
+                         f"channels per group a multiple of 4, C <= 2048)")
     out = torch.empty_like(x)
     dg = torch.empty(C, dtype=torch.float32, device=x.device)
     db = torch.empty(C, dtype=torch.float32, device=x.device)
@@ -734,20 +739,28 @@ def temporal_attention_bwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, go
 
 def layernorm_bwd(x: torch.Tensor, gy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float):
     """backward of layernorm(x) over the last axis: (dL/dx, d gamma, d beta).  A LayerNorm over C is a one-group GroupNorm whose
-    rows are the tokens, so this is gn_stats + gn_bwd_input + gn_bwd_params on the [tokens,1,1,1,C] view (tokens <= 65535: the
-    kernels' grid y; the temporal attention of the vae3d decoder sits at latent resolution)."""
+    rows are the tokens, so this is gn_stats + gn_bwd_input + gn_bwd_params on the [tokens,1,1,1,C] view.  The kernels take
+    their rows on grid y (<= 65535): more tokens (the vae3d decoder's temporal attention at 512x512 crops is 20480 per sample, so a
+    batch of 4 is beyond it) run as several launches over row chunks, the affine sums added in chunk order."""
     C = x.shape[-1]
     n = x.numel() // C
     assert x.is_contiguous() and gy.is_contiguous() and gy.shape == x.shape, (tuple(x.shape), tuple(gy.shape))
-    if n > 65535:
-        raise NotImplementedError(f"layernorm_bwd: {n} tokens exceed the 65535 rows one launch of the GroupNorm kernels takes")
-    x5, g5 = x.view(n, 1, 1, 1, C), gy.view(n, 1, 1, 1, C)
     one = torch.ones(C, dtype=torch.float32, device=x.device)
     zero = torch.zeros(C, dtype=torch.float32, device=x.device)
-    tabs = gn_stats(x5, one, zero, eps, groups=1)
-    gx = gn_bwd_input(x5, g5, tabs, gamma, beta, silu=False, groups=1)
-    dg, db = gn_bwd_params(x5, g5, tabs, gamma, beta, silu=False)
+    x2, g2 = x.view(n, C), gy.view(n, C)
+    gx = torch.empty_like(x2)
+    dg = db = None
+    for a in range(0, n, LAYERNORM_ROWS):
+        m = min(LAYERNORM_ROWS, n - a)
+        x5, g5 = x2[a:a + m].view(m, 1, 1, 1, C), g2[a:a + m].view(m, 1, 1, 1, C)
+        tabs = gn_stats(x5, one, zero, eps, groups=1)
+        gx[a:a + m] = gn_bwd_input(x5, g5, tabs, gamma, beta, silu=False, groups=1).view(m, C)
+        dgc, dbc = gn_bwd_params(x5, g5, tabs, gamma, beta, silu=False)
+        dg, db = (dgc, dbc) if dg is None else (dg + dgc, db + dbc)
     return gx.view(x.shape), dg, db
+
+
+LAYERNORM_ROWS = 65535  # rows one launch of the GroupNorm kernels takes (grid y)
 
 
 def ncdhw_to_ndhwc(x: torch.Tensor, cpad: int, dtype: torch.dtype) -> torch.Tensor:

@@ -446,6 +446,12 @@ def patched(whole_model: bool = False):
             torch.cuda.device = lambda *_a, **_k: contextlib.nullcontext()
 
             def _blend(a, b, o, axis):
+                o = min(a.shape[3 + axis], b.shape[3 + axis], o)  # (mirrors modeling._CVVAEBase._blend without its is_cuda guard)
+                if o <= 0:
+                    return b
+                if torch.is_grad_enabled() and (a.requires_grad or b.requires_grad):
+                    from cvvae_amd.grad3d import BlendFn
+                    return BlendFn.apply(a, b, o, axis)
                 bc = b.contiguous()
                 ops.blend_(a.contiguous(), bc, o, axis)
                 if bc is not b:

@@ -1,0 +1,241 @@
+"""Round 5 on the device:
+  * the BACKWARD at the size tools/train_step_bench.py times it (one 17-frame 256x256 crop through the full 4-level,
+    layers_per_block = 2 networks) against a fixture produced by the reference's OWN Encoder3D / Decoder3D under torch.autograd
+    (oracle/make_golden.py grad; models/vae_models3d_sd3.py:162-208, 323-388; lvdm/models/autoencoder.py:1057-1090);
+  * training through the windowed + tiled wrapper (every (window, tile) call its own autograd nodes; with and without recomputation)
+    against autograd over the oracle's wrapper;
+  * parameters written through `.data` (the reference's EMA swap) and refresh_weights() / the guards;
+  * the mixed tolerance mode: fp32-fast encoder (latents inside north_star's 1e-3 bound) + 16-bit decoder."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvvae_oracle as O
+from oracle import parity as P
+from oracle.golden_cases import BIG_CASES, GRAD_CASES, grad_sample_index, recon_subsample
+from oracle.seeded import seeded_input, seeded_state_dict
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DT = [torch.float32, torch.float16, torch.bfloat16]
+# relative L2 bands: (forward output, dL/d input, worst parameter tensor).  fp32 models run the split-precision kernels; the 16-bit
+# figures are the storage rounding of weights, activations and gradients through 60-90 layers against the reference's fp32 run
+GRAD_TOL = {torch.float32: (1e-4, 2e-3, 3e-3), torch.float16: (5e-3, 3e-2, 4e-2), torch.bfloat16: (4e-2, 1.5e-1, 2e-1)}
+
+
+def _log(line):
+    print("\n" + line)
+    d = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(d):
+        with open(os.path.join(d, "round5_parity.txt"), "a") as f:
+            f.write(line + "\n")
+
+
+def _rel(a, b, floor=0.0):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(floor if floor else 1e-30))
+
+
+def compare_grads_with_fixture(gold, part, net, y, gin):
+    """(forward rel, dL/d input rel, [(error, name)] worst first) of one network against the `part` ('enc' / 'dec') half of a
+    grad fixture: per parameter the worse of |norm - norm_ref| / norm_ref and the relative L2 error of the stored sample; tensors
+    whose reference gradient is (numerically) zero -- the attention's key bias -- are measured against 1e-3 of the largest norm"""
+    so, si = int(gold[part + "_out_stride"]), int(gold[part + "_gin_stride"])
+    yf, gf = y.detach().float().cpu(), gin.detach().float().cpu()
+    e_y = _rel(recon_subsample(yf, so) if so > 1 else yf, gold[part + "_out_sub"])
+    e_x = _rel(recon_subsample(gf, si) if si > 1 else gf, gold[part + "_gin_sub"])
+    names = [str(n) for n in gold[part + "_param_names"]]
+    norms, lens = gold[part + "_param_grad_norm"], gold[part + "_param_sample_len"]
+    samples = np.split(gold[part + "_param_grad_sample"], np.cumsum(lens)[:-1])
+    pars = dict(net.named_parameters())
+    assert sorted(pars) == names, sorted(set(pars) ^ set(names))
+    scale = float(norms.max())
+    errs = []
+    for n, nr, sr in zip(names, norms, samples):
+        g = pars[n].grad
+        assert g is not None and g.shape == pars[n].shape, n
+        g = g.detach().float().flatten().cpu()
+        idx = grad_sample_index(n, g.numel())
+        frac = (len(sr) / g.numel()) ** 0.5
+        e_n = abs(float(g.double().norm()) - float(nr)) / max(float(nr), 1e-3 * scale)
+        e_s = _rel(g[idx], sr, 1e-3 * scale * frac)
+        errs.append((max(e_n, e_s), n))
+    return e_y, e_x, sorted(errs, reverse=True)
+
+
+@pytest.mark.parametrize("dtype", DT, ids=["float32", "float16", "bfloat16"])
+def test_full_size_backward_golden(dtype, golden_dir):
+    name = "grad_sd3_t17_256"
+    path = os.path.join(golden_dir, name + ".npz")
+    if not os.path.isfile(path):
+        pytest.skip(f"fixture {name}.npz not generated")
+    import cvvae_amd
+    family, over, shape, wseed, xseed, cseeds, zseed, strides = GRAD_CASES[name]
+    gold = np.load(path)
+    m = cvvae_amd.CVVAESD3Model(**over)
+    sd = P.load_seeded(m, wseed)
+    assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - float(gold["weight_abs_sum"])) < 1e-6 * float(gold["weight_abs_sum"])
+    m = m.to(dtype).cuda().train()
+    tol = GRAD_TOL[dtype]
+    for part, net, inp, cseed in (("enc", m.encoder, seeded_input(shape, xseed), cseeds[0]),
+                                  ("dec", m.decoder, seeded_input(tuple(int(v) for v in (shape[0], 16) + tuple(gold["enc_out_shape"][2:])), zseed), cseeds[1])):
+        xin = inp.to(dtype).cuda().requires_grad_(True)
+        y = net(xin)
+        assert tuple(y.shape) == tuple(int(v) for v in gold[part + "_out_shape"])
+        cot = seeded_input(tuple(y.shape), cseed).to(dtype).cuda()
+        (y.float() * cot.float()).sum().backward()
+        e_y, e_x, errs = compare_grads_with_fixture(gold, part, net, y, xin.grad)
+        conv_w = [e for e, n in errs if n.endswith("weight") and ("conv" in n or "to_" in n)]
+        _log(f"[full-size backward {part} {str(dtype)[6:]} {tuple(inp.shape)}] vs the reference's own modules: forward rel {e_y:.2e}; "
+             f"dL/d(input) rel {e_x:.2e}; {len(errs)} parameter tensors: worst {errs[0][0]:.2e} ({errs[0][1]}), median "
+             f"{errs[len(errs) // 2][0]:.2e}, conv / linear weights worst {max(conv_w):.2e}")
+        assert e_y <= tol[0], e_y
+        assert e_x <= tol[1], e_x
+        assert errs[0][0] <= tol[2], errs[:5]
+        net.zero_grad(set_to_none=True)
+        del y, cot, xin
+        torch.cuda.empty_cache()
+
+
+TILED = dict(block_out_channels=[128, 256, 256], layers_per_block=1, spatial_n_compress=4, time_n_compress=2,
+             en_de_n_frames_a_time=4, tile_spatial_size=72)
+
+
+@pytest.mark.parametrize("dtype,recompute", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, True)],
+                         ids=["float32", "float32-recompute", "bfloat16-recompute"])
+def test_training_through_the_windowed_and_tiled_wrapper(dtype, recompute):
+    """tiled_encode / tiled_decode (2 windows x 2x2 blended tiles) in train() mode under grad mode against autograd over the
+    oracle's wrapper (lvdm/models/autoencoder.py:809-974 chunks and tiles under autograd)"""
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(**TILED)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 12)
+    m.load_state_dict(sd, strict=True)
+    ref = {k: v.to(dtype).float().clone().requires_grad_(True) for k, v in sd.items()}
+    x = seeded_input((1, 3, 9, 80, 96), 31).to(dtype)
+    xr = x.float().clone().requires_grad_(True)
+    mr = O.encode_moments(xr, ref, dict(TILED), "sd3")
+    yr = O.decode_sample(mr[:, :16], ref, dict(TILED), "sd3")
+    cm, cy = seeded_input(tuple(mr.shape), 5).to(dtype), seeded_input(tuple(yr.shape), 6).to(dtype)
+    ((mr * cm.float()).sum() + (yr * cy.float()).sum()).backward()
+    m = m.to(dtype).cuda().train()
+    m.encoder.recompute = m.decoder.recompute = recompute
+    assert len(m._windows(9, m.encode_n_frames_a_time)) == 2 and len(m._tile_grid(80, 96, 72, 56)) == 2
+    xa = x.cuda().requires_grad_(True)
+    mo = m.tiled_encode(xa)
+    ya = m.tiled_decode(mo[:, :16])
+    ((mo.float() * cm.cuda().float()).sum() + (ya.float() * cy.cuda().float()).sum()).backward()
+    e_m, e_y, e_x = _rel(mo.detach().cpu(), mr.detach()), _rel(ya.detach().cpu(), yr.detach()), _rel(xa.grad.cpu(), xr.grad)
+    scale = max(float(v.grad.norm()) for v in ref.values())
+    errs = sorted(((_rel(p.grad.cpu(), ref[n].grad, 1e-3 * scale), n) for n, p in m.named_parameters()), reverse=True)
+    _log(f"[tiled training {str(dtype)[6:]} recompute={recompute}] moments rel {e_m:.2e} recon rel {e_y:.2e} dL/dx rel {e_x:.2e}; "
+         f"parameters worst {errs[0][0]:.2e} ({errs[0][1]}), median {errs[len(errs) // 2][0]:.2e}")
+    tin, tw = (2e-3, 3e-3) if dtype == torch.float32 else (1e-1, 1.5e-1)
+    assert e_x <= tin and errs[0][0] <= tw, (e_x, errs[:4])
+    if recompute:  # same launches, same order: the recomputing node reproduces the taped pass bit for bit
+        g1 = {n: p.grad.clone() for n, p in m.named_parameters()}
+        gx1 = xa.grad.clone()
+        m.zero_grad(set_to_none=True)
+        m.encoder.recompute = m.decoder.recompute = False
+        xb = x.cuda().requires_grad_(True)
+        mo2 = m.tiled_encode(xb)
+        ya2 = m.tiled_decode(mo2[:, :16])
+        ((mo2.float() * cm.cuda().float()).sum() + (ya2.float() * cy.cuda().float()).sum()).backward()
+        assert torch.equal(mo2, mo) and torch.equal(ya2, ya) and torch.equal(xb.grad, gx1)
+        assert all(torch.equal(p.grad, g1[n]) for n, p in m.named_parameters())
+
+
+def test_weights_written_through_data_and_refresh_weights():
+    """`p.data.copy_()` (LitEma.copy_to / restore, lvdm/modules/ema.py:61-86) does not move `p._version`: the packed weights go stale
+    until refresh_weights() -- or, opted in, the per-pass checksum guard; the training path always checks"""
+    import cvvae_amd
+    over = dict(block_out_channels=[128, 256, 256], layers_per_block=1)
+    m = cvvae_amd.CVVAESD3Model(**over)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    x = seeded_input((1, 3, 5, 32, 32), 2).cuda()
+    y0 = m.encoder(x)
+    w = m.encoder.conv_in.weight
+    v0 = w._version
+    w.data.mul_(1.5)
+    assert w._version == v0 and torch.equal(m.encoder(x), y0)   # stale, by construction of the key
+    assert m.refresh_weights()
+    y1 = m.encoder(x)
+    sd2 = dict(sd, **{"encoder.conv_in.weight": sd["encoder.conv_in.weight"] * 1.5})
+    ref = O.sd3_encoder(x.cpu(), sd2, dict(over))
+    assert float((y1.cpu() - ref).abs().max()) < 1e-4 and float((y0.cpu() - ref).abs().max()) > 1e-3
+    m.enable_hip_graphs()
+    yg = m.encoder(x)
+    assert torch.equal(yg, y1)
+    w.data.mul_(2.0)
+    assert torch.equal(m.encoder(x), yg)    # the captured graph replays the stale packed weights
+    m.encoder.weight_guard = True
+    y2 = m.encoder(x)                       # first guarded pass: nothing packed before it can be vouched for -> rebuilt
+    assert not torch.equal(y2, yg)
+    w.data.mul_(1.5)
+    y3 = m.encoder(x)                       # the guard sees the change, drops packed forms and graphs
+    m.refresh_weights()
+    assert torch.equal(m.encoder(x), y3) and not torch.equal(y3, y2)
+    m.encoder.weight_guard = False
+    m.enable_hip_graphs(False)
+    # training path: always guarded
+    m.train()
+    ya = m.encoder(x.clone().requires_grad_(True))
+    w.data.mul_(2.0)
+    yb = m.encoder(x.clone().requires_grad_(True))
+    assert not torch.equal(ya.detach(), yb.detach())
+    with torch.no_grad():
+        w.mul_(1.01)
+    with pytest.raises(RuntimeError, match="modified"):
+        yb.sum().backward()
+
+
+@pytest.mark.parametrize("name", ["cfg1_vae3d_t1_256", "cfg2_vae3d_t17_256", "cfg3_sd3_t17_512"])
+def test_mixed_tolerance_mode_meets_the_latent_bound(name, golden_dir):
+    """fp32 model, `fp32_mode = "fast"` encoder + `decoder_compute_dtype = float16`: the latents (the encoder's output) stay inside
+    north_star's |delta| <= 1e-3 exactly as in the pure fast mode (same launches: the encoder does not know about the decoder),
+    and the frames carry the fp16 model's reconstruction error ("within fp16 tolerance": the band of the fp16 rows of
+    test_gpu_baseline_shapes.py, i.e. the reference's own fp16 noise at this shape)"""
+    if not os.path.isfile(os.path.join(golden_dir, name + ".npz")):
+        pytest.skip(f"fixture {name}.npz not generated")
+    import cvvae_amd
+    from tests.test_gpu_baseline_shapes import band
+    family, over, shape, wseed, xseed, s = BIG_CASES[name]
+    cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
+    m = cls(**over)
+    P.load_seeded(m, wseed)
+    m = m.cuda().eval()
+    m.fp32_mode = "fast"
+    pure = P.measure(m, name, golden_dir)
+    m.decoder_compute_dtype = torch.float16
+    x = seeded_input(shape, xseed).cuda()
+    z = m.encode(x).latent_dist.mode()
+    y = m.decode(z).sample
+    assert z.dtype == torch.float32 and y.dtype == torch.float16
+    r = P.measure(m, name, golden_dir)
+    t16 = band(name, "f16", golden_dir)
+    _log(f"[mixed tolerance mode {name}] latent max |delta| {r['latent_max_abs']:.3e} mean {r['latent_mean_abs']:.3e} (pure fast: "
+         f"{pure['latent_max_abs']:.3e}); recon PSNR {r['recon_psnr_db']:.1f} dB (pure fast {pure['recon_psnr_db']:.1f}; fp16 band "
+         f">= {t16['psnr']:.1f})")
+    assert r["latent_max_abs"] == pure["latent_max_abs"] and r["latent_max_abs"] <= 1e-3
+    assert r["recon_psnr_db"] >= t16["psnr"]
+    m.decoder_compute_dtype = None
+    assert m.decode(z).sample.dtype == torch.float32
+
+
+def test_layernorm_backward_beyond_one_launch_of_rows():
+    """more tokens than the 65535 rows one launch of the GroupNorm kernels takes (the vae3d decoder's temporal attention at batch >= 4
+    of 512x512 crops): row chunks, the affine sums added in chunk order"""
+    from cvvae_amd import ops
+    import torch.nn.functional as F
+    torch.manual_seed(1)
+    n, C = 70000, 128
+    x = (torch.randn(n, C) * 1.3 + 0.5)
+    go = torch.randn(n, C)
+    gamma, beta = (torch.randn(C) * 0.4 + 1.0).requires_grad_(True), (torch.randn(C) * 0.2).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    (F.layer_norm(xr, (C,), gamma, beta, 1e-5) * go).sum().backward()
+    gx, dg, db = ops.layernorm_bwd(x.cuda().view(1, 1, 1, n, C), go.cuda().view(1, 1, 1, n, C), gamma.detach().cuda(), beta.detach().cuda(), 1e-5)
+    assert _rel(gx.cpu().view(n, C), xr.grad) <= 2e-5 and _rel(dg.cpu(), gamma.grad) <= 2e-4 and _rel(db.cpu(), beta.grad) <= 2e-4

@@ -271,3 +271,97 @@ def test_autocast_runs_an_fp32_model_on_16_bit_weight_copies():
             assert enc.eval()(x).dtype == torch.float32
         finally:
             modeling._autocast_dtype = saved
+
+
+TILED = dict(block_out_channels=[128, 256, 256], layers_per_block=1, spatial_n_compress=4, time_n_compress=2,
+             en_de_n_frames_a_time=4, tile_spatial_size=36)
+
+
+@pytest.mark.parametrize("recompute", [False, True])
+def test_training_through_the_windowed_and_tiled_wrapper(recompute):
+    """the reference's Autoencoding3DEngine chunks time and tiles space UNDER AUTOGRAD (lvdm/models/autoencoder.py:809-974); here
+    `tiled_encode` / `tiled_decode` (2 windows x 2x2 blended tiles) in train() mode under grad mode: every (window, tile) call is
+    its own pair of autograd nodes (or, `recompute`, one node that keeps only its input), the blends are linear nodes, crops and
+    concatenations are torch's.  Gradients of the input and of EVERY parameter against autograd over the oracle's wrapper."""
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(**TILED)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 12)
+    m.load_state_dict(sd, strict=True)
+    ref = {k: v.float().clone().requires_grad_(True) for k, v in sd.items()}
+    x = seeded_input((1, 3, 9, 40, 48), 31)
+    xr = x.clone().requires_grad_(True)
+    mr = O.encode_moments(xr, ref, dict(TILED), "sd3")
+    zr = mr[:, :16]
+    yr = O.decode_sample(zr, ref, dict(TILED), "sd3")
+    cm, cy = seeded_input(tuple(mr.shape), 5), seeded_input(tuple(yr.shape), 6)
+    ((mr * cm).sum() + (yr * cy).sum()).backward()
+    with emu_ops.patched(whole_model=True):
+        m.train()
+        m.encoder.recompute = m.decoder.recompute = recompute
+        assert len(m._windows(9, m.encode_n_frames_a_time)) == 2 and len(m._tile_grid(40, 48, 36, 28)) == 2
+        xa = x.clone().requires_grad_(True)
+        mo = m.tiled_encode(xa)
+        assert mo.requires_grad and torch.allclose(mo.detach(), mr.detach(), rtol=1e-4, atol=1e-5), float((mo - mr).abs().max())
+        ya = m.tiled_decode(mo[:, :16])
+        assert torch.allclose(ya.detach(), yr.detach(), rtol=1e-4, atol=1e-4), float((ya - yr).abs().max())  # (z itself differs by ~5e-6)
+        ((mo * cm).sum() + (ya * cy).sum()).backward()
+        assert _rel(xa.grad, xr.grad) < 2e-4, _rel(xa.grad, xr.grad)
+        scale = max(float(v.grad.norm()) for v in ref.values())
+        for n, p in m.named_parameters():
+            assert p.grad is not None and p.grad.shape == p.shape, n
+            assert _rel(p.grad, ref[n].grad, 1e-4 * scale) < 3e-4, (n, _rel(p.grad, ref[n].grad))
+        # the public encode() / decode() stay inference entry points (no graph), whatever the module mode
+        assert not m.encode(x).latent_dist.parameters.requires_grad
+
+
+def test_refresh_weights_after_a_write_through_data():
+    """`p.data.copy_()` (the reference's EMA swap, lvdm/modules/ema.py:61-86) leaves `p._version` alone, so the packed forms keyed on
+    it go stale: refresh_weights() / the training path's checksum guard / weight_guard pick the new weights up"""
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(block_out_channels=[128, 256, 256], layers_per_block=1)
+    sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    x = seeded_input((1, 3, 5, 16, 16), 2)
+    with emu_ops.patched(whole_model=True):
+        y0 = m.encoder(x)
+        w = m.encoder.conv_in.weight
+        v0 = w._version
+        w.data.mul_(1.5)
+        assert w._version == v0                       # the write is invisible to the cache's keys (on the GPU the stale packed
+        assert m.refresh_weights()                    # weights would still answer: tests/test_gpu_round5.py; the emulated packers alias)
+        y1 = m.encoder(x)
+        assert not torch.allclose(y1, y0)
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2["encoder.conv_in.weight"] = sd["encoder.conv_in.weight"] * 1.5
+        ref = O.sd3_encoder(x, {k: v for k, v in sd2.items()}, dict(block_out_channels=[128, 256, 256], layers_per_block=1))
+        assert torch.allclose(y1, ref, rtol=1e-4, atol=1e-5)
+        # the opt-in guard of the inference path: a checksum per pass
+        m.encoder.weight_guard = True
+        m.encoder(x)                                  # (takes the first checksum)
+        w.data.mul_(2.0)
+        y2 = m.encoder(x)
+        assert not torch.allclose(y2, y1)
+        m.encoder.weight_guard = False
+        # the training path always checks
+        m.train()
+        xa = x.clone().requires_grad_(True)
+        ya = m.encoder(xa)
+        w.data.mul_(0.5)
+        yb = m.encoder(x.clone().requires_grad_(True))
+        assert torch.allclose(yb.detach(), y1, rtol=1e-5, atol=1e-6) and not torch.allclose(ya.detach(), yb.detach())
+
+
+def test_backward_after_a_parameter_update_raises():
+    """the backward reads the weights live: a parameter modified between forward and backward must raise (as PyTorch's own conv
+    backward does), not return gradients of the new weights over the old activations"""
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model(block_out_channels=[128, 256, 256], layers_per_block=1)
+    m.train()
+    x = seeded_input((1, 3, 5, 16, 16), 2)
+    with emu_ops.patched(whole_model=True):
+        y = m.encoder(x)
+        with torch.no_grad():
+            m.encoder.conv_in.weight.mul_(1.01)       # an optimizer.step() between forward and backward
+        with pytest.raises(RuntimeError, match="modified"):
+            y.sum().backward()
