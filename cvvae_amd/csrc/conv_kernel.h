@@ -182,6 +182,9 @@ struct ConvArgs {
 #define CVVAE_PROBE_MARK() do { } while (0)
 #endif
 
+#ifndef CVVAE_LD_PF
+#define CVVAE_LD_PF 0  // tuning aid: weight-ring depth of the DMA-staged instances (0: as deep as divides the time group)
+#endif
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 
 // Every wave keeps PF packed-weight fragments (1 KiB each) in flight and never branches on "last step", so it reads up
@@ -193,7 +196,15 @@ constexpr int WEIGHT_TAIL_BYTES = 16 * 1024;
 // NB: 32-channel N-blocks per wave.  NB = 2: a wave multiplies every activation fragment it reads from LDS with TWO weight
 // fragments (a 2 x MREP register block): half the LDS operand reads per MFMA -- the LDS pipe (128 B/clk/CU = one 1-KiB fragment
 // per 8 clocks) is otherwise exactly saturated at the full MFMA rate of four SIMDs -- for twice the (L2-resident) weight stream.
-template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int XP = 0, int NB = 1>
+// LD = 1 ("DMA-staged"): the halo tile goes global -> LDS by global_load_lds_dwordx4 (no VGPRs, no VALU: the instruction writes
+// lane i's 16 bytes at LDS base + 16 i), into a CHANNEL-PLANE layout -- plane q holds channels 8q..8q+7 of every halo pixel at a
+// 16-byte pitch, so a wave-load of 64 consecutive halo pixels of one plane is exactly one DMA instruction, the fragment reads of 16
+// consecutive pixels are 256 contiguous bytes (conflict-free without the 16 padding bytes per pixel of the register-staged
+// layout: a third less LDS at 16-channel chunks), and the tap offsets stay immediates.  Nothing stages in registers, so EVERY wave
+// multiplies all the time (the register-staged kernel alternates: one wave of a SIMD stages while the other multiplies, and a
+// lone wave issues an MFMA every ~38 instead of 32 cycles).  For instances WITHOUT a prologue (PRO = 0: the operand is consumed as
+// stored -- upsample / downsample convs, conv_in, 1x1 layers, and any conv whose GroupNorm + SiLU was applied by cvvae_gn_silu_apply).
+template <int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB, int XP = 0, int NB = 1, int LD = 0>
 struct Geo {
   static constexpr int NTAPS = KT * KH * KW;
   static constexpr int BM = TT * TH * TW;
@@ -205,9 +216,17 @@ struct Geo {
   // XP (fp32 activations, split-fp16 MFMA): a pixel holds, per 16 channels, hi[0..7] hi[8..15] lo[0..7] lo[8..15] (64 bytes);
   // XP == 2: hi[0..15] (fp16, 32 bytes) | lo[0..15] (bf8, 16 bytes) | hi[0..15] (bf8, 16 bytes)
   // XP == 3: hi[0..15] (fp16, 32 bytes) | bf6 codes of [lo*2^11 (8) | hi (8)] of channels 0..7, then of channels 8..15 (24 bytes) | pad
-  static constexpr int PIXB = (XP ? CK * 4 : CK * 2) + 16;
+  // LD: planes of NPIXP = NPIX rounded up to whole 64-pixel wave-loads, 16 bytes per pixel; plane q of a buffer at q * PLB
+  static constexpr int NQ = 2 * KSUB;                 // 8-channel planes per K chunk
+  static constexpr int NGRP = (NPIX + 63) / 64;       // 64-pixel groups = DMA wave-loads per plane
+  static constexpr int PLB = NGRP * 64 * 16;          // bytes per plane
+  static constexpr int NDMA = NQ * NGRP;              // wave-loads per chunk, dealt to the 8 waves round-robin
+  static constexpr int NDI = (NDMA + 7) / 8;          // ... per wave
+  static constexpr int PIXB = LD ? 16 : (XP ? CK * 4 : CK * 2) + 16;
+  static constexpr int KSB = LD ? 2 * PLB : (XP ? 64 : 32);  // byte offset of k16 sub-chunk ks inside a buffer: ks * KSB
+  static constexpr int KHB = LD ? PLB : 16;                  // ... of the upper k half (lanes 32-63 of an operand): + KHB
   static constexpr int XPM = XP ? 3 : 1;  // weight records per k16 sub-chunk and tap (XP == 1: one MFMA each)
-  static constexpr int BUFB = NPIX * PIXB;
+  static constexpr int BUFB = LD ? NQ * PLB : NPIX * PIXB;
   static constexpr int LDSB = 2 * BUFB;
   static constexpr int NWV = WM * WN * KG;  // waves per workgroup: 8 (one workgroup per CU) or 4 (TWO workgroups per CU)
   static constexpr int IPP = 2 * KSUB;   // 16-byte items per pixel
@@ -224,10 +243,17 @@ struct Geo {
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
   // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
   static constexpr int MPS = NB * MREP;  // MFMAs per k16 step of a wave
-  static constexpr int PF = XP ? 3 : (KT == 3 && KH * KW == 1) ? KSUB : (STEPS_W % 9 == 0) ? ((MPS >= 8 || KH * KW < 9) ? 3 : 9) : (STEPS_W % 8 == 0 ? (MPS >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
+  // LD: the staging registers are gone, and the DMA wave-loads of the next chunk -- issued at the top of a chunk -- sit in the same
+  // in-order vmcnt queue as the weight records: the first record requested AFTER them cannot be consumed before they have landed,
+  // so the ring is as deep as divides the time group (9 / 8 / 6 records: the DMA has that many k16 steps to arrive)
+  static constexpr int GSL = (KT == 3 && KG == 1 ? KH * KW : NTAPS) * KSUB;  // steps of a time group (or of the chunk)
+  static constexpr int PFL = GSL % 9 == 0 ? 9 : (GSL % 8 == 0 ? 8 : (GSL % 6 == 0 ? 6 : (GSL % 4 == 0 ? 4 : (GSL % 3 == 0 ? 3 : (GSL % 2 == 0 ? 2 : 1)))));
+  static constexpr int PF = LD ? (CVVAE_LD_PF ? (GSL % CVVAE_LD_PF == 0 ? CVVAE_LD_PF : PFL) : PFL) : XP ? 3 : (KT == 3 && KH * KW == 1) ? KSUB : (STEPS_W % 9 == 0) ? ((MPS >= 8 || KH * KW < 9) ? 3 : 9) : (STEPS_W % 8 == 0 ? (MPS >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
   // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
   static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
   static constexpr int SMEMB = cmax(LDSB, REDB);
+  static_assert(LD == 0 || (XP == 0 && NB == 1 && KG == 1 && NWV == 8 && TW >= 16), "DMA-staged instances: 16-bit, 8 waves, no K-group split, "
+                "fragment rows of >= 16 consecutive pixels");
   static_assert(XP == 0 || KG == 1, "split-precision instances: no K-group split");
   static_assert(NB == 1 || (NB == 2 && KG == 1 && XP == 0), "two N-blocks per wave: 16-bit instances without K-group split");
   static_assert(NWV == 8 || (NWV == 4 && KG == 1), "8 waves per workgroup, or 4 (two workgroups per CU; no K-group split)");
@@ -361,9 +387,10 @@ __device__ __forceinline__ int map_coord(int c, int L, int mode, bool& zero) {
 // serves both terms -- per (output channel, tap) for the weights (stored in the record), one per launch for the activations
 // (ConvArgs.q6_scale / q6_eb from the caller's bound of the operand).  An LDS pixel holds hi (fp16, 32 B) | 24 bytes of codes.
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS, int XP = 0, int NB = 1>
+          int PRO, int UPS, int XP = 0, int NB = 1, int LD = 0>
 __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) void conv_fwd_kernel(const ConvArgs p) {
-  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, XP, NB>;
+  using G = Geo<KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, XP, NB, LD>;
+  static_assert(LD == 0 || (PRO == 0 && UPS != 1 && !(KT == 3 && KH == 3 && KW == 1)), "DMA staging: no prologue, no nearest-2x gather, not the row-packed layer");
   using TIO = std::conditional_t<XP != 0, float, T>;  // element type of the activation tensors in HBM
   static_assert(XP == 0 || std::is_same<T, _Float16>::value, "split precision runs on fp16 MFMA");
   constexpr int XPM = G::XPM;
@@ -500,31 +527,76 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
                              : (TFOLD ? (((hcnt + 1) / 2 + G::PPP - 1) / G::PPP * G::PPP) : G::NPH);  // pixels staged by group X
   const int pstart = hbase + (grp ? nph_x : 0);
   const int pend = hbase + (grp ? hcnt : (nph_x < hcnt ? nph_x : hcnt));
+  // stored pixel that feeds halo slot hp (frame-major inside the halo tile), or -1: zero padding
+  auto halo_src = [&](int hp) -> int {
+    const int f = hp / (G::FH * G::FW);
+    const int rem = hp - f * (G::FH * G::FW);
+    const int hy = rem / G::FW;
+    const int hx = rem - hy * G::FW;
+    bool zero = false;
+    int ts = map_coord(t0 * ST + f - p.pt, p.Tl, p.mode_t, zero);
+    // UPS == 2: phase 0 along an axis reads rows {y-1, y} (front pad 1), phase 1 reads {y, y+1} (front pad 0)
+    int ys = map_coord(y0 * SH + hy - (UPS == 2 ? p.ph - py : p.ph), p.Hl, p.mode_hw, zero);
+    int xs = map_coord(x0 * SW + hx - (UPS == 2 ? p.pw - px : p.pw), p.Wl, p.mode_hw, zero);
+    if (UPS == 1) {
+      ys >>= 1;
+      xs >>= 1;
+    }
+    return zero ? -1 : ((b * p.Ti + ts) * p.Hi + ys) * p.Wi + xs;
+  };
   int srcpix[NPASS];
   unsigned passmask = 0;  // wave-uniform: passes in which some lane of this wave has a slot
+  if constexpr (!LD) {
 #pragma unroll
-  for (int k = 0; k < NPASS; ++k) {
-    const int hp = pstart + spl + k * G::PPP;
-    int sp = -2;  // -2: slot not mine / beyond tile, -1: zero padding
-    if (hp < pend) {
-      const int f = hp / (G::FH * G::FW);
-      const int rem = hp - f * (G::FH * G::FW);
-      const int hy = rem / G::FW;
-      const int hx = rem - hy * G::FW;
-      bool zero = false;
-      int ts = map_coord(t0 * ST + f - p.pt, p.Tl, p.mode_t, zero);
-      // UPS == 2: phase 0 along an axis reads rows {y-1, y} (front pad 1), phase 1 reads {y, y+1} (front pad 0)
-      int ys = map_coord(y0 * SH + hy - (UPS == 2 ? p.ph - py : p.ph), p.Hl, p.mode_hw, zero);
-      int xs = map_coord(x0 * SW + hx - (UPS == 2 ? p.pw - px : p.pw), p.Wl, p.mode_hw, zero);
-      if (UPS == 1) {
-        ys >>= 1;
-        xs >>= 1;
-      }
-      sp = zero ? -1 : ((b * p.Ti + ts) * p.Hi + ys) * p.Wi + xs;
+    for (int k = 0; k < NPASS; ++k) {
+      const int hp = pstart + spl + k * G::PPP;
+      const int sp = hp < pend ? halo_src(hp) : -2;  // -2: slot not mine / beyond tile, -1: zero padding
+      srcpix[k] = sp;
+      if (__builtin_amdgcn_ballot_w64(sp != -2) != 0) passmask |= 1u << k;
     }
-    srcpix[k] = sp;
-    if (__builtin_amdgcn_ballot_w64(sp != -2) != 0) passmask |= 1u << k;
   }
+  // ---- LD: the DMA plan (chunk independent).  Wave-load ii = wave + 8 k of a chunk fills plane ii % NQ, halo pixels
+  //      64 (ii / NQ) .. +63: my lane's slot of it is fed by stored pixel dpix[k] (NOSRC: zero padding, a halo frame nobody reads, or
+  //      beyond the halo tile -- such lanes are masked out of the load; zero-padding slots are zeroed ONCE below, in both buffers)
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  constexpr unsigned NOSRC = 0xffffffffu;
+  unsigned dpix[LD ? G::NDI : 1];
+  if constexpr (LD) {
+#pragma unroll
+    for (int k = 0; k < G::NDI; ++k) {
+      const int ii = wave + 8 * k;
+      const int hp = (ii / G::NQ) * 64 + lane;
+      unsigned sp = NOSRC;
+      if (ii < G::NDMA && hp >= hbase && hp < hbase + hcnt) {
+        const int v = halo_src(hp);
+        if (v >= 0) sp = (unsigned)v;
+        else {  // zero padding: the DMA never writes this slot
+          const uint4 z = make_uint4(0, 0, 0, 0);
+          char* d = smem + (ii % G::NQ) * G::PLB + hp * 16;
+          *reinterpret_cast<uint4*>(d) = z;
+          *reinterpret_cast<uint4*>(d + G::BUFB) = z;
+        }
+      }
+      dpix[k] = sp;
+    }
+  }
+  auto dma_from = [&](const TIO* __restrict__ src, size_t src_ps, int chunk, int bufsel) {
+    if constexpr (LD) {
+      const char* cbase = reinterpret_cast<const char*>(src) + (size_t)chunk * (CK * sizeof(TIO));  // wave-uniform
+      const unsigned pitch = (unsigned)(src_ps * sizeof(TIO));
+#pragma unroll
+      for (int k = 0; k < G::NDI; ++k) {
+        const int ii = wave + 8 * k;
+        if (ii >= G::NDMA) continue;
+        const int q = ii % G::NQ, j = ii / G::NQ;
+        if (j * 64 + 63 < hbase || j * 64 >= hbase + hcnt) continue;  // (wave-uniform: a halo frame no wave reads)
+        if (dpix[k] != NOSRC)
+          __builtin_amdgcn_global_load_lds((gptr_t)(cbase + (size_t)dpix[k] * pitch + q * 16),
+                                           (lptr_t)(smem + bufsel * G::BUFB + q * G::PLB + j * 1024), 16, 0, 0);
+      }
+    }
+  };
   const int lds_w0 = (pstart + spl) * PIXB + (XP ? (sq >> 1) * 64 + (sq & 1) * 16 : sq * 16);  // XP: my hi slice; lo = +32
   // (XP == 2: my 8 bf8 lo values at +32 + (sq & 1) * 8 and my 8 bf8 hi values at +48 + (sq & 1) * 8 of the k16 group)
   const int lds_q8 = (pstart + spl) * PIXB + (sq >> 1) * 64 + 32 + (sq & 1) * 8;
@@ -659,8 +731,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   for (int r = 0; r < MREP; ++r) {
     const int m = (wave_m * MREP + r) * 32 + (lane & 31);
     const int tx = m % TW, ty = (m / TW) % TH, tt = m / (TW * TH);
-    aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * 16 +
-                         kgrp * (KSUB / KG) * 32);
+    aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * G::KHB +
+                         kgrp * (KSUB / KG) * G::KSB);
   }
   // step i of a time group: k16 sub-chunk i / NSP, spatial tap i % NSP
   auto tf_rec = [&](int i) -> long long {
@@ -692,6 +764,18 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   // elements between the packed weights of consecutive 32-channel blocks (NB = 2: the wave's second block)
   const long long wq_nbs = (long long)p.nchunks * (TFOLD ? w_cs : (long long)(STEPS * 512));
   v8 wf[NB][NWF];
+  // LD: the weight records are requested and awaited BY HAND.  hipcc's own s_waitcnt placement treats a pending global_load_lds
+  // as an access that may touch both memories and turns the next vmcnt dependency into a full drain -- of the wave-loads just
+  // issued and of the ring's whole read-ahead.  With the request and the wait as asm statements the ring keeps its depth: at the
+  // start of step i the PF - 1 youngest requests are the records of steps i+1 .. i+PF-1, so "at most PF - 1 outstanding" means record
+  // i has arrived (any other request in the queue -- the wave-loads, a residual run -- only makes that wait stricter, never laxer).
+  auto wload = [&](v8& dst, const T* ptr) __attribute__((always_inline)) {
+    if constexpr (LD) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(ptr));
+    else dst = *reinterpret_cast<const v8*>(ptr);
+  };
+  auto wwait = [&](v8& rec) __attribute__((always_inline)) {
+    if constexpr (LD) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rec) : "n"(PF - 1));
+  };
   if constexpr (XP >= 2) {
     const T* e = wqx + (TFOLD ? tf_w0 : 0);  // chunk 0, time group 0, pair 0 (taps 0 and 1 of k16 sub-chunk 0)
     wf[0][0] = *reinterpret_cast<const v8*>(e);
@@ -712,7 +796,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     for (int n = 0; n < NB; ++n)
 #pragma unroll
       for (int i = 0; i < PF; ++i)
-        wf[n][i] = *reinterpret_cast<const v8*>((TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512) + n * wq_nbs);
+        wload(wf[n][i], (TFOLD ? wq + tf_w0 + tf_rec(i) : wq + i * 512) + n * wq_nbs);
   }
 
   // The accumulators start from the BIAS (alpha == 1, i.e. every layer but the attention score product): 128 v_add per lane
@@ -751,15 +835,33 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 
   // ---- pipeline
   CVVAE_PROBE_MARK();
-  stage(0, 0);
+  if constexpr (LD) {
+    dma_from(inp, (size_t)p.in_ps, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    stage(0, 0);
+  }
   CVVAE_PROBE_MARK();
   __syncthreads();
   for (int c = 0; c < p.nchunks; ++c) {
     const int cur = c & 1;
     const bool more = (c + 1) < p.nchunks;
     CVVAE_PROBE_MARK();
-    const bool stage_first = grp == 0 && !p.phase_sync;
+    const bool stage_first = !LD && grp == 0 && !p.phase_sync;
     if (stage_first && more) stage(c + 1, cur ^ 1);
+    // LD: every wave requests its share of the next chunk's halo and goes on multiplying this one.  WHERE in the chunk: vector
+    // memory operations complete in order, so the first weight record requested after the wave-loads cannot be consumed before they
+    // have landed -- and the wait for this chunk's first records sits in front of its first MFMA (with a ring as deep as a time
+    // group it is a wait for everything outstanding).  The wave-loads therefore go out right AFTER the MFMAs of the chunk's first
+    // k16 step (LD_ISSUE below), not here; a wave without output channels has no such step
+    if (LD && more && !active) dma_from(inp, (size_t)p.in_ps, c + 1, cur ^ 1);
+#define CVVAE_LD_ISSUE(first_step)                                             \
+    if constexpr (LD) {                                                          \
+      if (first_step) {                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                       \
+        if (more) dma_from(inp, (size_t)p.in_ps, c + 1, cur ^ 1);                \
+      }                                                                          \
+    }
     CVVAE_PROBE_MARK();
     if constexpr (XP >= 2) {
       // ---- fast fp32: per pair of taps (a, b) of a run of R = KH*KW taps:  Whi.hi (a), Whi.hi (b) on the fp16 MFMA, then both
@@ -873,7 +975,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           for (int i = 0; i < GS; ++i) {
             const int nj = (i + 1) / XPM, npart = (i + 1) % XPM;
             const int nsp = nj % NSP, nks = nj / NSP;
-            const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
+            const int noff = ((nsp / KW) * G::FW + (nsp % KW)) * PIXB + nks * G::KSB + (npart == 2 ? 16 : 0);
+#pragma unroll
+            for (int n = 0; n < NB; ++n) wwait(wf[n][i % PF]);
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
 #pragma unroll
@@ -887,9 +991,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
               for (int r = 0; r < MREP; ++r) ab[0][r] = *reinterpret_cast<const v8*>(&smem[lbn + aoff[r]]);
             }
+            CVVAE_LD_ISSUE(i == 0 && g == 0)
 #pragma unroll
             for (int n = 0; n < NB; ++n)
-              wf[n][i % PF] = *reinterpret_cast<const v8*>((i + PF < GS ? wg + tf_rec(i + PF) : wn + tf_rec(i + PF - GS)) + n * wq_nbs);
+              wload(wf[n][i % PF], (i + PF < GS ? wg + tf_rec(i + PF) : wn + tf_rec(i + PF - GS)) + n * wq_nbs);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -927,7 +1032,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         const int nq = (st + 1) / XPM, npart = (st + 1) % XPM;
         const int nks = nq / NTAPS, nt = nq % NTAPS;  // next step's k-sub-chunk (within my K-group) / tap
         const int ndt = nt / (KH * KW), ndy = (nt / KW) % KH, ndx = nt % KW;
-        const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * (XP ? 64 : 32) + (npart == 2 ? 16 : 0);
+        const int noff = ((ndt * G::FH + ndy) * G::FW + ndx) * PIXB + nks * G::KSB + (npart == 2 ? 16 : 0);
+#pragma unroll
+        for (int n = 0; n < NB; ++n) wwait(wf[n][st % PF]);
 #pragma unroll
         for (int r = 0; r < MREP; ++r) {
 #pragma unroll
@@ -935,10 +1042,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
           if (st + 1 < STEPS_W)
             ab[(st + 1) & (NAB - 1)][r] = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (npart ? lhi16 : 0u) + (unsigned)noff]);
         }
+        CVVAE_LD_ISSUE(st == 0)
         // ring refill: my record st+PF of this chunk, or (wrapping) record st+PF-STEPS_W of the next chunk
 #pragma unroll
         for (int n = 0; n < NB; ++n)
-          wf[n][st % PF] = *reinterpret_cast<const v8*>(wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512 + n * wq_nbs);
+          wload(wf[n][st % PF], wc + (st + PF < STEPS_W ? st + PF : st + PF - STEPS_W + STEPS) * 512 + n * wq_nbs);
         // Fence per step: keeps the next step's ds_reads and the weight prefetch inside THIS step.  hipcc otherwise
         // sinks every load to just before its first use, which exposes the LDS / L2 latency once per MFMA
         // (measured on MI355X: 1158 -> 1240 TFLOP/s on 256->256 @9x256^2; pinning a strict MFMA/ds_read
@@ -966,10 +1074,24 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         }
       }
     }
+#undef CVVAE_LD_ISSUE
     CVVAE_PROBE_MARK();
-    if (!stage_first && more) stage(c + 1, cur ^ 1);
+    if (!LD && !stage_first && more) stage(c + 1, cur ^ 1);
+    if constexpr (LD) {
+      // my wave-loads of the next chunk were issued BEFORE this chunk's weight-record requests, and vector memory operations
+      // complete in order: once all but the PF youngest requests (the ring's read-ahead) are back, so are they.  A wave without
+      // output channels requested nothing after them: it waits for everything.
+      if (more) {
+        if (active) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PF) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
     CVVAE_PROBE_MARK();
-    __syncthreads();
+    // (LD: the plain barrier instruction.  __syncthreads() carries workgroup fences, and with LDS-DMA writes possibly pending hipcc
+    //  turns them into s_waitcnt vmcnt(0) -- which would also drain the weight ring's read-ahead at every chunk.  What the barrier
+    //  needs is exactly what the two waits give: my wave-loads have landed, my LDS reads of this chunk are back)
+    if constexpr (LD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    else __syncthreads();
   }
   // ---- fused 1x1 shortcut: more K chunks over the second input through the centre tap (the final barrier of the loop
   //      above has released both halo buffers)
@@ -977,16 +1099,18 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     if (p.in2 != nullptr) {
       const TIO* __restrict__ inp2 = reinterpret_cast<const TIO*>(p.in2);
       auto stage2 = [&](int chunk, int bufsel) {
-        stage_from(std::integral_constant<int, 0>{}, inp2, (size_t)p.in2_ps, chunk, bufsel);
+        if constexpr (LD) dma_from(inp2, (size_t)p.in2_ps, chunk, bufsel);
+        else stage_from(std::integral_constant<int, 0>{}, inp2, (size_t)p.in2_ps, chunk, bufsel);
       };
       constexpr unsigned ctr = (unsigned)((1 * G::FW + 1) * PIXB);  // centre tap (dy = dx = 1)
       const T* w2q = reinterpret_cast<const T*>(p.w2) + (size_t)(active ? nb : 0) * (size_t)p.nchunks2 * (KSUB * XPM * 512) + lane * 8;
       stage2(0, 0);
+      if constexpr (LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       for (int c = 0; c < p.nchunks2; ++c) {
         const int cur = c & 1;
         const bool more = (c + 1) < p.nchunks2;
-        const bool stage_first = grp == 0 && !p.phase_sync;
+        const bool stage_first = LD || (grp == 0 && !p.phase_sync);
         if (stage_first && more) stage2(c + 1, cur ^ 1);
         if (active) {
           const unsigned lb = (unsigned)(cur * G::BUFB);
@@ -1004,12 +1128,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
                 const v8 bf = *reinterpret_cast<const v8*>(&smem[lb + aoff[r] + (part ? lhi16 : 0u) + ctr +
-                                                                 ks * (XP ? 64 : 32) + (part == 2 ? 16 : 0)]);
+                                                                 ks * G::KSB + (part == 2 ? 16 : 0)]);
 #pragma unroll
                 for (int n = 0; n < NB; ++n) acc[n * MREP + r] = Tr<T>::mfma(wv[n][ks * XPM + part], bf, acc[n * MREP + r]);
               }
         }
         if (!stage_first && more) stage2(c + 1, cur ^ 1);
+        if constexpr (LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the 1x1 weights of a chunk are requested at its top)
         __syncthreads();
       }
     }
@@ -1472,11 +1597,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 
 // host-side launcher, one per instantiation (defined in conv_inst_*.hip)
 template <typename T, int KT, int KH, int KW, int ST, int SH, int SW, int TT, int TH, int TW, int WM, int WN, int KG, int KSUB,
-          int PRO, int UPS, int XP = 0, int NB = 1>
+          int PRO, int UPS, int XP = 0, int NB = 1, int LD = 0>
 int launch_conv(const ConvArgs& a, int grid, hipStream_t s) {
   // (debug aid: CVVAE_NW4_SOLO=1 pads a 4-wave launch's LDS so that only ONE workgroup fits a CU)
   static const bool solo = getenv("CVVAE_NW4_SOLO") && atoi(getenv("CVVAE_NW4_SOLO"));
-  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XP, NB>), dim3(grid),
+  hipLaunchKernelGGL((conv_fwd_kernel<T, KT, KH, KW, ST, SH, SW, TT, TH, TW, WM, WN, KG, KSUB, PRO, UPS, XP, NB, LD>), dim3(grid),
                      dim3(WM * WN * KG * 64), (WM * WN * KG == 4 && solo) ? 48 * 1024 : 0, s, a);
   return (int)hipGetLastError();
 }

@@ -194,6 +194,29 @@
   X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0)
 
+// DMA-staged instances (LD = 1, conv_kernel.h): 16-bit models, PRO = 0 -- the folded upsample convs, the strided downsamplers, the
+// 1x1 layers and the decoder's conv_in as they are, and every other conv when its GroupNorm + SiLU is applied by the pass
+// (cvvae_gn_silu_apply; engine.prepass) instead of in the staging.  Same tiles as the register-staged instances they shadow; the
+// selection prefers them unless CVVAE_CONV_DMA=0 (A/B aid).  Split in three translation units for the parallel build.
+//   X(KT,KH,KW, ST,SH,SW, TT,TH,TW, WM,WN,KG, KSUB, PRO, UPS)
+#define CVVAE_CONV_LD_A(X) \
+  X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 0,0)
+#define CVVAE_CONV_LD_B(X) \
+  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2) \
+  X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2) \
+  X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 2, 0,0) \
+  X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
+  X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 8, 0,0)
+#define CVVAE_CONV_LD_C(X) \
+  X(1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 0,0) \
+  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 4, 0,0)
+#define CVVAE_CONV_LD(X) CVVAE_CONV_LD_A(X) CVVAE_CONV_LD_B(X) CVVAE_CONV_LD_C(X)
+
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \
   CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X) CVVAE_CONV_G12(X) CVVAE_CONV_G13(X)

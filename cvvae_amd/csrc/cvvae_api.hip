@@ -30,12 +30,18 @@ CVVAE_CONV_XQ6(CVVAE_EXTERN_XQ6)
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_NB2(CVVAE_EXTERN_NB2)
 
+#define CVVAE_EXTERN_LD(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,1,1>(const ConvArgs&, int, hipStream_t); \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,1,1>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_LD(CVVAE_EXTERN_LD)
+
 // Per-frame GroupNorm tables are merged from the statistics records of a kT == 1 conv (cvvae_gn_finalize_frames, ops.GNPartials.frames):
 // that assumes ONE-FRAME tiles written in frame-major record order, i.e. TT == 1 for every kT == 1 instance of every list
 #define CVVAE_CHECK_FRAME_TILES(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   static_assert(KT != 1 || TT == 1, "kT == 1 instances must have one-frame tiles: per-frame statistics are merged from their records");
 CVVAE_CONV_ALL(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_NB2(CVVAE_CHECK_FRAME_TILES)
+CVVAE_CONV_LD(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_XP(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_XQ(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_XQ6(CVVAE_CHECK_FRAME_TILES)
@@ -45,29 +51,35 @@ typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 struct Instance {
   int kt, kh, kw, st, sh, sw, tt, th, tw, wm, wn, kg, ksub, pro, ups;
   int nbw;  // 32-channel N-blocks per wave (1; 2 = the register-blocked instances: a wave's tile is 64 channels wide)
+  int ld;   // 1: DMA-staged (conv_kernel.h LD): 16-bit, no prologue
   launch_fn fn[5];  // [CVVAE_F16], [CVVAE_BF16], [CVVAE_F32] (split-precision instances: only this one), [CVVAE_F32Q], [CVVAE_F32Q6] (fast fp32)
   char name[96];
 };
 
 #define CVVAE_ROW(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 0, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, \
     &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS>, nullptr, nullptr, nullptr}, ""},
 #define CVVAE_ROW_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 2, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 2, 0, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, \
     &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>, nullptr, nullptr, nullptr}, ""},
 #define CVVAE_ROW_XP(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 0, \
    {nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,1>, nullptr, nullptr}, ""},
 #define CVVAE_ROW_XQ(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 0, \
    {nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,2>, nullptr}, ""},
 #define CVVAE_ROW_XQ6(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
-  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 0, \
    {nullptr, nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3>}, ""},
 
-static Instance g_table[] = {CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ) CVVAE_CONV_XQ6(CVVAE_ROW_XQ6)};
+#define CVVAE_ROW_LD(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 1, \
+   {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,1,1>, \
+    &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,1,1>, nullptr, nullptr, nullptr}, ""},
+
+static Instance g_table[] = {CVVAE_CONV_LD(CVVAE_ROW_LD) CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ) CVVAE_CONV_XQ6(CVVAE_ROW_XQ6)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -104,6 +116,9 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
   // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
   cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
   if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)
+  // DMA-staged twins: same tile, no staging registers or VALU, every wave multiplies all the time (conv_kernel.h LD).
+  // CVVAE_CONV_DMA=0 takes them out (A/B aid), =<factor> scales their cost
+  if (e.ld) cost *= 0.9;
   // two N-blocks per wave: half the LDS operand reads per MFMA (the weight-traffic term above already charges its doubled weight
   // stream); CVVAE_CONV_NB2=<factor> scales its cost (tuning aid)
   if (e.nbw == 2) {
@@ -146,11 +161,20 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
   // (optional ":NB" suffix: 32-channel N-blocks per wave)
   int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0, fg = 0, fk = 0, fnb = 0;
   if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%dx%d:%d:%d", &ft, &fh, &fw, &fm, &fn, &fg, &fk, &fnb);
+  // A/B aid, read per call (the GPU tests flip it inside one process): CVVAE_CONV_DMA=0 takes the DMA-staged instances out
+  const char* dma_env = getenv("CVVAE_CONV_DMA");
+  const bool dma_off = dma_env && atoi(dma_env) == 0;
   auto eligible = [&](const Instance& e, bool forced) {
     if (!e.fn[d->dtype]) return false;  // fp32 models run the split-precision instances, fp16 / bf16 models the others
     if (forced && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) return false;
     if (forced && ft && fnb && e.nbw != fnb) return false;
     if (e.nbw == 2 && (d->Cout % 64)) return false;  // both N-blocks of every wave must be real
+    if (e.ld) {
+      if (dma_off || d->in_overlap) return false;
+      // the wave-loads address a pixel by a 32-bit byte offset from the tensor's base
+      if ((long long)d->B * d->Ti * d->Hi * d->Wi * d->in_pix_stride * 2 >= (1LL << 32)) return false;
+      if (d->sc_Cin && (long long)d->B * d->Ti * d->Hi * d->Wi * d->sc_in_pix_stride * 2 >= (1LL << 32)) return false;
+    }
     // the folded upsample (upsample2x == 2) runs 3x2x2 phase kernels; everything else matches the descriptor's taps
     const int fold = d->upsample2x == 2;
     if (e.kt != d->kT || e.kh != (fold ? 2 : d->kH) || e.kw != (fold ? 2 : d->kW)) return false;
@@ -187,7 +211,7 @@ static const Instance* odd_frame_sibling(const cvvae_conv_desc* d, const Instanc
   for (int i = 0; i < g_ntable; ++i) {
     const Instance& s = g_table[i];
     if (!s.fn[d->dtype]) continue;
-    if (s.tt == 1 && s.th == e->th && s.tw == e->tw && s.wm == e->wm && s.wn == e->wn && s.nbw == e->nbw && s.kg == e->kg && s.ksub == e->ksub &&
+    if (s.tt == 1 && s.th == e->th && s.tw == e->tw && s.wm == e->wm && s.wn == e->wn && s.nbw == e->nbw && s.ld == e->ld && s.kg == e->kg && s.ksub == e->ksub &&
         s.pro == e->pro && s.ups == e->ups && s.kt == e->kt && s.kh == e->kh && s.kw == e->kw && s.st == e->st && s.sh == e->sh &&
         s.sw == e->sw)
       return &s;
@@ -199,7 +223,7 @@ static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
     snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d%s", e->kt, e->kh, e->kw, e->st,
              e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups,
-             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->fn[4] ? "_xq6" : (e->nbw == 2 ? "_nb2" : ""))));
+             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->fn[4] ? "_xq6" : (e->nbw == 2 ? "_nb2" : (e->ld ? "_dma" : "")))));
   (void)dtype;
   return e->name;
 }

@@ -8,7 +8,7 @@ import os
 import numpy as np
 import torch
 
-from .golden_cases import BIG_CASES, CASES, DEC_CASES, ENC_CASES, recon_subsample
+from .golden_cases import BIG_CASES, CASES, DEC_CASES, ENC_CASES, grad_sample_index, recon_subsample
 from .seeded import seeded_input, seeded_state_dict
 
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
@@ -141,3 +141,59 @@ def measure_decode(model, name: str, golden_dir: str = GOLDEN_DIR) -> dict:
 def fmt(tag: str, m: dict) -> str:
     return (f"{m['case']:28s} {tag:5s} latent max|d| {m['latent_max_abs']:.3e} mean|d| {m['latent_mean_abs']:.3e}  "
             f"moments max|d| {m['moments_max_abs']:.3e}  recon max|d| {m['recon_max_abs']:.3e} PSNR {m['recon_psnr_db']:.2f} dB")
+
+
+def _rel_l2(a, b, floor=0.0):
+    a, b = torch.as_tensor(a).double().flatten(), torch.as_tensor(b).double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(floor if floor else 1e-30))
+
+
+def compare_grads_with_fixture(gold, part, net, y, gin):
+    """(forward rel, dL/d input rel, [(error, name)] worst first) of one network against the `part` ('enc' / 'dec') half of a
+    grad fixture: per parameter the worse of |norm - norm_ref| / norm_ref and the relative L2 error of the stored sample; tensors
+    whose reference gradient is (numerically) zero -- the attention's key bias -- are measured against 1e-3 of the largest norm"""
+    so, si = int(gold[part + "_out_stride"]), int(gold[part + "_gin_stride"])
+    yf, gf = y.detach().float().cpu(), gin.detach().float().cpu()
+    e_y = _rel_l2(recon_subsample(yf, so) if so > 1 else yf, gold[part + "_out_sub"])
+    e_x = _rel_l2(recon_subsample(gf, si) if si > 1 else gf, gold[part + "_gin_sub"])
+    names = [str(n) for n in gold[part + "_param_names"]]
+    norms, lens = gold[part + "_param_grad_norm"], gold[part + "_param_sample_len"]
+    samples = np.split(gold[part + "_param_grad_sample"], np.cumsum(lens)[:-1])
+    pars = dict(net.named_parameters())
+    assert sorted(pars) == names, sorted(set(pars) ^ set(names))
+    scale = float(norms.max())
+    errs = []
+    for n, nr, sr in zip(names, norms, samples):
+        g = pars[n].grad
+        assert g is not None and g.shape == pars[n].shape, n
+        g = g.detach().float().flatten().cpu()
+        idx = grad_sample_index(n, g.numel())
+        frac = (len(sr) / g.numel()) ** 0.5
+        e_n = abs(float(g.double().norm()) - float(nr)) / max(float(nr), 1e-3 * scale)
+        e_s = _rel_l2(g[idx], sr, 1e-3 * scale * frac)
+        errs.append((max(e_n, e_s), n))
+    return e_y, e_x, sorted(errs, reverse=True)
+
+
+def measure_backward(model, name: str = "grad_sd3_t17_256", golden_dir: str = GOLDEN_DIR) -> dict:
+    """`model`: a device model in train() mode carrying the case's seeded weights: forward + backward of both networks at the
+    fixture's size against the gradients of the reference's own modules (tests/golden/<name>.npz, oracle/make_golden.py grad)"""
+    from .golden_cases import GRAD_CASES
+    family, over, shape, wseed, xseed, cseeds, zseed, strides = GRAD_CASES[name]
+    gold = np.load(os.path.join(golden_dir, name + ".npz"))
+    dtype, dev = model.dtype, model.device
+    zshape = (shape[0], int(gold["enc_out_shape"][1]) // 2) + tuple(int(v) for v in gold["enc_out_shape"][2:])
+    out = {}
+    for part, net, inp, cseed in (("enc", model.encoder, seeded_input(shape, xseed), cseeds[0]),
+                                  ("dec", model.decoder, seeded_input(zshape, zseed), cseeds[1])):
+        net.zero_grad(set_to_none=True)
+        xin = inp.to(dtype).to(dev).requires_grad_(True)
+        y = net(xin)
+        cot = seeded_input(tuple(y.shape), cseed).to(dtype).to(dev)
+        (y.float() * cot.float()).sum().backward()
+        e_y, e_x, errs = compare_grads_with_fixture(gold, part, net, y, xin.grad)
+        out[part] = {"forward_rel": float(f"{e_y:.3e}"), "input_grad_rel": float(f"{e_x:.3e}"), "param_worst_rel": float(f"{errs[0][0]:.3e}"),
+                     "param_worst": errs[0][1], "param_median_rel": float(f"{errs[len(errs) // 2][0]:.3e}"), "n_param_tensors": len(errs)}
+        net.zero_grad(set_to_none=True)
+        del y, cot, xin
+    return out

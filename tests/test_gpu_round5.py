@@ -38,31 +38,7 @@ def _rel(a, b, floor=0.0):
     return float((a - b).norm() / b.norm().clamp_min(floor if floor else 1e-30))
 
 
-def compare_grads_with_fixture(gold, part, net, y, gin):
-    """(forward rel, dL/d input rel, [(error, name)] worst first) of one network against the `part` ('enc' / 'dec') half of a
-    grad fixture: per parameter the worse of |norm - norm_ref| / norm_ref and the relative L2 error of the stored sample; tensors
-    whose reference gradient is (numerically) zero -- the attention's key bias -- are measured against 1e-3 of the largest norm"""
-    so, si = int(gold[part + "_out_stride"]), int(gold[part + "_gin_stride"])
-    yf, gf = y.detach().float().cpu(), gin.detach().float().cpu()
-    e_y = _rel(recon_subsample(yf, so) if so > 1 else yf, gold[part + "_out_sub"])
-    e_x = _rel(recon_subsample(gf, si) if si > 1 else gf, gold[part + "_gin_sub"])
-    names = [str(n) for n in gold[part + "_param_names"]]
-    norms, lens = gold[part + "_param_grad_norm"], gold[part + "_param_sample_len"]
-    samples = np.split(gold[part + "_param_grad_sample"], np.cumsum(lens)[:-1])
-    pars = dict(net.named_parameters())
-    assert sorted(pars) == names, sorted(set(pars) ^ set(names))
-    scale = float(norms.max())
-    errs = []
-    for n, nr, sr in zip(names, norms, samples):
-        g = pars[n].grad
-        assert g is not None and g.shape == pars[n].shape, n
-        g = g.detach().float().flatten().cpu()
-        idx = grad_sample_index(n, g.numel())
-        frac = (len(sr) / g.numel()) ** 0.5
-        e_n = abs(float(g.double().norm()) - float(nr)) / max(float(nr), 1e-3 * scale)
-        e_s = _rel(g[idx], sr, 1e-3 * scale * frac)
-        errs.append((max(e_n, e_s), n))
-    return e_y, e_x, sorted(errs, reverse=True)
+compare_grads_with_fixture = P.compare_grads_with_fixture
 
 
 @pytest.mark.parametrize("dtype", DT, ids=["float32", "float16", "bfloat16"])
@@ -239,3 +215,124 @@ def test_layernorm_backward_beyond_one_launch_of_rows():
     (F.layer_norm(xr, (C,), gamma, beta, 1e-5) * go).sum().backward()
     gx, dg, db = ops.layernorm_bwd(x.cuda().view(1, 1, 1, n, C), go.cuda().view(1, 1, 1, n, C), gamma.detach().cuda(), beta.detach().cuda(), 1e-5)
     assert _rel(gx.cpu().view(n, C), xr.grad) <= 2e-5 and _rel(dg.cpu(), gamma.grad) <= 2e-4 and _rel(db.cpu(), beta.grad) <= 2e-4
+
+
+# ---- DMA-staged conv instances (conv_kernel.h LD): same tiles, same products in the same order as their register-staged twins -> the
+#      two forms must agree BIT FOR BIT on every padding flavour, fold, stride, tile overhang and epilogue
+def _both_forms(fn):
+    """fn() under CVVAE_CONV_DMA=0 and =1 -> (register-staged result, DMA-staged result, kernel name taken by the DMA run)"""
+    from cvvae_amd import ops
+    old = os.environ.get("CVVAE_CONV_DMA")
+    try:
+        os.environ["CVVAE_CONV_DMA"] = "0"
+        a = fn()
+        os.environ["CVVAE_CONV_DMA"] = "1"
+        names = []
+
+        def observer(d, pw, launch):
+            names.append(ops.conv_kernel_name(d))
+            launch()
+        ops.PROFILE = observer
+        b = fn()
+    finally:
+        ops.PROFILE = None
+        if old is None:
+            os.environ.pop("CVVAE_CONV_DMA", None)
+        else:
+            os.environ["CVVAE_CONV_DMA"] = old
+    return a, b, names
+
+
+DMA_CASES = [
+    # name, Cin, Cout, k, stride, pad, mode_t, mode_hw, (B,T,H,W), extras
+    ("c333_causal_128_two_frame_tile_odd_T", 128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), 1, 1, (1, 5, 24, 70), {}),
+    ("c333_sym_256to128_tfolds", 256, 128, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), 1, 1, (2, 4, 17, 40), {"tfolds": True}),
+    ("c333_zero_512_bn256", 512, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), 0, 0, (1, 3, 16, 64), {}),
+    ("c333_causal_zero_hw_256_small", 256, 256, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), 1, 0, (1, 5, 9, 33), {"tfolds": True}),
+    ("down222_128", 128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (1, 1), (1, 1)), 1, 1, (1, 9, 32, 48), {}),
+    ("down122_256", 256, 256, (3, 3, 3), (1, 2, 2), ((2, 0), (1, 1), (1, 1)), 1, 1, (1, 5, 20, 36), {}),
+    ("down222_vae3d_pad01", 128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (0, 1), (0, 1)), 1, 0, (1, 5, 16, 32), {}),
+    ("c133_zero_128_res_stats", 128, 128, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), 0, 0, (1, 3, 40, 64), {"res": True, "stats": True}),
+    ("c133_zero_256_shortcut", 256, 512, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), 0, 0, (2, 2, 16, 32), {"shortcut": 128}),
+    ("c111_512", 512, 512, (1, 1, 1), (1, 1, 1), ((0, 0), (0, 0), (0, 0)), 0, 0, (3, 1, 1, 300), {}),
+    ("upfold_256to512_time_shuffle", 256, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), 1, 1, (1, 3, 12, 20), {"up": True, "shuffle": True}),
+    ("upfold_512_zero_pad", 512, 512, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), 0, 0, (1, 2, 8, 33), {"up": True}),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bfloat16", "float16"])
+@pytest.mark.parametrize("case", DMA_CASES, ids=[c[0] for c in DMA_CASES])
+def test_dma_staged_instances_reproduce_the_register_staged_ones(case, dtype):
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+    name, cin, cout, k, stride, pad, mt, mhw, (B, T, H, W), ex = case
+    torch.manual_seed(len(name))
+    x = torch.randn(B, T, H, W, cin).to(dtype).cuda()
+    w = (torch.randn(cout, cin, *k) / (cin * k[0] * k[1] * k[2]) ** 0.5)
+    b = torch.randn(cout) * 0.1
+    if ex.get("up"):
+        pw = ops.pack_weight_upfold(w.to(dtype).cuda(), b.cuda(), 0, time_folds=(mt == 1))
+    elif ex.get("tfolds"):
+        pw = ops.pack_weight_tfolds(w.to(dtype).cuda(), b.cuda())
+    else:
+        pw = ops.pack_weight(w.reshape(cout, cin, -1).to(dtype).cuda(), b.cuda(), k)
+    kw = dict(stride=stride, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw)
+    if ex.get("up"):
+        kw.update(upsample2x=2, out_mode=L.OUT_TIME_SHUFFLE if ex.get("shuffle") else L.OUT_NDHWC)
+    if ex.get("res"):
+        kw["residual"] = torch.randn(B, T, H, W, cout).to(dtype).cuda()
+    if ex.get("stats"):
+        kw["gn_out"] = 32
+    if ex.get("shortcut"):
+        c2 = ex["shortcut"]
+        x2 = torch.randn(B, T, H, W, c2).to(dtype).cuda()
+        pw2 = ops.pack_weight((torch.randn(cout, c2, 1) / c2 ** 0.5).to(dtype).cuda(), None, (1, 1, 1))
+        kw["shortcut"] = (x2, pw2)
+
+    def run():
+        out = ops.conv(x, pw, **kw)
+        if isinstance(out, tuple):
+            return (out[0], out[1].buf)
+        return (out,)
+    a, bq, names = _both_forms(run)
+    assert names and all(n.endswith("_dma") for n in names), names
+    for u, v in zip(a, bq):
+        assert torch.equal(u, v), (name, names, float((u.float() - v.float()).abs().max()))
+    # ... and against fp32 F.conv3d on the same rounded operands (loose: this pins gross errors such as a stale halo plane)
+    if not ex.get("up") and not ex.get("shortcut"):
+        import torch.nn.functional as F
+        from tests.test_gpu_grad3d import _pad3
+        ref = F.conv3d(_pad3(x.float().cpu().permute(0, 4, 1, 2, 3), pad, mt, mhw), w.to(dtype).float(), b, stride=stride)
+        if ex.get("res"):
+            ref = ref + kw["residual"].float().cpu().permute(0, 4, 1, 2, 3)
+        got = bq[0].float().cpu().permute(0, 4, 1, 2, 3)
+        assert float((got - ref).abs().max()) <= (0.02 if dtype == torch.float16 else 0.06) * float(ref.abs().max())
+
+
+def test_whole_model_is_bit_identical_with_and_without_dma_staging():
+    """cfg-3-like pass of the sd3 model in bf16 (the folded upsample convs, the strided downsamplers, the 1x1 layers and the decoder's
+    conv_in take the DMA-staged instances by default), and the same with the GroupNorm + SiLU pass in front of every conv
+    (CVVAE_PREPASS=1: every conv then runs without prologue, i.e. DMA-staged): identical bits to the register-staged instances"""
+    import cvvae_amd
+    m = cvvae_amd.CVVAESD3Model()
+    P.load_seeded(m, 0)
+    m = m.to(torch.bfloat16).cuda().eval()
+    x = seeded_input((1, 3, 9, 128, 160), 3).to(torch.bfloat16).cuda()
+
+    def run():
+        z = m.encode(x).latent_dist.mode()
+        return z, m.decode(z).sample
+    old = os.environ.get("CVVAE_PREPASS")
+    try:
+        for pre in ("0", "1"):
+            os.environ["CVVAE_PREPASS"] = pre
+            a, b, names = _both_forms(run)
+            assert any(n.endswith("_dma") for n in names)
+            if pre == "1":
+                assert sum(n.endswith("_dma") for n in names) >= 0.8 * len(names), names
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), pre
+    finally:
+        if old is None:
+            os.environ.pop("CVVAE_PREPASS", None)
+        else:
+            os.environ["CVVAE_PREPASS"] = old

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--autocast", default=None, choices=["bf16", "f16"],
                     help="with --dtype f32: run the step under torch.autocast (fp32 master weights, 16-bit launches) and nudge the "
                          "masters between steps as an optimizer would (so every step re-casts and re-packs the weights)")
+    ap.add_argument("--no-golden", action="store_true", help="skip the gradient comparison with the reference-generated fixture")
     ap.add_argument("--cprofile", default=None, help="write a cProfile listing of one more step (host side) to this file")
     args = ap.parse_args()
     import cvvae_amd
@@ -126,6 +127,19 @@ def main():
                          "host_launch_ms": round(host_launch, 2), "host_wait_for_gpu_ms": round(host_wait, 2),
                          "parameters_with_grad": ngrad, "parameters": sum(1 for _ in m.parameters()),
                          "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2**30, 2)}
+    # ---- the gradients of a step of THIS size against the reference's own modules (tests/golden/grad_sd3_t17_256.npz:
+    #      oracle/make_golden.py grad): the checker leg, after every timed region
+    gpath = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "grad_sd3_t17_256.npz")
+    if (args.T, args.H, args.W) == (17, 256, 256) and acd is None and os.path.isfile(gpath) and not args.no_golden:
+        from oracle import parity as P
+        del m
+        torch.cuda.empty_cache()
+        mg = cvvae_amd.CVVAESD3Model()
+        P.load_seeded(mg, 0)
+        mg = mg.to(dtype).cuda().train()
+        out["gradient_parity_vs_reference_modules"] = dict(
+            P.measure_backward(mg), fixture="tests/golden/grad_sd3_t17_256.npz (the reference's Encoder3D / Decoder3D under torch.autograd, "
+                                            "CPU fp32, seeded weights, seeded cotangent)", metric="relative L2")
     print(json.dumps(out))
 
 
