@@ -1093,6 +1093,9 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     if constexpr (LD) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     else __syncthreads();
   }
+  // LD: the ring's read-ahead of the last chunk is still in flight, requested by asm statements hipcc knows nothing about: once the
+  // loop is over it would hand the ring's registers to the epilogue (addresses, bias) and the late records would land on top of them
+  if constexpr (LD) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   // ---- fused 1x1 shortcut: more K chunks over the second input through the centre tap (the final barrier of the loop
   //      above has released both halo buffers)
   if constexpr (KT == 1 && KH == 3 && KW == 3 && ST == 1 && SH == 1 && SW == 1 && KG == 1 && UPS == 0 && XP < 2) {
