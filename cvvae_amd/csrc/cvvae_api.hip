@@ -161,11 +161,14 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
   // (optional ":NB" suffix: 32-channel N-blocks per wave)
   int ft = 0, fh = 0, fw = 0, fm = 0, fn = 0, fg = 0, fk = 0, fnb = 0;
   if (const char* f = getenv("CVVAE_CONV_FORCE")) sscanf(f, "%dx%dx%d:%dx%dx%d:%d:%d", &ft, &fh, &fw, &fm, &fn, &fg, &fk, &fnb);
-  // The DMA-staged instances are an OPT-IN (CVVAE_CONV_DMA=1; read per call: the GPU tests flip it inside one process).  Measured
-  // (profiles/r5_ab_dma_staging.log): bit-identical results and the same time to +-2 % as their register-staged twins -- the big convs
-  // sit on the board's power frontier, not on the issue rate of a lone multiplying wave
+  // The DMA-staged instances are taken where they exist (CVVAE_CONV_DMA=0 takes them out; read per call: the GPU tests flip it inside
+  // one process).  Measured (profiles/r5_ab_dma_staging.log, three interleaved rounds on one box): bit-identical results; cfg 3
+  // 68.97 -> 68.50 ms per step with the layers that have no prologue (folded upsample convs, strided downsamplers, 1x1 layers) on
+  // them; the 3x3x3 layers behind the GroupNorm + SiLU pass run at the SAME time in either form -- matrix-pipe busy x clock is 0.44-0.50
+  // of nominal both ways (profiles/r5_pmc_sq_dma{0,1}.txt): those kernels sit on the board's power frontier, not on the issue rate of
+  // a lone multiplying wave
   const char* dma_env = getenv("CVVAE_CONV_DMA");
-  const bool dma_off = !(dma_env && atoi(dma_env) != 0);
+  const bool dma_off = dma_env && atoi(dma_env) == 0;
   auto eligible = [&](const Instance& e, bool forced) {
     if (!e.fn[d->dtype]) return false;  // fp32 models run the split-precision instances, fp16 / bf16 models the others
     if (forced && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) return false;
