@@ -112,11 +112,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   //      Task -> lane order: 16 consecutive lanes are 4 k blocks x 4 channel groups (4-channel tasks) or 8 k blocks x 2 groups
   //      (8-channel tasks) -- rows 4 (8) apart are 16 (32) banks apart at this row pitch, so the 16 sixteen-byte writes of a quarter
   //      wave tile all 64 banks (channel-group-fastest order was 4- to 8-way conflicted).
-  // (the task kind is WAVE-uniform -- whole waves of x tasks, then whole waves of g tasks -- and is derived from a scalar so that the
-  //  two kinds are separate scalar branches: as per-lane predicates hipcc merged their register writes into dynamically indexed ones)
-  static_assert(NXT % 64 == 0 && NGT % 64 == 0, "staging tasks: whole waves per kind");
-  const int wv_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const bool is_x = wv_u < NXT / 64, is_g = wv_u >= NXT / 64 && wv_u < (NXT + NGT) / 64;
+  const bool is_x = tid < NXT, is_g = tid >= NXT && tid < NXT + NGT;
   auto decode = [](int t, int ch, int nc, int& kb, int& cg, int& rest) {
     const int kl = ch == 4 ? 2 : 3, cl = ch == 4 ? 2 : 1;   // low bits of kb / cg inside a 16-lane group
     const int kbl = t & ((1 << kl) - 1), cgl = (t >> kl) & ((1 << cl) - 1);
@@ -134,13 +130,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   decode(tid - NXT, CHG, NCG, gt_kb, gt_cg, gt_rest);
   (void)gt_rest;
   constexpr int NREG = NL > 8 ? NL : 8;
-  // A panel's staging registers.  16-bit models: an x task keeps 8 bytes per pixel (NL pixels, two per uint4), a g task 16 (8
-  // pixels): NR4 = max(ceil(NL / 2), 8) uint4 per panel instead of max(NL, 8), so that TWO panels of prefetch fit beside the 144
-  // accumulators.  (Both task kinds write WHOLE uint4 elements at static indices: with word-granular layouts hipcc merged the two
-  // branches' stores into dynamically indexed ones and sent the array to scratch.)
-  constexpr int NR4 = XP ? NREG : ((NL + 1) / 2 > 8 ? (NL + 1) / 2 : 8);
-  typedef uint4 Raw[NR4];
-  auto load_panel = [&](long long pi, Raw& raw) __attribute__((always_inline)) {
+  uint4 raw[NREG];
+  auto load_panel = [&](long long pi) {
     const long long pg_ = pbeg + pi;
     const int row = (int)(pg_ / npanel_row), x0 = (int)(pg_ % npanel_row) * KP;
     const int yo = row % p.Ho, to = (row / p.Ho) % p.To, b = row / (p.Ho * p.To);
@@ -151,52 +142,37 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
       const int c = ci0 + xt_cg * CHX;
       const TIO* rowp = ap + (((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi * p.a_ps + c;
       const int xb = (x0 + xt_kb * 8) * SW - p.pw;  // unpadded input column of pixel 0 of my block
-      auto x_pixel = [&](int i) -> uint4 {  // pixel i of my block: 4 floats (fp32 models) or 4 x 16 bit in .x, .y
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
         bool zero = zrow;
         const int xsrc = map_coord(xb + i, p.Wi, p.mode_hw, zero);
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
         if (!zero && c < p.Cin) {
           if constexpr (XP) {
-            r = *reinterpret_cast<const uint4*>(rowp + (long long)xsrc * p.a_ps);
+            r = *reinterpret_cast<const uint4*>(rowp + (long long)xsrc * p.a_ps);   // 4 floats
           } else {
-            const uint2 v2 = *reinterpret_cast<const uint2*>(rowp + (long long)xsrc * p.a_ps);
-            r.x = v2.x;
-            r.y = v2.y;
+            const uint2 v2 = *reinterpret_cast<const uint2*>(rowp + (long long)xsrc * p.a_ps);  // 4 x 16 bit
+            r = make_uint4(v2.x, v2.y, 0u, 0u);
           }
         }
-        return r;
-      };
-      // (BOTH task kinds write raw[0 .. NR4) in index order, padding with zeros: hipcc sinks the two branches' stores into common
-      //  code, and with different index sequences that made the index dynamic -- and the array a scratch array)
-      if constexpr (XP) {
-#pragma unroll
-        for (int i = 0; i < NR4; ++i) raw[i] = i < NL ? x_pixel(i) : make_uint4(0u, 0u, 0u, 0u);
-      } else {
-#pragma unroll
-        for (int k = 0; k < NR4; ++k) {  // two pixels per register quad, written as ONE element
-          const uint4 lo2 = 2 * k < NL ? x_pixel(2 * k) : make_uint4(0u, 0u, 0u, 0u);
-          const uint4 hi2 = 2 * k + 1 < NL ? x_pixel(2 * k + 1) : make_uint4(0u, 0u, 0u, 0u);
-          raw[k] = make_uint4(lo2.x, lo2.y, hi2.x, hi2.y);
-        }
+        raw[i] = r;
       }
     } else if (is_g) {
       const int c = co0 + gt_cg * CHG;
       const TIO* rowp = gp + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * p.g_ps + c;
       const int kx = x0 + gt_kb * 8;
 #pragma unroll
-      for (int i = 0; i < NR4; ++i) {
+      for (int i = 0; i < 8; ++i) {
         uint4 r = make_uint4(0u, 0u, 0u, 0u);
-        if (i < 8 && kx + i < p.Wo && c < p.Cout) r = *reinterpret_cast<const uint4*>(rowp + (long long)(kx + i) * p.g_ps);
+        if (kx + i < p.Wo && c < p.Cout) r = *reinterpret_cast<const uint4*>(rowp + (long long)(kx + i) * p.g_ps);
         raw[i] = r;
       }
     }
   };
   // my task's pixels -> the storage type T, packed per pixel: `hi` (16-bit models: the loaded 8-channel vector itself) and, for
   // fp32 models (4 floats per pixel), hi = T(x) and lo = T(x - hi) in the low halves of the vectors
-  // (x8: the task's pixels are 8-byte x vectors -- 16-bit models' x tasks; else 16 bytes per pixel)
-  auto convert = [&](auto n_tag, auto x8_tag, const Raw& raw, uint4 (&hi)[NREG], uint4 (&lo)[NREG]) __attribute__((always_inline)) {
+  auto convert = [&](auto n_tag, uint4 (&hi)[NREG], uint4 (&lo)[NREG]) {
     constexpr int N = decltype(n_tag)::value;
-    constexpr bool X8 = decltype(x8_tag)::value;
 #pragma unroll
     for (int i = 0; i < N; ++i) {
       if constexpr (XP) {
@@ -209,15 +185,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
         }
         hi[i] = pack8<T>(fh);
         lo[i] = pack8<T>(fl);
-      } else if constexpr (X8) {
-        hi[i] = (i & 1) ? make_uint4(raw[i >> 1].z, raw[i >> 1].w, 0u, 0u) : make_uint4(raw[i >> 1].x, raw[i >> 1].y, 0u, 0u);
       } else {
         hi[i] = raw[i];
       }
     }
   };
   // pixels first, first + step, ..., first + 7 step of px -> CH channel rows of 8 consecutive k each (16-byte LDS writes)
-  auto put_block = [&](auto nch_tag, const uint4 (&px)[NREG], int first, int step, char* dst) __attribute__((always_inline)) {
+  auto put_block = [&](auto nch_tag, const uint4 (&px)[NREG], int first, int step, char* dst) {
     constexpr int NCH = decltype(nch_tag)::value;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
@@ -229,10 +203,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
       *reinterpret_cast<uint4*>(dst + j * ROWP) = o;
     }
   };
-  auto store_panel = [&](const Raw& raw) __attribute__((always_inline)) {
+  auto store_panel = [&]() {
     uint4 hi[NREG], lo[NREG];
     if (is_x) {
-      convert(std::integral_constant<int, NL>{}, std::integral_constant<bool, !XP>{}, raw, hi, lo);
+      convert(std::integral_constant<int, NL>{}, hi, lo);
 #pragma unroll
       for (int dx = 0; dx < KHW; ++dx) {
         char* dst = xs + ((xt_dy * KHW + dx) * CI + xt_cg * CHX) * ROWP + xt_kb * 16;
@@ -240,7 +214,7 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
         if constexpr (XP) put_block(std::integral_constant<int, CHX>{}, lo, dx, SW, dst + XS_BYTES);
       }
     } else if (is_g) {
-      convert(std::integral_constant<int, 8>{}, std::integral_constant<bool, false>{}, raw, hi, lo);
+      convert(std::integral_constant<int, 8>{}, hi, lo);
       char* dst = gs + (gt_cg * CHG) * ROWP + gt_kb * 16;
       put_block(std::integral_constant<int, CHG>{}, hi, 0, 1, dst);
       if constexpr (XP) put_block(std::integral_constant<int, CHG>{}, lo, 0, 1, dst + GS_BYTES);
@@ -253,18 +227,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
 
   // 16-bit models: the loads of panel i+1 fly under the MFMAs of panel i (40-68 registers of prefetch).  fp32 models: no room
   // beside the 144 accumulators and the three-MFMA operand sets -- the loads are issued right before they are staged
-  // (round 5: TWO panels of prefetch -- the counters of the one-panel form said the kernel waits on its global side: wait_any 0.44
-  //  of the wave cycles with one workgroup per CU and the loads of panel i+1 issued one MFMA phase, ~1 us, ahead of their use.
-  //  Panel i+2's loads now go out as soon as panel i's registers are staged: two MFMA phases + a staging phase to arrive.)
   constexpr bool PREFETCH = !XP;
-  Raw rawA, rawB;
-  if (PREFETCH && npanels > 0) load_panel(0, rawA);
-  if (PREFETCH && npanels > 1) load_panel(1, rawB);
-  auto panel = [&](long long pi, Raw& raw) __attribute__((always_inline)) {
-    if (!PREFETCH) load_panel(pi, raw);
-    store_panel(raw);
+  if (PREFETCH && npanels > 0) load_panel(0);
+  for (long long pi = 0; pi < npanels; ++pi) {
+    if (!PREFETCH) load_panel(pi);
+    store_panel();
     __syncthreads();
-    if (PREFETCH && pi + 2 < npanels) load_panel(pi + 2, raw);
+    if (PREFETCH && pi + 1 < npanels) load_panel(pi + 1);
 #pragma unroll
     for (int s = 0; s < KP / 16; ++s) {
       const v8 ah = *reinterpret_cast<const v8*>(gs + a_off + s * 32);
@@ -282,14 +251,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
       }
     }
     __syncthreads();
-  };
-  if constexpr (PREFETCH) {
-    for (long long pi = 0; pi < npanels; pi += 2) {
-      panel(pi, rawA);
-      if (pi + 1 < npanels) panel(pi + 1, rawB);
-    }
-  } else {
-    for (long long pi = 0; pi < npanels; ++pi) panel(pi, rawA);
   }
   // partial tile: part[slab][tap][co][ci]; accumulator register i of a lane = output channel 8*(i/4) + 4*(lane/32) + i%4 of the
   // fragment, input channel lane % 32

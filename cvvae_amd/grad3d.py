@@ -397,9 +397,6 @@ def run_trainable(net, x: torch.Tensor, kwargs: dict) -> torch.Tensor:
     (or, `net.recompute`, one node that keeps only x and re-runs the taped pass in its backward)"""
     if kwargs:
         raise NotImplementedError(f"training-mode forward takes no extra arguments (got {sorted(kwargs)})")
-    # parameters written through `.data` since the last pass (EMA swaps: lvdm/modules/ema.py:61-86) do not move the cache's keys:
-    # a device-side checksum does (one sync per training pass)
-    net._cache().guard()
     named = [(n, p) for n, p in net.named_parameters()]
     if getattr(net, "recompute", False):
         return Net3DRecomputeFn.apply(x, net, tuple(n for n, _ in named), *[p for _, p in named])

@@ -111,6 +111,13 @@ class _Net(nn.Module):
         # main.py:905-912): the pass runs on 16-bit copies of the weights and returns the autocast dtype, as F.conv3d would
         # (the dtype is set for THIS pass and restored afterwards: WeightCache.computing_in)
         cd = self._pass_dtype(x)
+        if self.weight_guard or self._guard_pending:
+            # parameters written through `.data` (EMA swaps: lvdm/modules/ema.py:61-86) do not move the cache's keys; a device-side
+            # checksum does.  It costs a host sync (measured: the host then trails the GPU for the first ~7 ms of a training step), so
+            # by default it runs ONCE after every train() / eval() transition -- the trainers swap EMA weights between those calls and
+            # the passes (eval() -> copy_to -> validation passes -> restore -> train()) -- and on every pass only with `weight_guard`
+            object.__setattr__(self, "_guard_pending", False)
+            self.refresh_weights(only_if_changed=True)
         with self._cache().computing_in(cd):
             if (self._trainable and self.training and torch.is_grad_enabled()
                     and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
@@ -118,8 +125,6 @@ class _Net(nn.Module):
                 # launches with a tape, two autograd nodes (body + tail) over (x, parameters).  eval() mode / no_grad: the inference pass below
                 from . import grad3d
                 return grad3d.run_trainable(self, x, kwargs)
-            if self.weight_guard:
-                self.refresh_weights(only_if_changed=True)
             with torch.no_grad():
                 return self._forward_inference(x, **kwargs)
 
@@ -127,10 +132,15 @@ class _Net(nn.Module):
     # torch.autocast but without the context -- `CVVAEModel.decoder_compute_dtype` builds the mixed tolerance mode on it (fp32-fast
     # encoder: latents inside north_star's 1e-3 bound; 16-bit decoder).  None = the parameters' own dtype.
     compute_dtype_override: Optional[torch.dtype] = None
-    # inference passes re-check a device-side checksum of the parameters first (one sync per pass) and drop stale packed forms:
-    # for callers that write weights through `.data` (EMA swaps) and cannot call refresh_weights() themselves.  The TRAINING path
-    # (train() mode under grad mode) always checks.
+    # every pass re-checks a device-side checksum of the parameters first (one sync per pass) and drops stale packed forms: for
+    # callers that write weights through `.data` at arbitrary moments and cannot call refresh_weights() themselves.  Default: the
+    # check runs once after each train() / eval() transition (see forward).
     weight_guard: bool = os.environ.get("CVVAE_WEIGHT_GUARD", "0") == "1"
+    _guard_pending: bool = False
+
+    def train(self, mode: bool = True):
+        object.__setattr__(self, "_guard_pending", True)
+        return super().train(mode)
 
     def _pass_dtype(self, x: torch.Tensor) -> Optional[torch.dtype]:
         if self.conv_in.weight.dtype != torch.float32:

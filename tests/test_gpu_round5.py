@@ -156,12 +156,17 @@ def test_weights_written_through_data_and_refresh_weights():
     assert torch.equal(m.encoder(x), y3) and not torch.equal(y3, y2)
     m.encoder.weight_guard = False
     m.enable_hip_graphs(False)
-    # training path: always guarded
+    # train() / eval() transitions arm one check: the trainers' EMA swaps sit between a transition and the passes that follow it
     m.train()
     ya = m.encoder(x.clone().requires_grad_(True))
-    w.data.mul_(2.0)
+    m.eval()
+    w.data.mul_(2.0)                        # LitEma.copy_to after pl_module.eval()
+    yv = m.encoder(x)
+    assert not torch.equal(ya.detach(), yv)
+    w.data.mul_(0.5)                        # LitEma.restore, then pl_module.train()
+    m.train()
     yb = m.encoder(x.clone().requires_grad_(True))
-    assert not torch.equal(ya.detach(), yb.detach())
+    assert torch.equal(ya.detach(), yb.detach())
     with torch.no_grad():
         w.mul_(1.01)
     with pytest.raises(RuntimeError, match="modified"):
@@ -304,8 +309,8 @@ def test_dma_staged_instances_reproduce_the_register_staged_ones(case, dtype):
     if same:
         for u, v in zip(a, bq):
             assert torch.equal(u, v), (name, names, float((u.float() - v.float()).abs().max()))
-    else:  # (another tile: the stored values agree to the output rounding; the statistics records are laid out per tile)
-        assert name.startswith("c133_zero_128"), (name, names)
+    else:  # (the register-staged list lacks this tile without prologue: another tile, at most another summation order; the
+        #       statistics records are laid out per tile)
         d = float((a[0].float() - bq[0].float()).abs().max())
         assert d <= (2e-2 if dtype == torch.float16 else 1.2e-1), d
     # ... and against fp32 F.conv3d on the same rounded operands (loose: this pins gross errors such as a stale halo plane)

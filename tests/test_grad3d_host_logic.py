@@ -343,13 +343,14 @@ def test_refresh_weights_after_a_write_through_data():
         y2 = m.encoder(x)
         assert not torch.allclose(y2, y1)
         m.encoder.weight_guard = False
-        # the training path always checks
+        # a train() / eval() transition arms one check
         m.train()
         xa = x.clone().requires_grad_(True)
         ya = m.encoder(xa)
+        m.eval()
         w.data.mul_(0.5)
-        yb = m.encoder(x.clone().requires_grad_(True))
-        assert torch.allclose(yb.detach(), y1, rtol=1e-5, atol=1e-6) and not torch.allclose(ya.detach(), yb.detach())
+        yb = m.encoder(x)
+        assert torch.allclose(yb, y1, rtol=1e-5, atol=1e-6) and not torch.allclose(ya.detach(), yb)
 
 
 def test_backward_after_a_parameter_update_raises():
