@@ -83,18 +83,21 @@
   X(1,1,1, 1,1,1, 1,1,256, 2,4,1, 8, 2,0)
 
 // FOUR-wave instances (WM x WN x KG = 4: 256 threads, <= 80 KiB of LDS, two workgroups resident per CU) for the 128-channel
-// layers at 17x512^2, whose staging VALU work (GroupNorm + SiLU of every halo element for only 128 output channels) and store
-// tail are too large a share of a tile to hide inside one workgroup: see conv_kernel.h (NWV) and DESIGN.md section 3.1
-// NOT BUILT BY DEFAULT (make NW4=1 / -DCVVAE_BUILD_NW4): with two workgroups co-resident on a CU about one fused GroupNorm record
-// in 10^4 came out wrong and differed from run to run (root cause unknown), so the instances exist for
-// that investigation only.
+// layers at full resolution, whose staging VALU work (GroupNorm + SiLU of every halo element for only 128 output channels) and store
+// tail are too large a share of a tile to hide inside one workgroup: see conv_kernel.h (NWV) and DESIGN.md section 3.1.
+// The per-frame instance (+6 % on the ResnetBlock conv2 of the 128-channel level) is BUILT, and selected only after the host's
+// self-check on the device at hand (cvvae_conv_set_four_wave; engine.four_wave_selfcheck): round 2 saw about one fused GroupNorm
+// record in 10^4 come out wrong with two workgroups co-resident on one box of the pool, round 3 could not reproduce it on four
+// others (150 repetitions each) -- a box-dependent fault is what a per-device check at load time is for.  The two 3x3x3 forms were
+// slower than the 8-wave two-frame tile (-4 %) and stay behind make NW4=1.
 #ifdef CVVAE_BUILD_NW4
 #define CVVAE_CONV_G11(X) \
   X(1,3,3, 1,1,1, 1,8,32, 1,4,1, 2, 1,0) \
   X(3,3,3, 1,1,1, 2,8,16, 1,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 1,8,16, 1,4,1, 1, 1,0)
 #else
-#define CVVAE_CONV_G11(X)
+#define CVVAE_CONV_G11(X) \
+  X(1,3,3, 1,1,1, 1,8,32, 1,4,1, 2, 1,0)
 #endif
 
 // Split-precision (XP) instances for fp32 models: fp32 activations in HBM, every product as three fp16 MFMAs (conv_kernel.h).
@@ -204,11 +207,12 @@
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 0,0) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 0,0)
+// (the strided downsamplers were built and measured too: 1.28-1.31 ms per cfg 3 step DMA-staged against 1.22-1.26 register-staged --
+//  their 64-pixel tiles spend the chunk waiting for the wave-loads either way, and the deeper hand-kept weight ring costs them
+//  occupancy; not in the list.  profiles/r5_ab_dma_staging.log)
 #define CVVAE_CONV_LD_B(X) \
   X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 2, 0,2) \
   X(3,2,2, 1,1,1, 1,8,32, 1,8,1, 1, 0,2) \
-  X(3,3,3, 2,2,2, 1,4,16, 1,8,1, 2, 0,0) \
-  X(3,3,3, 1,2,2, 1,4,16, 1,8,1, 2, 0,0) \
   X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 8, 0,0)
 #define CVVAE_CONV_LD_C(X) \
   X(1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 0,0) \

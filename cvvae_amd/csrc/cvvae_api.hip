@@ -84,6 +84,9 @@ static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
+// cost factor of the four-wave instances (0: not selected), set by cvvae_conv_set_four_wave
+static double g_four_wave_factor = 0.0;
+
 // compute units of the current device (256 on MI355X); used by the instance cost model only
 static int cu_count() {
   static int cus = 0;
@@ -125,12 +128,12 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
     static const double nb2 = getenv("CVVAE_CONV_NB2") ? atof(getenv("CVVAE_CONV_NB2")) : 1.0;
     cost *= nb2;
   }
-  // four-wave instances (two workgroups per CU): NOT selected by default.  Measured (profiles/r2_ab_4wave_*.log): per-frame 3x3 at
-  // 128 channels with residual + statistics 1.71 -> 1.62 ms (+6 %), 3x3x3 at 128 channels 3.38 -> 3.55 ms (-4 %) -- but with two
-  // workgroups resident on a CU a few of the fused GroupNorm records came out wrong and differed from run to run (DESIGN.md
-  // section 3.1, unexplained).  CVVAE_CONV_NW4=<factor> makes them eligible (tuning / debugging aid).
+  // four-wave instances (two workgroups per CU): selected only after cvvae_conv_set_four_wave(factor > 0) -- the host calls it when
+  // its self-check on this device came back clean (engine.four_wave_selfcheck: +6 % on the per-frame 128-channel conv with residual
+  // + statistics, 1.71 -> 1.62 ms at 17x512^2; profiles/r2_ab_4wave_*.log).  CVVAE_CONV_NW4=<factor> overrides (tuning / debugging aid).
   if (e.wm * e.wn * e.kg == 4) {
-    static const double nw4 = getenv("CVVAE_CONV_NW4") ? atof(getenv("CVVAE_CONV_NW4")) : 0.0;
+    static const double nw4_env = getenv("CVVAE_CONV_NW4") ? atof(getenv("CVVAE_CONV_NW4")) : -1.0;
+    const double nw4 = nw4_env >= 0.0 ? nw4_env : g_four_wave_factor;
     cost *= nw4 > 0.0 ? nw4 : 100.0;
   }
   // strided convs do 4-8x fewer MFMAs per staged byte and their halos (430 KiB per workgroup at 128 channels) do not survive in
@@ -281,6 +284,12 @@ static int check_desc(const cvvae_conv_desc* d) {
 using namespace cvvae;
 
 extern "C" {
+
+int cvvae_conv_set_four_wave(double factor) {
+  if (!(factor >= 0.0) || factor > 100.0) return CVVAE_EINVAL;
+  g_four_wave_factor = factor;
+  return CVVAE_OK;
+}
 
 const char* cvvae_conv_kernel_name(const cvvae_conv_desc* d) {
   if (check_desc(d) != CVVAE_OK) return nullptr;

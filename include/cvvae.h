@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 10
+#define CVVAE_ABI_VERSION 11
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
@@ -411,6 +411,12 @@ int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t
  * rows = B*C*T.  a is [rows][Ha][Wa], b is [rows][Hb][Wb]. */
 int cvvae_blend(int32_t dtype, const void* a, int32_t Ha, int32_t Wa, void* b, int32_t Hb, int32_t Wb, int64_t rows,
                 int32_t overlap, int32_t axis, void* stream);
+
+/* Process-wide switch of the four-wave conv instances (two workgroups resident per CU; csrc/conv_table.h G11): factor > 0 makes them
+ * eligible with their cost scaled by `factor` (the host passes ~0.95 after its per-device self-check, cvvae_amd/engine.py
+ * four_wave_selfcheck), 0 takes them out (the default).  Not a per-launch argument: the choice of instance fixes the layout of the
+ * fused GroupNorm records, so it must not change between cvvae_conv_gn_slabs and the launch.  No reference counterpart. */
+int cvvae_conv_set_four_wave(double factor);
 
 int cvvae_abi_version(void);
 /* name of the kernel instance cvvae_conv_fwd would launch for d (for profiling reports); NULL if unsupported */
