@@ -154,7 +154,10 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
     // at 256 channels, 9x64x64 at 512) the 256-pixel tile is 15-23 % faster even at 1.1-2.25 rounds
     // (profiles/r4_tune_instances_cfg2.log): 0.1 keeps the term as the tie-breaker against starved grids (5x32x32: 40 workgroups)
     static const double quant_w = getenv("CVVAE_CONV_QUANT_W") ? atof(getenv("CVVAE_CONV_QUANT_W")) : 0.1;
-    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + quant_w * (ceil(wgs / cus) / (wgs / cus) - 1.0);
+    // (round 5: a STARVED grid -- fewer workgroups than CUs -- pays its empty CUs in full: vae3d's 512-channel 3x3x3 convs at 5x32x32
+    //  run 80 workgroups of the BN = 256 tile in 0.181 ms and 320 of the BN = 32 tile in 0.160 ms, profiles/r5_tune_instances_cfg2.log)
+    const double qw = wgs < cus ? 1.0 : quant_w;
+    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + qw * (ceil(wgs / cus) / (wgs / cus) - 1.0);
   }
   return cost;
 }
@@ -177,6 +180,10 @@ static const Instance* select_instance(const cvvae_conv_desc* d) {
     if (forced && ft && (e.tt != ft || e.th != fh || e.tw != fw || e.wm != fm || e.wn != fn || e.kg != fg || e.ksub != fk)) return false;
     if (forced && ft && fnb && e.nbw != fnb) return false;
     if (e.nbw == 2 && (d->Cout % 64)) return false;  // both N-blocks of every wave must be real
+    // four-wave instances: measured where they pay -- ONE N tile (Cout <= 128: with more, the BN = 256 eight-wave tiles win: cfg 3's
+    // 256/512-channel per-frame convs 7.66 -> 7.7 ms, cfg 1's image-mode convs 2.76 -> 3.37 ms) on frames large enough to keep
+    // every CU double-occupied (17x256^2: +9-13 %, 4x512^2: +2-6 %; profiles/r5_tune_instances_cfg2.log)
+    if (e.wm * e.wn * e.kg == 4 && (d->Cout > 128 || (long long)d->B * d->To * d->Ho * d->Wo < (1LL << 19))) return false;
     if (e.ld) {
       if (dma_off || d->in_overlap) return false;
       // the wave-loads address a pixel by a 32-bit byte offset from the tensor's base
