@@ -154,10 +154,11 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
     // at 256 channels, 9x64x64 at 512) the 256-pixel tile is 15-23 % faster even at 1.1-2.25 rounds
     // (profiles/r4_tune_instances_cfg2.log): 0.1 keeps the term as the tie-breaker against starved grids (5x32x32: 40 workgroups)
     static const double quant_w = getenv("CVVAE_CONV_QUANT_W") ? atof(getenv("CVVAE_CONV_QUANT_W")) : 0.1;
-    // (round 5: a STARVED grid -- fewer workgroups than CUs -- pays its empty CUs in full: vae3d's 512-channel 3x3x3 convs at 5x32x32
-    //  run 80 workgroups of the BN = 256 tile in 0.181 ms and 320 of the BN = 32 tile in 0.160 ms, profiles/r5_tune_instances_cfg2.log)
-    const double qw = wgs < cus ? 1.0 : quant_w;
-    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + qw * (ceil(wgs / cus) / (wgs / cus) - 1.0);
+    // (round 5: charging a STARVED grid -- fewer workgroups than CUs -- its empty CUs in full was tried: right for vae3d's 512-channel
+    //  3x3x3 convs at 5x32x32 (80 workgroups of the BN = 256 tile 0.181 ms, 320 of the BN = 32 tile 0.160 ms) and wrong for cfg 3's at
+    //  5x64x64 (160 workgroups of the 256-pixel tile 0.29 ms, 320 of the 128-pixel tile 0.30 ms: +1.3 ms per step).  Not kept;
+    //  profiles/r5_ab_four_wave.log, profiles/r5_tune_instances_cfg2.log)
+    if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + quant_w * (ceil(wgs / cus) / (wgs / cus) - 1.0);
   }
   return cost;
 }
