@@ -263,6 +263,228 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// wgrad_dma_kernel (round 5; 16-bit models, 3x3 spatial taps): the same tile and the same partial-tile output as wgrad_kernel, with
+// NOTHING staged through registers.  The contraction runs over pixels, the slow axis of both operands, and wgrad_kernel pays for
+// that with a register transpose of every staged block and 96 KB of transposing LDS writes per panel, alternating with its 36
+// MFMAs per wave behind two barriers (0.23 of the MFMA peak, the matrix pipe 0.29 busy at 2.2 GHz: not power-limited).  gfx950 has
+// the two instructions that remove both: global_load_lds_dwordx4 (a wave-load puts lane i's 16 bytes at LDS base + 16 i: the tiles
+// go global -> LDS in their NATURAL pixel-major layout) and ds_read_b64_tr_b16 (a 16-lane group reads a [4 rows][16 columns] block of
+// 16-bit elements through per-lane 8-byte chunk addresses and every lane receives one COLUMN: 4 consecutive k of one channel -- the
+// K-major MFMA operand out of a pixel-major image).
+//   * LDS images per panel of KP = 64 output pixels of one output row:  GS[k][128 co] (row pitch 256 B) and, per kernel row dy,
+//     XS[dy][input pixel][64 ci] (pitch 128 B) holding the (KP-1) sW + 3 input pixels under the panel ONCE -- the three kW taps read
+//     the same rows at per-lane row offsets (the transpose read takes any 8-byte-aligned chunk address), where wgrad_kernel kept one
+//     transposed copy per tap.  44 KB per panel (sW = 1): THREE panels in flight; 69 KB (sW = 2): two.
+//   * 16-byte pieces of a row are stored XOR-swizzled (by row bits, chosen when the wave-load's lanes pick their source addresses:
+//     the LDS side of a wave-load is lane-linear) so that the 32 lanes of a transpose-read half cover all 64 banks (sW = 1).
+//   * padding = the source address of a lane: replicate clamps it, zero padding / pixels past the row end / channels past the stored
+//     ones read a 512-byte zero page at the end of the workspace (cleared by the launcher).
+//   * every wave issues the same number of wave-loads per panel (the tail repeats a load), so "panel i has landed" is an exact
+//     s_waitcnt vmcnt(NLW) -- nothing else of this loop touches vector memory -- and ONE barrier per panel orders landing and reuse.
+// ---------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+template <typename T, int SW>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, const void* __restrict__ zero_page) {
+  using v8 = typename Tr<T>::v8;
+  constexpr int KP = 64, CO = 128, CI = 64, NSP = 9;
+  constexpr int XR = (KP - 1) * SW + 3;               // input pixels under a panel, per kernel row
+  constexpr int XRP = (XR + 7) / 8 * 8;               // ... in whole wave-loads of 8 rows x 128 bytes
+  constexpr int XS_B = 3 * XRP * 128, GS_B = KP * 256, BUF_B = XS_B + GS_B;
+  constexpr int NBUF = 3 * BUF_B <= 160 * 1024 ? 3 : 2;
+  constexpr int NLX = 3 * XRP / 8, NLG = KP / 4, NL = NLX + NLG, NLW = (NL + 7) / 8;
+  static_assert(NBUF * BUF_B <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF_B];
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  typedef __attribute__((address_space(3))) s16x4* lrd_t;
+
+  const int tid = threadIdx.x, lane_ = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lane = lane_;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int member = idx % p.n_members, slab = (idx / p.n_members) * 8 + xcd;
+  if (slab >= p.nslab) return;
+  const int coci = member % p.n_coci, dt = member / p.n_coci;
+  const int co_blk = coci / p.n_ci_blk, ci_blk = coci % p.n_ci_blk;
+  const int co0 = co_blk * CO, ci0 = ci_blk * CI;
+  const int npanel_row = (p.Wo + KP - 1) / KP;
+  const long long ptotal = (long long)p.rows_total * npanel_row;
+  const long long pbeg = ptotal * slab / p.nslab, npanels = ptotal * (slab + 1) / p.nslab - pbeg;
+  const T* __restrict__ ap = reinterpret_cast<const T*>(p.a);
+  const T* __restrict__ gp = reinterpret_cast<const T*>(p.g);
+  const char* const zp = reinterpret_cast<const char*>(zero_page);
+
+  f32x16 acc[NSP];
+#pragma unroll
+  for (int t = 0; t < NSP; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+
+  // ---- my wave-loads of a panel: load k of this wave is wave-load ii = wave + 8 k, or -- past the end -- a repetition of the wave's
+  //      previous one (same bytes to the same place), so that every wave issues exactly NLW per panel.  Which (row, piece) of which
+  //      image a lane fetches is panel independent (lrow, lcoff: kept in registers); the panel contributes scalars -- the base of the
+  //      three input rows and of the gradient row -- and the lane's source address is branch-free arithmetic: the first build
+  //      re-derived everything per load behind data-dependent branches, ~170 instructions per wave-load beside a 36-MFMA panel.
+  int lrow[NLW], lcoff[NLW];   // my row inside the image; my byte offset inside the source pixel, or -1: beyond the stored channels
+#pragma unroll
+  for (int k = 0; k < NLW; ++k) {
+    int ii = wave + 8 * k;
+    if (ii >= NL) ii -= 8;
+    if (ii < NLX) {
+      const int rb = ii % (XRP / 8);
+      const int r = rb * 8 + (lane >> 3), q = (lane & 7) ^ (((r >> 1) & 1) << 2);
+      const int c = ci0 + q * 8;
+      lrow[k] = r;
+      lcoff[k] = (c < (int)p.a_ps && r < XR) ? c * (int)sizeof(T) : -1;
+    } else {
+      const int gi = ii - NLX;
+      const int r = gi * 4 + (lane >> 4), q = (lane & 15) ^ ((r & 3) << 2);
+      const int c = co0 + q * 8;
+      lrow[k] = r;
+      lcoff[k] = c < (int)p.g_ps ? c * (int)sizeof(T) : -1;
+    }
+  }
+  const char* const zlane = zp + (lane & 31) * 16;
+  const long long apitch = p.a_ps * (long long)sizeof(T), gpitch = p.g_ps * (long long)sizeof(T);
+  // (panels are requested in order: the (batch, frame, row, panel-in-row) position advances by counters -- the divisions of the
+  //  first build were a hundred instructions per panel)
+  int q_xp = (int)(pbeg % npanel_row), q_yo, q_to, q_b;
+  {
+    const int row0 = (int)(pbeg / npanel_row);
+    q_yo = row0 % p.Ho;
+    q_to = (row0 / p.Ho) % p.To;
+    q_b = row0 / (p.Ho * p.To);
+  }
+  auto issue = [&](unsigned buf_off) __attribute__((always_inline)) {
+    const int x0 = q_xp * KP, yo = q_yo, to = q_to, b = q_b;
+    if (++q_xp == npanel_row) {
+      q_xp = 0;
+      if (++q_yo == p.Ho) {
+        q_yo = 0;
+        if (++q_to == p.To) {
+          q_to = 0;
+          ++q_b;
+        }
+      }
+    }
+    // (wave-uniform) the three input rows under this output row, or none (zero padding in time / height)
+    bool zt = false;
+    const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zt);
+    const char* xrow[3];
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      bool z = zt;
+      const int ys = map_coord(yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, z);
+      xrow[dy] = z ? nullptr : reinterpret_cast<const char*>(ap) + ((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
+    }
+    const char* const grow = reinterpret_cast<const char*>(gp) + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * gpitch;
+    const int xbase = x0 * SW - p.pw;
+#pragma unroll
+    for (int k = 0; k < NLW; ++k) {
+      int ii = wave + 8 * k;
+      if (ii >= NL) ii -= 8;
+      const char* src;
+      unsigned dsto;
+      if (ii < NLX) {  // (wave-uniform branch)
+        const int dy = ii / (XRP / 8), rb = ii % (XRP / 8);
+        const int xi = xbase + lrow[k];
+        const int xc = xi < 0 ? 0 : (xi >= p.Wi ? p.Wi - 1 : xi);
+        const bool ok = lcoff[k] >= 0 && xrow[dy] != nullptr && (p.mode_hw != 0 || xi == xc);
+        src = ok ? xrow[dy] + xc * apitch + lcoff[k] : zlane;
+        dsto = buf_off + dy * (XRP * 128) + rb * 1024;
+      } else {
+        const int kx = x0 + lrow[k];
+        const bool ok = lcoff[k] >= 0 && kx < p.Wo;
+        src = ok ? grow + kx * gpitch + lcoff[k] : zlane;
+        dsto = buf_off + XS_B + (ii - NLX) * 1024;
+      }
+      // The wave-load is issued BY HAND: with a global_load_lds it knows of still pending, hipcc puts s_waitcnt vmcnt(0) in front of
+      // the next LDS read that may alias it -- i.e. in front of this panel's first fragment read, which would wait for the panels just
+      // requested.  Landing and reuse are ordered by the explicit vmcnt + barrier of the panel loop instead.
+      const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(lptr_t)smem + dsto));
+      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(la) : "memory", "m0");
+    }
+  };
+
+  // ---- fragment addresses.  A transpose read: the 16 lanes of a group give the 8-byte chunks of a [4 rows][16 columns] block in
+  //      row-major chunk order (lane i: row i / 4, columns 4 (i % 4) .. +3) and lane i receives column i of the four rows.  Group g of
+  //      an operand: 16-channel half g & 1 of the wave's 32-channel fragment, k half g >> 1 (the MFMA's lanes 32-63 carry k 8..15).
+  const int cof = wave & 3, cif = wave >> 2;
+  const int li = lane & 15, lg = lane >> 4;
+  const int rsub = li >> 2;                          // row of my chunk inside the 4-row block
+  const int khalf8 = (lg >> 1) * 8;
+  // gy^T: row (k16 step * 16 + khalf8 + 4 ksub + rsub): row & 3 = rsub, so the swizzle is a lane constant
+  const int ga_c8 = (cof * 32 + (lg & 1) * 16) / 4 + (li & 3);      // 8-byte chunk inside the 256-byte row
+  const unsigned ga = (unsigned)(XS_B + (khalf8 + rsub) * 256 + (((ga_c8 >> 1) ^ (rsub << 2)) * 16) + (ga_c8 & 1) * 8);
+  // a: row (k sW + dx) of kernel row dy; per kW tap the row's swizzle bit differs per lane
+  const int xb_c8 = (cif * 32 + (lg & 1) * 16) / 4 + (li & 3);
+  unsigned xb[3];
+#pragma unroll
+  for (int dx = 0; dx < 3; ++dx) {
+    const int t = (khalf8 + rsub) * SW + dx;         // (the rest of the row index is a multiple of 4: bit 1 of the row is bit 1 of t)
+    xb[dx] = (unsigned)(t * 128 + (((xb_c8 >> 1) ^ (((t >> 1) & 1) << 2)) * 16) + (xb_c8 & 1) * 8);
+  }
+  auto tr8 = [&](unsigned off, int imm0, int imm1) __attribute__((always_inline)) -> v8 {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lrd_t)(smem + off + imm0));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lrd_t)(smem + off + imm1));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(v8, v);
+  };
+
+  // ---- pipeline: NBUF - 1 panels in flight ahead of the one being multiplied.  (The buffer offsets are rotated as scalars and the
+  //      panel loop is not unrolled: with `pi % 3` hipcc unrolled it three times and spilled 51 registers.)
+#pragma unroll
+  for (int j = 0; j < NBUF - 1; ++j)
+    if (j < npanels) issue((unsigned)(j * BUF_B));
+  unsigned cur_off = 0, fill_off = (unsigned)((NBUF - 1) * BUF_B);
+#pragma unroll 1
+  for (long long pi = 0; pi < npanels; ++pi) {
+    // panel pi has landed once at most the loads of the panels issued after it are outstanding
+    if (NBUF == 3 && pi + 1 < npanels) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave; and panel pi - 1's buffer is free
+    if (pi + NBUF - 1 < npanels) issue(fill_off);
+    const unsigned lb = cur_off;
+    cur_off = cur_off + BUF_B == (unsigned)(NBUF * BUF_B) ? 0u : cur_off + BUF_B;
+    fill_off = fill_off + BUF_B == (unsigned)(NBUF * BUF_B) ? 0u : fill_off + BUF_B;
+    asm volatile("" : "+s"(cur_off), "+s"(fill_off));
+    // one operand pair ahead: the reads of (step, tap) + 1 are requested before the MFMA of (step, tap); the fence keeps hipcc from
+    // hoisting more of them (left alone it requested a whole step's nine B fragments first and spilled)
+    auto b_of = [&](int s, int t) __attribute__((always_inline)) -> v8 {
+      const int dy = t / 3, dx = t % 3;
+      return tr8(lb + xb[dx], dy * (XRP * 128) + (s * 16) * SW * 128, dy * (XRP * 128) + (s * 16 + 4) * SW * 128);
+    };
+    v8 a = tr8(lb + ga, 0, 4 * 256);
+    v8 bq = b_of(0, 0);
+#pragma unroll
+    for (int s = 0; s < KP / 16; ++s) {
+      v8 an = a;
+#pragma unroll
+      for (int t = 0; t < NSP; ++t) {
+        v8 bn = bq;
+        if (t + 1 < NSP) bn = b_of(s, t + 1);
+        else if (s + 1 < KP / 16) {
+          bn = b_of(s + 1, 0);
+          an = tr8(lb + ga, ((s + 1) * 16) * 256, ((s + 1) * 16 + 4) * 256);
+        }
+        acc[t] = Tr<T>::mfma(a, bq, acc[t]);
+        bq = bn;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      a = an;
+    }
+  }
+  const int ntaps = p.kT * NSP;
+#pragma unroll
+  for (int t = 0; t < NSP; ++t) {
+    float* o = p.part + (((long long)slab * ntaps + dt * NSP + t) * p.Coutp + co0 + cof * 32) * p.Cinp + ci0 + cif * 32 + (lane & 31);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * p.Cinp] = acc[t][i];
+  }
+}
+
 // dW[co][ci][tap] = sum over slabs (index order) of part[slab][tap][co][ci]
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int ntaps, int Coutp, int Cinp,
                                                            int Cout, int Cin, float* __restrict__ dw) {
@@ -316,6 +538,11 @@ static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_c
   nslab = (int)s;
 }
 
+static long long wgrad_partial_bytes(const cvvae_conv_desc* d, int nslab, int n_co, int n_ci) {
+  const long long b = (long long)nslab * d->kT * d->kH * d->kW * n_co * 128 * n_ci * 64 * (long long)sizeof(float);
+  return (b + 255) / 256 * 256;
+}
+
 template <typename T, int KHW, bool XP, int SW>
 static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
   int nslab, n_co, n_ci;
@@ -331,8 +558,23 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
   p.n_coci = n_co * n_ci;
   p.n_members = n_co * n_ci * d->kT;
   const int nslab8 = (nslab + 7) / 8 * 8;  // (blocks of the padding slabs exit at once)
-  hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p);
-  int rc = (int)hipGetLastError();
+  int rc = 0;
+  // CVVAE_WGRAD_DMA=0: the register-staged kernel for every layer (A/B aid; read once)
+  static const bool dma_off = getenv("CVVAE_WGRAD_DMA") && atoi(getenv("CVVAE_WGRAD_DMA")) == 0;
+  if constexpr (KHW == 3 && !XP) {
+    if (!dma_off) {
+      // the zero page behind the partial tiles (cvvae_conv_wgrad_workspace_bytes reserves it)
+      char* zero = reinterpret_cast<char*>(ws) + wgrad_partial_bytes(d, nslab, n_co, n_ci);
+      rc = (int)hipMemsetAsync(zero, 0, 512, s);
+      if (rc) return rc;
+      hipLaunchKernelGGL((wgrad_dma_kernel<T, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (const void*)zero);
+    } else {
+      hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p);
+    }
+  } else {
+    hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p);
+  }
+  rc = (int)hipGetLastError();
   if (rc) return rc;
   const int ntaps = d->kT * d->kH * d->kW;
   long long blocks = ((long long)ntaps * p.Coutp * (p.Cinp / 4) + 255) / 256;
@@ -679,7 +921,7 @@ int64_t cvvae_conv_wgrad_workspace_bytes(const cvvae_conv_desc* d) {
   if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kT <= 0) return CVVAE_EINVAL;
   int nslab, n_co, n_ci;
   wgrad_plan(d, nslab, n_co, n_ci);
-  return (int64_t)nslab * d->kT * d->kH * d->kW * n_co * 128 * n_ci * 64 * (int64_t)sizeof(float);
+  return (int64_t)wgrad_partial_bytes(d, nslab, n_co, n_ci) + 512;  // + the zero page of wgrad_dma_kernel
 }
 
 int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, void* workspace,
