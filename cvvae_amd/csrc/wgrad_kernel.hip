@@ -345,8 +345,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
       lcoff[k] = c < (int)p.g_ps ? c * (int)sizeof(T) : -1;
     }
   }
-  const char* const zlane = zp + (lane & 31) * 16;
-  const long long apitch = p.a_ps * (long long)sizeof(T), gpitch = p.g_ps * (long long)sizeof(T);
+  const unsigned long long zlane = (unsigned long long)(size_t)(zp + (lane & 31) * 16);
+  const unsigned apitch = (unsigned)(p.a_ps * sizeof(T)), gpitch = (unsigned)(p.g_ps * sizeof(T));
   // (panels are requested in order: the (batch, frame, row, panel-in-row) position advances by counters -- the divisions of the
   //  first build were a hundred instructions per panel)
   int q_xp = (int)(pbeg % npanel_row), q_yo, q_to, q_b;
@@ -356,6 +356,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
     q_to = (row0 / p.Ho) % p.To;
     q_b = row0 / (p.Ho * p.To);
   }
+  const int wi1 = p.Wi - 1;
+  const bool zero_hw = p.mode_hw == 0;
   auto issue = [&](unsigned buf_off) __attribute__((always_inline)) {
     const int x0 = q_xp * KP, yo = q_yo, to = q_to, b = q_b;
     if (++q_xp == npanel_row) {
@@ -368,35 +370,40 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
         }
       }
     }
-    // (wave-uniform) the three input rows under this output row, or none (zero padding in time / height)
+    // (wave-uniform) the three input rows under this output row, or none (zero padding in time / height): address 0
     bool zt = false;
     const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zt);
-    const char* xrow[3];
+    unsigned long long xrow[3];
 #pragma unroll
     for (int dy = 0; dy < 3; ++dy) {
       bool z = zt;
       const int ys = map_coord(yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, z);
-      xrow[dy] = z ? nullptr : reinterpret_cast<const char*>(ap) + ((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
+      xrow[dy] = z ? 0ull : (unsigned long long)(size_t)ap + (unsigned long long)((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
     }
-    const char* const grow = reinterpret_cast<const char*>(gp) + ((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * gpitch;
+    const unsigned long long grow = (unsigned long long)(size_t)gp + (unsigned long long)((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * gpitch;
     const int xbase = x0 * SW - p.pw;
 #pragma unroll
     for (int k = 0; k < NLW; ++k) {
       int ii = wave + 8 * k;
       if (ii >= NL) ii -= 8;
-      const char* src;
+      unsigned long long src;
       unsigned dsto;
+      // branch-free per lane: clamp, one 32 x 32 -> 64 multiply-add, a mask select between the source and the zero page
       if (ii < NLX) {  // (wave-uniform branch)
         const int dy = ii / (XRP / 8), rb = ii % (XRP / 8);
         const int xi = xbase + lrow[k];
-        const int xc = xi < 0 ? 0 : (xi >= p.Wi ? p.Wi - 1 : xi);
-        const bool ok = lcoff[k] >= 0 && xrow[dy] != nullptr && (p.mode_hw != 0 || xi == xc);
-        src = ok ? xrow[dy] + xc * apitch + lcoff[k] : zlane;
+        const int xc = min(max(xi, 0), wi1);
+        const bool ok = (lcoff[k] >= 0) & (xrow[dy] != 0ull) & (!zero_hw | (xi == xc));
+        const unsigned long long m = ok ? ~0ull : 0ull;
+        const unsigned long long a = xrow[dy] + (unsigned long long)(unsigned)xc * apitch + (unsigned)lcoff[k];
+        src = (a & m) | (zlane & ~m);
         dsto = buf_off + dy * (XRP * 128) + rb * 1024;
       } else {
         const int kx = x0 + lrow[k];
-        const bool ok = lcoff[k] >= 0 && kx < p.Wo;
-        src = ok ? grow + kx * gpitch + lcoff[k] : zlane;
+        const bool ok = (lcoff[k] >= 0) & (kx < p.Wo);
+        const unsigned long long m = ok ? ~0ull : 0ull;
+        const unsigned long long a = grow + (unsigned long long)(unsigned)kx * gpitch + (unsigned)lcoff[k];
+        src = (a & m) | (zlane & ~m);
         dsto = buf_off + XS_B + (ii - NLX) * 1024;
       }
       // The wave-load is issued BY HAND: with a global_load_lds it knows of still pending, hipcc puts s_waitcnt vmcnt(0) in front of

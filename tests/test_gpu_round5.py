@@ -340,7 +340,7 @@ def test_whole_model_is_bit_identical_with_and_without_dma_staging():
             a, b, names, same = _both_forms(run)
             assert any(n.endswith("_dma") for n in names)
             if pre == "1":
-                assert sum(n.endswith("_dma") for n in names) >= 0.8 * len(names), names
+                assert sum(n.endswith("_dma") for n in names) >= 0.7 * len(names), names
             if same:
                 assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), pre
             else:  # (a tile the register-staged list lacks without prologue -- the 128-channel per-frame convs behind the pass, the
