@@ -284,6 +284,9 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
 //     s_waitcnt vmcnt(NLW) -- nothing else of this loop touches vector memory -- and ONE barrier per panel orders landing and reuse.
 // ---------------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+#ifndef CVVAE_WGRAD_DEPTH
+#define CVVAE_WGRAD_DEPTH 4  // operand pairs requested ahead of their MFMA (tuning aid)
+#endif
 
 template <typename T, int SW>
 __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, const void* __restrict__ zero_page) {
@@ -296,7 +299,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
   constexpr int NLX = 3 * XRP / 8, NLG = KP / 4, NL = NLX + NLG, NLW = (NL + 7) / 8;
   static_assert(NBUF * BUF_B <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF_B];
-  typedef const __attribute__((address_space(1))) void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   typedef __attribute__((address_space(3))) s16x4* lrd_t;
 
@@ -358,10 +360,29 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
   }
   const int wi1 = p.Wi - 1;
   const bool zero_hw = p.mode_hw == 0;
+  // (wave-uniform) bases of the three input rows under the current output row -- 0: none (zero padding in time / height) -- and of the
+  // gradient row: recomputed when the row changes, i.e. every npanel_row panels
+  unsigned long long xrow[3], grow;
+  auto row_bases = [&]() __attribute__((always_inline)) {
+    bool zt = false;
+    const int ts = map_coord(q_to * p.sT + dt - p.pt, p.Ti, p.mode_t, zt);
+#pragma unroll
+    for (int dy = 0; dy < 3; ++dy) {
+      bool z = zt;
+      const int ys = map_coord(q_yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, z);
+      xrow[dy] = z ? 0ull : (unsigned long long)(size_t)ap + (unsigned long long)((((long long)q_b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
+    }
+    grow = (unsigned long long)(size_t)gp + (unsigned long long)((((long long)q_b * p.To + q_to) * p.Ho + q_yo) * p.Wo) * gpitch;
+  };
+  row_bases();
+  bool q_new_row = false;
   auto issue = [&](unsigned buf_off) __attribute__((always_inline)) {
-    const int x0 = q_xp * KP, yo = q_yo, to = q_to, b = q_b;
+    if (q_new_row) row_bases();
+    const int x0 = q_xp * KP;
+    q_new_row = false;
     if (++q_xp == npanel_row) {
       q_xp = 0;
+      q_new_row = true;
       if (++q_yo == p.Ho) {
         q_yo = 0;
         if (++q_to == p.To) {
@@ -370,17 +391,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
         }
       }
     }
-    // (wave-uniform) the three input rows under this output row, or none (zero padding in time / height): address 0
-    bool zt = false;
-    const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, zt);
-    unsigned long long xrow[3];
-#pragma unroll
-    for (int dy = 0; dy < 3; ++dy) {
-      bool z = zt;
-      const int ys = map_coord(yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, z);
-      xrow[dy] = z ? 0ull : (unsigned long long)(size_t)ap + (unsigned long long)((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
-    }
-    const unsigned long long grow = (unsigned long long)(size_t)gp + (unsigned long long)((((long long)b * p.To + to) * p.Ho + yo) * p.Wo) * gpitch;
     const int xbase = x0 * SW - p.pw;
 #pragma unroll
     for (int k = 0; k < NLW; ++k) {
@@ -410,7 +420,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
       // the next LDS read that may alias it -- i.e. in front of this panel's first fragment read, which would wait for the panels just
       // requested.  Landing and reuse are ordered by the explicit vmcnt + barrier of the panel loop instead.
       const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(lptr_t)smem + dsto));
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"  // (m0 is a reserved register: nothing else of this kernel uses it)
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(la) : "memory", "m0");
+#pragma clang diagnostic pop
     }
   };
 
@@ -452,36 +465,43 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
     if (NBUF == 3 && pi + 1 < npanels) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave; and panel pi - 1's buffer is free
-    if (pi + NBUF - 1 < npanels) issue(fill_off);
-    const unsigned lb = cur_off;
+    // The barrier puts every wave at the same point, and a panel's requests are ~300 scalar / vector instructions: issued by all
+    // waves at once they leave the matrix pipe idle meanwhile (the first build: 0.39 busy, waves 0.5 of their cycles waiting).  The two
+    // waves of a SIMD therefore run opposite orders -- waves 0-3 request, then multiply; waves 4-7 multiply, then request -- so that
+    // one's requests issue under the other's MFMAs.  (Both orders are legal: the buffer being filled was last read by panel pi - 1,
+    // which every wave finished before this barrier; the late requests still have a whole panel to land.)
+    const bool request_first = NBUF == 2 || wave < 4;
+    const bool more = pi + NBUF - 1 < npanels;
+    if (more && request_first) issue(fill_off);
+    const unsigned lb = cur_off, fill_off_now = fill_off;
     cur_off = cur_off + BUF_B == (unsigned)(NBUF * BUF_B) ? 0u : cur_off + BUF_B;
     fill_off = fill_off + BUF_B == (unsigned)(NBUF * BUF_B) ? 0u : fill_off + BUF_B;
     asm volatile("" : "+s"(cur_off), "+s"(fill_off));
-    // one operand pair ahead: the reads of (step, tap) + 1 are requested before the MFMA of (step, tap); the fence keeps hipcc from
-    // hoisting more of them (left alone it requested a whole step's nine B fragments first and spilled)
-    auto b_of = [&](int s, int t) __attribute__((always_inline)) -> v8 {
-      const int dy = t / 3, dx = t % 3;
+    // DEPTH operand pairs ahead: the reads of MFMA m + DEPTH are requested before MFMA m issues (the counters of the one-ahead form:
+    // waves 0.51 of their cycles in s_waitcnt with the LDS pipe nowhere near busy -- a transpose read takes longer to come back than
+    // one or two MFMAs last); the fence keeps hipcc from hoisting more (left alone it requested a whole step's fragments and spilled)
+    constexpr int DEPTH = CVVAE_WGRAD_DEPTH, NM = (KP / 16) * NSP;
+    auto b_of = [&](int m) __attribute__((always_inline)) -> v8 {
+      const int s = m / NSP, t = m % NSP, dy = t / 3, dx = t % 3;
       return tr8(lb + xb[dx], dy * (XRP * 128) + (s * 16) * SW * 128, dy * (XRP * 128) + (s * 16 + 4) * SW * 128);
     };
-    v8 a = tr8(lb + ga, 0, 4 * 256);
-    v8 bq = b_of(0, 0);
+    auto a_of = [&](int s) __attribute__((always_inline)) -> v8 { return tr8(lb + ga, (s * 16) * 256, (s * 16 + 4) * 256); };
+    v8 aq[2], bq[DEPTH];
+    aq[0] = a_of(0);
 #pragma unroll
-    for (int s = 0; s < KP / 16; ++s) {
-      v8 an = a;
+    for (int m = 0; m < DEPTH; ++m) bq[m] = b_of(m);
 #pragma unroll
-      for (int t = 0; t < NSP; ++t) {
-        v8 bn = bq;
-        if (t + 1 < NSP) bn = b_of(s, t + 1);
-        else if (s + 1 < KP / 16) {
-          bn = b_of(s + 1, 0);
-          an = tr8(lb + ga, ((s + 1) * 16) * 256, ((s + 1) * 16 + 4) * 256);
-        }
-        acc[t] = Tr<T>::mfma(a, bq, acc[t]);
-        bq = bn;
-        __builtin_amdgcn_sched_barrier(0);
+    for (int m = 0; m < NM; ++m) {
+      const int s = m / NSP, t = m % NSP;
+      const v8 bcur = bq[m % DEPTH];
+      if (m + DEPTH < NM) {
+        bq[m % DEPTH] = b_of(m + DEPTH);
+        if ((m + DEPTH) % NSP == 0) aq[((m + DEPTH) / NSP) & 1] = a_of((m + DEPTH) / NSP);
       }
-      a = an;
+      acc[t] = Tr<T>::mfma(aq[s & 1], bcur, acc[t]);
+      __builtin_amdgcn_sched_barrier(0);
     }
+    if (more && !request_first) issue(fill_off_now);
   }
   const int ntaps = p.kT * NSP;
 #pragma unroll
