@@ -67,11 +67,9 @@ class WeightCache:
     def guard(self) -> bool:
         """compare a checksum (per-tensor L1 and L2 norms, one fused launch each, ONE host sync) of the module's parameters with the
         one taken at the previous call; on a difference drop every cached form.  Returns True when the cache was dropped."""
-        ps = [p.detach() for p in self.m.parameters()]
-        if not ps:
+        cur = self._checksum()
+        if cur is None:
             return False
-        with torch.no_grad():
-            cur = torch.stack(list(torch._foreach_norm(ps, 1)) + list(torch._foreach_norm(ps, 2))).double()
         last = getattr(self, "_sum", None)
         # (no previous checksum: forms packed before the first guarded pass cannot be vouched for)
         changed = (bool(self._c) or bool(self._cast)) if last is None else (
@@ -80,6 +78,13 @@ class WeightCache:
             self.invalidate()
         self._sum = cur
         return changed
+
+    def _checksum(self) -> Optional[torch.Tensor]:
+        ps = [p.detach() for p in self.m.parameters()]
+        if not ps:
+            return None
+        with torch.no_grad():
+            return torch.stack(list(torch._foreach_norm(ps, 1)) + list(torch._foreach_norm(ps, 2))).double()
 
     def computing_in(self, dtype: Optional[torch.dtype]):
         """context manager: `compute_dtype` = dtype inside, the previous value afterwards (the dtype is per PASS, not per cache: a
@@ -307,6 +312,7 @@ class WeightCache:
         if self.compute_dtype is not None:
             with self.computing_in(None):
                 return self.import_packed(blob)
+        fresh = not self._c and not self._cast
         for tag, e in blob.items():
             try:
                 ps = [self.p(nm) for nm in e["names"]]
@@ -319,6 +325,9 @@ class WeightCache:
             f["w"], f["bias"], f["k"] = f["w"].to(dev), f["bias"].to(dev), tuple(f["k"])
             self._c[tag] = (self._key(*ps), ops.PackedConv(**f), tuple(e["names"]))
             n += 1
+        if fresh and n and getattr(self, "_sum", None) is None:
+            # every entry was just checked against the parameters' fingerprints: the first guarded pass may keep them
+            self._sum = self._checksum()
         return n
 
     def bias_sum(self, pre_a: str, pre_b: str) -> torch.Tensor:
