@@ -20,12 +20,11 @@ def short(n):
         if f[-1] in ("true", "false"):  # ABI 6-7: one trailing bool XP
             sfx = "_xp" if f[-1] == "true" else ""
             f = f[:-1]
-        else:  # ABI 8+: trailing ints after the 16 leading arguments (T + 15): XP (0 / 1 split precision / 2, 3 fast fp32), NB
-            # (N-blocks per wave) and -- round 5 -- LD (1: DMA-staged)
-            extra = [int(v) for v in f[16:]] + [0, 1, 0]
-            xp, nb, ld = (extra[0], extra[1], extra[2]) if len(f) >= 19 else (extra[0], extra[1], 0)
+        else:  # ABI 11: the name ends ...,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,XP,NB,LD -- XP 0 / 1 split precision / 2, 3 fast fp32, NB
+            # N-blocks per wave, LD 1 = DMA-staged.  Counted from the END: the number of (garbled) leading fields varies.
+            xp, nb, ld = (int(v) for v in f[-3:])
             sfx = {0: "", 1: "_xp", 2: "_xq", 3: "_xq6"}[xp] + ("_nb2" if nb == 2 else "") + ("_dma" if ld == 1 else "")
-            f = f[:16]
+            f = f[:-3]
         t = f[-9:]
         return f"conv_*_t{t[0]}x{t[1]}x{t[2]}_w{t[3]}x{t[4]}x{t[5]}_c{16 * int(t[6])}_pro{t[7]}_ups{t[8]}{sfx}"
     n = re.sub(r"\(.*", "", n)

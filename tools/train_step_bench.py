@@ -28,6 +28,7 @@ def main():
                     help="with --dtype f32: run the step under torch.autocast (fp32 master weights, 16-bit launches) and nudge the "
                          "masters between steps as an optimizer would (so every step re-casts and re-packs the weights)")
     ap.add_argument("--no-golden", action="store_true", help="skip the gradient comparison with the reference-generated fixture")
+    ap.add_argument("--wgrad-only", action="store_true", help="time the weight-gradient layers (10 launches each) and stop")
     ap.add_argument("--cprofile", default=None, help="write a cProfile listing of one more step (host side) to this file")
     args = ap.parse_args()
     import cvvae_amd
@@ -51,15 +52,19 @@ def main():
         ops.conv_wgrad(a, g, k, **kw)
         e0, e1 = ev(), ev()
         e0.record()
-        for _ in range(3):
+        reps = 10 if args.wgrad_only else 3
+        for _ in range(reps):
             ops.conv_wgrad(a, g, k, **kw)
         e1.record()
         torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 3
+        ms = e0.elapsed_time(e1) / reps
         fl = 2.0 * To * Ho * Wo * co * ci * k[0] * k[1] * k[2]
         out["wgrad"].append({"layer": name, "in": [T, H, W], "ms": round(ms, 3), "tflops": round(fl / ms / 1e9, 1),
                              "frac_of_mfma_peak": round(fl / ms / 1e9 / 2500.0, 4)})
         del a, g
+    if args.wgrad_only:
+        print(json.dumps(out))
+        return
     # ---- one training step of both networks
     torch.manual_seed(0)
     m = cvvae_amd.CVVAESD3Model()  # (the classes initialise their parameters with PyTorch's default-init statistics)
