@@ -252,14 +252,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
     }
     __syncthreads();
   }
-  // partial tile: part[slab][tap][co][ci]; accumulator register i of a lane = output channel 8*(i/4) + 4*(lane/32) + i%4 of the
-  // fragment, input channel lane % 32
+  // partial tile: part[slab][tap][co block][ci block][128 co][64 ci] (see wgrad_reduce_kernel); accumulator register i of a lane =
+  // output channel 8*(i/4) + 4*(lane/32) + i%4 of the fragment, input channel lane % 32
   const int ntaps = p.kT * NSP;
 #pragma unroll
   for (int t = 0; t < NSP; ++t) {
-    float* o = p.part + (((long long)slab * ntaps + dt * NSP + t) * p.Coutp + co0 + cof * 32) * p.Cinp + ci0 + cif * 32 + (lane & 31);
+    float* o = p.part + ((((long long)slab * ntaps + dt * NSP + t) * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * (CO * CI) +
+               (cof * 32) * CI + cif * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * p.Cinp] = acc[t][i];
+    for (int i = 0; i < 16; ++i) o[(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * CI] = acc[t][i];
   }
 }
 
@@ -279,24 +280,31 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
 //   * 16-byte pieces of a row are stored XOR-swizzled (by row bits, chosen when the wave-load's lanes pick their source addresses:
 //     the LDS side of a wave-load is lane-linear) so that the 32 lanes of a transpose-read half cover all 64 banks (sW = 1).
 //   * padding = the source address of a lane: replicate clamps it, zero padding / pixels past the row end / channels past the stored
-//     ones read a 512-byte zero page at the end of the workspace (cleared by the launcher).
+//     ones read a 512-byte zero page at the end of the workspace (cleared by every workgroup before its first wave-load).
 //   * every wave issues the same number of wave-loads per panel (the tail repeats a load), so "panel i has landed" is an exact
 //     s_waitcnt vmcnt(NLW) -- nothing else of this loop touches vector memory -- and ONE barrier per panel orders landing and reuse.
 // ---------------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef CVVAE_WGRAD_DEPTH
-#define CVVAE_WGRAD_DEPTH 4  // operand pairs requested ahead of their MFMA (tuning aid)
+#define CVVAE_WGRAD_DEPTH 3  // input fragments requested ahead of their first MFMA (tuning aid)
+#endif
+#ifndef CVVAE_WGRAD_STAGGER
+#define CVVAE_WGRAD_STAGGER 1  // the two waves of a SIMD request / multiply in opposite orders (tuning aid)
+#endif
+#ifndef CVVAE_WGRAD_ABLATE
+// timing aid, scratch builds only (the results are WRONG when nonzero): leave out  1 the transpose reads,  2 the wave-load instruction
+// (its address arithmetic stays),  4 the whole request code,  8 the MFMAs -- what the loop costs without each of its parts
+#define CVVAE_WGRAD_ABLATE 0
 #endif
 
-template <typename T, int SW>
-__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, const void* __restrict__ zero_page) {
+template <typename T, int SW, bool FAST>
+__global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, void* __restrict__ zero_page) {
   using v8 = typename Tr<T>::v8;
   constexpr int KP = 64, CO = 128, CI = 64, NSP = 9;
   constexpr int XR = (KP - 1) * SW + 3;               // input pixels under a panel, per kernel row
   constexpr int XRP = (XR + 7) / 8 * 8;               // ... in whole wave-loads of 8 rows x 128 bytes
   constexpr int XS_B = 3 * XRP * 128, GS_B = KP * 256, BUF_B = XS_B + GS_B;
   constexpr int NBUF = 3 * BUF_B <= 160 * 1024 ? 3 : 2;
-  constexpr int NLX = 3 * XRP / 8, NLG = KP / 4, NL = NLX + NLG, NLW = (NL + 7) / 8;
   static_assert(NBUF * BUF_B <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(1024))) char smem[NBUF * BUF_B];
   typedef __attribute__((address_space(3))) void* lptr_t;
@@ -316,6 +324,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
   const T* __restrict__ ap = reinterpret_cast<const T*>(p.a);
   const T* __restrict__ gp = reinterpret_cast<const T*>(p.g);
   const char* const zp = reinterpret_cast<const char*>(zero_page);
+  // The zero page is cleared HERE, by every workgroup (they all store the same zeros), not by a memset launched in front of the
+  // kernel.  The stores are acknowledged by this XCD's L2 (vmcnt) before the barrier; the wave-loads that read the page come
+  // after it and go through the same L2.
+  if (tid < 128) __atomic_store_n(reinterpret_cast<unsigned*>(zero_page) + tid, 0u, __ATOMIC_RELAXED);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 
   f32x16 acc[NSP];
 #pragma unroll
@@ -323,32 +337,36 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
 
-  // ---- my wave-loads of a panel: load k of this wave is wave-load ii = wave + 8 k, or -- past the end -- a repetition of the wave's
-  //      previous one (same bytes to the same place), so that every wave issues exactly NLW per panel.  Which (row, piece) of which
-  //      image a lane fetches is panel independent (lrow, lcoff: kept in registers); the panel contributes scalars -- the base of the
-  //      three input rows and of the gradient row -- and the lane's source address is branch-free arithmetic: the first build
-  //      re-derived everything per load behind data-dependent branches, ~170 instructions per wave-load beside a 36-MFMA panel.
-  int lrow[NLW], lcoff[NLW];   // my row inside the image; my byte offset inside the source pixel, or -1: beyond the stored channels
-#pragma unroll
-  for (int k = 0; k < NLW; ++k) {
-    int ii = wave + 8 * k;
-    if (ii >= NL) ii -= 8;
-    if (ii < NLX) {
-      const int rb = ii % (XRP / 8);
-      const int r = rb * 8 + (lane >> 3), q = (lane & 7) ^ (((r >> 1) & 1) << 2);
-      const int c = ci0 + q * 8;
-      lrow[k] = r;
-      lcoff[k] = (c < (int)p.a_ps && r < XR) ? c * (int)sizeof(T) : -1;
-    } else {
-      const int gi = ii - NLX;
-      const int r = gi * 4 + (lane >> 4), q = (lane & 15) ^ ((r & 3) << 2);
-      const int c = co0 + q * 8;
-      lrow[k] = r;
-      lcoff[k] = c < (int)p.g_ps ? c * (int)sizeof(T) : -1;
-    }
-  }
+  // ---- my wave-loads of a panel.  An input image row dy is C = XRP / 8 wave-loads (8 pixels x 128 bytes each), the gradient image
+  //      KP / 4 = 16 (4 pixels x 256 bytes).  Wave w issues, in this order: for dy = 0, 1, 2 the input chunks w, w + 8, .. of row dy
+  //      (C = 8 JX + 1); the gradient chunks w and w + 8; and -- waves 0, 1, 2 only -- the last chunk C - 1 of row dy = w.  WHICH row
+  //      and chunk a load fetches is therefore known at compile time except for the one extra load (the first form dealt the loads
+  //      round-robin, ii = wave + 8 k: every load selected its row base, its LDS slot and its lane constants at run time -- ~35 scalar
+  //      and ~25 vector instructions per wave-load), and a lane's (pixel, 16-byte piece) inside a chunk is the same for all of them.
+  //      Waves 0-2 wait for one more load per panel than the others (NLW_LO + 1).
+  constexpr int C = XRP / 8, JX = C / 8, NLW_LO = 3 * JX + 2;
+  static_assert(C % 8 == 1 && KP / 4 == 16, "wave-load assignment");
+  const int xr8 = lane >> 3;                                             // my pixel inside an input chunk
+  const int xq = (lane & 7) ^ (((xr8 >> 1) & 1) << 2);                   // my 16-byte piece (swizzled by bit 1 of the row = of xr8)
+  const bool cx_ok = ci0 + xq * 8 < (int)p.a_ps;
+  const unsigned lcx = (unsigned)((ci0 + xq * 8) * (int)sizeof(T));
+  const int gr4 = wave * 4 + (lane >> 4);                                // my pixel inside the gradient image (first chunk)
+  const int gq = (lane & 15) ^ ((gr4 & 3) << 2);
+  const bool cg_ok = co0 + gq * 8 < (int)p.g_ps;
+  const unsigned lcg = (unsigned)((co0 + gq * 8) * (int)sizeof(T));
   const unsigned long long zlane = (unsigned long long)(size_t)(zp + (lane & 31) * 16);
   const unsigned apitch = (unsigned)(p.a_ps * sizeof(T)), gpitch = (unsigned)(p.g_ps * sizeof(T));
+  // FAST (chosen by the launcher: whole gradient panels, every channel of the tile stored, and the input tensor and the zero page
+  // within 4 GB of each other): a wave-load is SCALAR base + 32-bit lane offset.  The ablated builds of the first form
+  // (profiles/r5_ab_wgrad_parts.log) showed the requests costing their issue time in full ON TOP of the MFMA time (vector ALU work
+  // of the other wave of a SIMD is not hidden under MFMAs: the round-2 probe, profiles/r2_peak_probe.txt).  Here an input load is
+  // add / clamp / multiply-add (+ compare / select under zero padding) relative to `lo` = the lower of the two addresses, a
+  // gradient load is no vector instruction at all.
+  const unsigned long long lo64 = FAST ? ((size_t)ap < (size_t)zp ? (unsigned long long)(size_t)ap : (unsigned long long)(size_t)zp) : 0ull;
+  const unsigned zvoff = (unsigned)((unsigned long long)(size_t)zp - lo64) + (unsigned)(lane & 31) * 16u;
+  const unsigned gvoff = (unsigned)gr4 * gpitch + lcg;                   // (FAST) my offset inside the gradient panel
+  constexpr unsigned NONE = 0xffffffffu;
+  unsigned xrel[3];
   // (panels are requested in order: the (batch, frame, row, panel-in-row) position advances by counters -- the divisions of the
   //  first build were a hundred instructions per panel)
   int q_xp = (int)(pbeg % npanel_row), q_yo, q_to, q_b;
@@ -371,12 +389,46 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
       bool z = zt;
       const int ys = map_coord(q_yo * p.sH + dy - p.ph, p.Hi, p.mode_hw, z);
       xrow[dy] = z ? 0ull : (unsigned long long)(size_t)ap + (unsigned long long)((((long long)q_b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
+      if (FAST) xrel[dy] = z ? NONE : (unsigned)(xrow[dy] - lo64);
     }
     grow = (unsigned long long)(size_t)gp + (unsigned long long)((((long long)q_b * p.To + q_to) * p.Ho + q_yo) * p.Wo) * gpitch;
   };
   row_bases();
   bool q_new_row = false;
+  const unsigned sm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)smem) + (unsigned)wave * 1024u;
+  // The wave-load is issued BY HAND: with a global_load_lds it knows of still pending, hipcc puts s_waitcnt vmcnt(0) in front of
+  // the next LDS read that may alias it -- i.e. in front of this panel's first fragment read, which would wait for the panels just
+  // requested.  Landing and reuse are ordered by the explicit vmcnt + barrier of the panel loop instead.
+  // (m0 is a reserved register: nothing else of this kernel uses it)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+  auto dma = [&](unsigned long long src, unsigned voff, unsigned long long sbase, unsigned la) __attribute__((always_inline)) {
+    if (CVVAE_WGRAD_ABLATE & 2) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0" ::"v"(src), "s"(la), "v"(voff), "s"(sbase) : "memory", "m0");
+    else if (FAST) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
+    else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(la) : "memory", "m0");
+  };
+#pragma clang diagnostic pop
+  // one input chunk: pixels xs .. xs + 7 (xs wave-uniform) of the row whose base is rel (FAST) / rowbase, to LDS address la
+  auto xload = [&](unsigned rel, unsigned long long rowbase, int xs, unsigned la) __attribute__((always_inline)) {
+    const int xi = xs + xr8;
+    const int xc = min(max(xi, 0), wi1);
+    if (FAST) {
+      unsigned voff = zvoff;
+      if (rel != NONE) {                      // (wave-uniform)
+        voff = __umul24((unsigned)xc, apitch) + lcx + rel;
+        if (zero_hw) voff = xi == xc ? voff : zvoff;
+      }
+      dma(0ull, voff, lo64, la);
+    } else {
+      // branch-free per lane: clamp, one 32 x 32 -> 64 multiply-add, a mask select between the source and the zero page
+      const bool ok = cx_ok & (rowbase != 0ull) & (!zero_hw | (xi == xc));
+      const unsigned long long m = ok ? ~0ull : 0ull;
+      const unsigned long long a = rowbase + (unsigned long long)(unsigned)xc * apitch + lcx;
+      dma((a & m) | (zlane & ~m), 0u, 0ull, la);
+    }
+  };
   auto issue = [&](unsigned buf_off) __attribute__((always_inline)) {
+    if (CVVAE_WGRAD_ABLATE & 4) return;
     if (q_new_row) row_bases();
     const int x0 = q_xp * KP;
     q_new_row = false;
@@ -391,61 +443,69 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
         }
       }
     }
-    const int xbase = x0 * SW - p.pw;
+    const int xbase = x0 * SW - p.pw + wave * 8;     // first pixel of my first chunk
+    const unsigned lbase = sm0 + buf_off;            // LDS address of chunk `wave` of input row 0
 #pragma unroll
-    for (int k = 0; k < NLW; ++k) {
-      int ii = wave + 8 * k;
-      if (ii >= NL) ii -= 8;
-      unsigned long long src;
-      unsigned dsto;
-      // branch-free per lane: clamp, one 32 x 32 -> 64 multiply-add, a mask select between the source and the zero page
-      if (ii < NLX) {  // (wave-uniform branch)
-        const int dy = ii / (XRP / 8), rb = ii % (XRP / 8);
-        const int xi = xbase + lrow[k];
-        const int xc = min(max(xi, 0), wi1);
-        const bool ok = (lcoff[k] >= 0) & (xrow[dy] != 0ull) & (!zero_hw | (xi == xc));
+    for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+      for (int j = 0; j < JX; ++j) xload(xrel[dy], xrow[dy], xbase + 64 * j, lbase + (unsigned)(dy * (XRP * 128) + j * 8192));
+    const unsigned long long gbase = grow + (unsigned long long)((unsigned)x0 * gpitch);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      if (FAST) dma(0ull, gvoff, gbase + (unsigned long long)((unsigned)(32 * j) * gpitch), lbase + (unsigned)(XS_B + j * 8192));
+      else {
+        const int kx = x0 + gr4 + 32 * j;
+        const bool ok = cg_ok & (kx < p.Wo);
         const unsigned long long m = ok ? ~0ull : 0ull;
-        const unsigned long long a = xrow[dy] + (unsigned long long)(unsigned)xc * apitch + (unsigned)lcoff[k];
-        src = (a & m) | (zlane & ~m);
-        dsto = buf_off + dy * (XRP * 128) + rb * 1024;
-      } else {
-        const int kx = x0 + lrow[k];
-        const bool ok = (lcoff[k] >= 0) & (kx < p.Wo);
-        const unsigned long long m = ok ? ~0ull : 0ull;
-        const unsigned long long a = grow + (unsigned long long)(unsigned)kx * gpitch + (unsigned)lcoff[k];
-        src = (a & m) | (zlane & ~m);
-        dsto = buf_off + XS_B + (ii - NLX) * 1024;
+        const unsigned long long a = grow + (unsigned long long)(unsigned)kx * gpitch + lcg;
+        dma((a & m) | (zlane & ~m), 0u, 0ull, lbase + (unsigned)(XS_B + j * 8192));
       }
-      // The wave-load is issued BY HAND: with a global_load_lds it knows of still pending, hipcc puts s_waitcnt vmcnt(0) in front of
-      // the next LDS read that may alias it -- i.e. in front of this panel's first fragment read, which would wait for the panels just
-      // requested.  Landing and reuse are ordered by the explicit vmcnt + barrier of the panel loop instead.
-      const unsigned la = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(size_t)(lptr_t)smem + dsto));
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"  // (m0 is a reserved register: nothing else of this kernel uses it)
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(la) : "memory", "m0");
-#pragma clang diagnostic pop
+    }
+    if (wave < 3) {   // the last chunk of input row dy = wave
+      const unsigned rel = wave == 0 ? xrel[0] : (wave == 1 ? xrel[1] : xrel[2]);
+      const unsigned long long rb = wave == 0 ? xrow[0] : (wave == 1 ? xrow[1] : xrow[2]);
+      xload(rel, rb, xbase - wave * 8 + (C - 1) * 8, sm0 - (unsigned)wave * 1024u + buf_off + (unsigned)(wave * (XRP * 128) + (C - 1) * 1024));
     }
   };
 
+  // ---- which products a wave owns.  The tile is 4 co-fragments x 2 ci-fragments x 9 taps of 32 x 32 products.  The first working form
+  //      gave a wave ONE (co, ci) fragment pair and all nine taps: 2 transpose reads of gy^T and 18 of the input per k16 step for 9
+  //      MFMAs.  Now a wave owns a PAIR of co-fragments of one ci-fragment and four taps (wave >> 2 picks taps 0-3 or 4-7), plus
+  //      tap 8 for its first co-fragment: still 9 MFMAs and 9 accumulator tiles, but every input fragment read feeds two MFMAs --
+  //      4 + 10 = 14 reads per step instead of 20 (the LDS pipe moved 327 KB per panel per CU; now 229 KB).
+  const int tg = wave >> 2, cif = (wave >> 1) & 1, cp = wave & 1;
+  const int cof0 = 2 * cp + tg, cof1 = 2 * cp + (1 - tg);   // (my first co-fragment is the one whose tap 8 is mine)
   // ---- fragment addresses.  A transpose read: the 16 lanes of a group give the 8-byte chunks of a [4 rows][16 columns] block in
   //      row-major chunk order (lane i: row i / 4, columns 4 (i % 4) .. +3) and lane i receives column i of the four rows.  Group g of
   //      an operand: 16-channel half g & 1 of the wave's 32-channel fragment, k half g >> 1 (the MFMA's lanes 32-63 carry k 8..15).
-  const int cof = wave & 3, cif = wave >> 2;
   const int li = lane & 15, lg = lane >> 4;
   const int rsub = li >> 2;                          // row of my chunk inside the 4-row block
   const int khalf8 = (lg >> 1) * 8;
   // gy^T: row (k16 step * 16 + khalf8 + 4 ksub + rsub): row & 3 = rsub, so the swizzle is a lane constant
-  const int ga_c8 = (cof * 32 + (lg & 1) * 16) / 4 + (li & 3);      // 8-byte chunk inside the 256-byte row
-  const unsigned ga = (unsigned)(XS_B + (khalf8 + rsub) * 256 + (((ga_c8 >> 1) ^ (rsub << 2)) * 16) + (ga_c8 & 1) * 8);
+  auto ga_of = [&](int cof) __attribute__((always_inline)) -> unsigned {
+    const int c8 = (cof * 32 + (lg & 1) * 16) / 4 + (li & 3);       // 8-byte chunk inside the 256-byte row
+    return (unsigned)(XS_B + (khalf8 + rsub) * 256 + (((c8 >> 1) ^ (rsub << 2)) * 16) + (c8 & 1) * 8);
+  };
+  const unsigned ga[2] = {ga_of(cof0), ga_of(cof1)};
   // a: row (k sW + dx) of kernel row dy; per kW tap the row's swizzle bit differs per lane
   const int xb_c8 = (cif * 32 + (lg & 1) * 16) / 4 + (li & 3);
-  unsigned xb[3];
+  auto xb_of = [&](int t) __attribute__((always_inline)) -> unsigned {
+    const int dy = t / 3, dx = t - 3 * dy;
+    const int r = (khalf8 + rsub) * SW + dx;         // (the rest of the row index is a multiple of 4: bit 1 of the row is bit 1 of r)
+    return (unsigned)(dy * (XRP * 128) + r * 128 + (((xb_c8 >> 1) ^ (((r >> 1) & 1) << 2)) * 16) + (xb_c8 & 1) * 8);
+  };
+  constexpr int NTW = 5;                              // taps a wave reads: 4 tg .. 4 tg + 3, and 8
+  unsigned xb[NTW];
 #pragma unroll
-  for (int dx = 0; dx < 3; ++dx) {
-    const int t = (khalf8 + rsub) * SW + dx;         // (the rest of the row index is a multiple of 4: bit 1 of the row is bit 1 of t)
-    xb[dx] = (unsigned)(t * 128 + (((xb_c8 >> 1) ^ (((t >> 1) & 1) << 2)) * 16) + (xb_c8 & 1) * 8);
-  }
+  for (int j = 0; j < 4; ++j) xb[j] = xb_of(4 * tg + j);
+  xb[4] = xb_of(8);
   auto tr8 = [&](unsigned off, int imm0, int imm1) __attribute__((always_inline)) -> v8 {
+    if (CVVAE_WGRAD_ABLATE & 1) {
+      typedef short s16x8 __attribute__((ext_vector_type(8)));
+      s16x8 v = (short)(off + imm0);
+      asm volatile("" : "+v"(v));
+      return __builtin_bit_cast(v8, v);
+    }
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lrd_t)(smem + off + imm0));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lrd_t)(smem + off + imm1));
     typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -462,70 +522,82 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, co
 #pragma unroll 1
   for (long long pi = 0; pi < npanels; ++pi) {
     // panel pi has landed once at most the loads of the panels issued after it are outstanding
-    if (NBUF == 3 && pi + 1 < npanels) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NBUF == 3 && pi + 1 < npanels) {
+      if (wave < 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW_LO + 1) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLW_LO) : "memory");
+    } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave; and panel pi - 1's buffer is free
     // The barrier puts every wave at the same point, and a panel's requests are ~300 scalar / vector instructions: issued by all
     // waves at once they leave the matrix pipe idle meanwhile (the first build: 0.39 busy, waves 0.5 of their cycles waiting).  The two
     // waves of a SIMD therefore run opposite orders -- waves 0-3 request, then multiply; waves 4-7 multiply, then request -- so that
     // one's requests issue under the other's MFMAs.  (Both orders are legal: the buffer being filled was last read by panel pi - 1,
     // which every wave finished before this barrier; the late requests still have a whole panel to land.)
-    const bool request_first = NBUF == 2 || wave < 4;
+    const bool request_first = NBUF == 2 || wave < 4 || !CVVAE_WGRAD_STAGGER;
     const bool more = pi + NBUF - 1 < npanels;
     if (more && request_first) issue(fill_off);
     const unsigned lb = cur_off, fill_off_now = fill_off;
     cur_off = cur_off + BUF_B == (unsigned)(NBUF * BUF_B) ? 0u : cur_off + BUF_B;
     fill_off = fill_off + BUF_B == (unsigned)(NBUF * BUF_B) ? 0u : fill_off + BUF_B;
     asm volatile("" : "+s"(cur_off), "+s"(fill_off));
-    // DEPTH operand pairs ahead: the reads of MFMA m + DEPTH are requested before MFMA m issues (the counters of the one-ahead form:
-    // waves 0.51 of their cycles in s_waitcnt with the LDS pipe nowhere near busy -- a transpose read takes longer to come back than
-    // one or two MFMAs last); the fence keeps hipcc from hoisting more (left alone it requested a whole step's fragments and spilled)
-    constexpr int DEPTH = CVVAE_WGRAD_DEPTH, NM = (KP / 16) * NSP;
-    auto b_of = [&](int m) __attribute__((always_inline)) -> v8 {
-      const int s = m / NSP, t = m % NSP, dy = t / 3, dx = t % 3;
-      return tr8(lb + xb[dx], dy * (XRP * 128) + (s * 16) * SW * 128, dy * (XRP * 128) + (s * 16 + 4) * SW * 128);
+    // Input fragments are requested DEPTH taps (2 DEPTH MFMAs) ahead of their first MFMA, the next step's two gy^T fragments during
+    // the current step; the fences keep hipcc from hoisting more (left alone it requested a whole step's fragments and spilled).
+    constexpr int DEPTH = CVVAE_WGRAD_DEPTH < 6 ? CVVAE_WGRAD_DEPTH : 5, NS = KP / 16, NU = NS * NTW;
+    auto b_of = [&](int u) __attribute__((always_inline)) -> v8 {
+      const int st = u / NTW, j = u % NTW;
+      return tr8(lb + xb[j], (st * 16) * SW * 128, (st * 16 + 4) * SW * 128);
     };
-    auto a_of = [&](int s) __attribute__((always_inline)) -> v8 { return tr8(lb + ga, (s * 16) * 256, (s * 16 + 4) * 256); };
-    v8 aq[2], bq[DEPTH];
-    aq[0] = a_of(0);
+    auto a_of = [&](int st, int c) __attribute__((always_inline)) -> v8 { return tr8(lb + ga[c], (st * 16) * 256, (st * 16 + 4) * 256); };
+    v8 aq[2][2], bq[DEPTH];
+    aq[0][0] = a_of(0, 0);
+    aq[0][1] = a_of(0, 1);
 #pragma unroll
-    for (int m = 0; m < DEPTH; ++m) bq[m] = b_of(m);
+    for (int u = 0; u < DEPTH; ++u) bq[u] = b_of(u);
 #pragma unroll
-    for (int m = 0; m < NM; ++m) {
-      const int s = m / NSP, t = m % NSP;
-      const v8 bcur = bq[m % DEPTH];
-      if (m + DEPTH < NM) {
-        bq[m % DEPTH] = b_of(m + DEPTH);
-        if ((m + DEPTH) % NSP == 0) aq[((m + DEPTH) / NSP) & 1] = a_of((m + DEPTH) / NSP);
-      }
-      acc[t] = Tr<T>::mfma(aq[s & 1], bcur, acc[t]);
+    for (int u = 0; u < NU; ++u) {
+      const int st = u / NTW, j = u % NTW;
+      const v8 bcur = bq[u % DEPTH];
+      if (u + DEPTH < NU) bq[u % DEPTH] = b_of(u + DEPTH);
+      if (st + 1 < NS && (j == 1 || j == 2)) aq[(st + 1) & 1][j - 1] = a_of(st + 1, j - 1);
+      if (CVVAE_WGRAD_ABLATE & 8) asm volatile("" ::"v"(aq[st & 1][0]), "v"(bcur));
+      else acc[2 * j] = Tr<T>::mfma(aq[st & 1][0], bcur, acc[2 * j]);       // (tap 8: j = 4 -> acc[8])
       __builtin_amdgcn_sched_barrier(0);
+      if (j < 4) {
+        if (CVVAE_WGRAD_ABLATE & 8) asm volatile("" ::"v"(aq[st & 1][1]), "v"(bcur));
+        else acc[2 * j + 1] = Tr<T>::mfma(aq[st & 1][1], bcur, acc[2 * j + 1]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     if (more && !request_first) issue(fill_off_now);
   }
   const int ntaps = p.kT * NSP;
 #pragma unroll
-  for (int t = 0; t < NSP; ++t) {
-    float* o = p.part + (((long long)slab * ntaps + dt * NSP + t) * p.Coutp + co0 + cof * 32) * p.Cinp + ci0 + cif * 32 + (lane & 31);
+  for (int a = 0; a < NSP; ++a) {
+    const int t = a == 8 ? 8 : 4 * tg + (a >> 1), cof = (a == 8 || !(a & 1)) ? cof0 : cof1;
+    float* o = p.part + ((((long long)slab * ntaps + dt * NSP + t) * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * (CO * CI) +
+               (cof * 32) * CI + cif * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * p.Cinp] = acc[t][i];
+    for (int i = 0; i < 16; ++i) o[(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * CI] = acc[a][i];
   }
 }
 
-// dW[co][ci][tap] = sum over slabs (index order) of part[slab][tap][co][ci]
+// dW[co][ci][tap] = sum over slabs (index order) of the partial tiles.  part[slab][tap][co block][ci block][128][64]: the 128 x 64
+// tile a workgroup writes per tap is CONTIGUOUS (32 KB; until round 5 the layout was [slab][tap][Coutp][Cinp], 256-byte pieces at a
+// pitch of Cinp floats -- measured the same, tools/r5_call17.sh: the stores were not what the call waits for).
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int ntaps, int Coutp, int Cinp,
                                                            int Cout, int Cin, float* __restrict__ dw) {
-  // One thread = four consecutive input channels of one (tap, co): the slab reads are 16-byte and coalesced (the partial
-  // buffer is ~100x the weight tensor; an earlier revision indexed by OUTPUT element -- tap fastest -- and read 4 bytes per
-  // 128-byte line).  The 4-byte stores into [Cout][Cin][taps] are scattered, but they are 1/nslab of the traffic.
-  const int c4 = Cinp >> 2;
-  const long long n4 = (long long)ntaps * Coutp * c4;
+  // One thread = four consecutive input channels of one (tap, co), in the order of the partial buffer: the slab reads are 16-byte
+  // and coalesced (the partial buffer is ~100x the weight tensor; an earlier revision indexed by OUTPUT element -- tap fastest --
+  // and read 4 bytes per 128-byte line).  The 4-byte stores into [Cout][Cin][taps] are scattered, but they are 1/nslab of the traffic.
+  const int n_co = Coutp >> 7, n_ci = Cinp >> 6;
+  const long long n4 = (long long)ntaps * Coutp * (Cinp >> 2);
   const long long slab_stride4 = n4;  // float4 units
   const float4* __restrict__ part4 = reinterpret_cast<const float4*>(part);
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int ci = (int)(i % c4) * 4;
-    const long long r = i / c4;
-    const int co = (int)(r % Coutp), tap = (int)(r / Coutp);
+    const int within = (int)(i & 2047);            // float4 index inside the 128 x 64 tile
+    const long long tile = i >> 11;
+    const int ci = (int)(tile % n_ci) * 64 + (within & 15) * 4;
+    const int co = (int)((tile / n_ci) % n_co) * 128 + (within >> 4);
+    const int tap = (int)(tile / ((long long)n_ci * n_co));
     if (co >= Cout || ci >= Cin) continue;
     const float4* s = part4 + i;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -556,7 +628,25 @@ static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_c
   const int kp = d->kH == 1 ? (xp ? 64 : 128) : (xp ? 32 : 64);      // the kernel's K panel (wgrad_kernel)
   const long long rows = (long long)d->B * d->To * d->Ho * ((d->Wo + kp - 1) / kp);  // panels in all
   const long long per_slab = (long long)n_co * n_ci * d->kT;
+  static const int target = getenv("CVVAE_WGRAD_WGS") ? atoi(getenv("CVVAE_WGRAD_WGS")) : 0;   // (tuning aid, read once)
+  static const bool dma_off = getenv("CVVAE_WGRAD_DMA") && atoi(getenv("CVVAE_WGRAD_DMA")) == 0;
   long long s = (768 + per_slab - 1) / per_slab;                      // ~3 workgroups per CU in all
+  if (target > 0) s = target >= 512 ? (target + per_slab - 1) / per_slab : target / per_slab;
+  else if (!xp && d->kH == 3 && !dma_off) {
+    // wgrad_dma_kernel: ONE workgroup per CU at a time (its LDS), the workgroups of a slab share an XCD (slab % 8), and every
+    // workgroup pays a pipeline fill and a 295 KB partial-tile store the CU waits for -- all of them at once, against HBM.  So the
+    // fewest ROUNDS r of 32 workgroups per XCD that fill >= 90 % of the r x 32 places with whole slabs: 128 -> 128 (6 members per
+    // slab): 5 slabs per XCD in one round; 2 members: 16 in one; 24 or 96 members: three rounds (the 768 of the line above).
+    // Measured (profiles/r5_ab_wgrad_rounds.log): one round instead of three is -11 % on the per-frame 128-channel layers, -24 % on
+    // the strided ones, even on 128 -> 128 3x3x3 -- and a third of the partial tiles to write and to reduce.
+    for (int r = 1; r <= 3; ++r) {
+      const long long spx = 32ll * r / per_slab;
+      if (spx >= 1 && spx * per_slab * 10 >= 9 * 32ll * r) {
+        s = spx * 8;
+        break;
+      }
+    }
+  }
   const long long tile_bytes = (long long)d->kT * d->kH * d->kW * n_co * 128 * n_ci * 64 * 4;
   const long long cap = (512ll << 20) / (tile_bytes > 0 ? tile_bytes : 1);  // <= 512 MB of partials
   if (s > cap) s = cap;
@@ -592,9 +682,16 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
     if (!dma_off) {
       // the zero page behind the partial tiles (cvvae_conv_wgrad_workspace_bytes reserves it)
       char* zero = reinterpret_cast<char*>(ws) + wgrad_partial_bytes(d, nslab, n_co, n_ci);
-      rc = (int)hipMemsetAsync(zero, 0, 512, s);
-      if (rc) return rc;
-      hipLaunchKernelGGL((wgrad_dma_kernel<T, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (const void*)zero);
+      // the scalar-base form of the wave-loads (FAST, see the kernel): whole gradient panels, every channel of the tiles stored, the
+      // input tensor and the zero page inside one 4 GB window
+      const unsigned long long a0 = (unsigned long long)(size_t)a, z0 = (unsigned long long)(size_t)zero;
+      const unsigned long long a1 = a0 + (unsigned long long)d->B * d->Ti * d->Hi * d->Wi * d->in_pix_stride * sizeof(T);
+      const unsigned long long lo = a0 < z0 ? a0 : z0, hi = a1 > z0 + 512 ? a1 : z0 + 512;
+      static const bool fast_off = getenv("CVVAE_WGRAD_FAST") && atoi(getenv("CVVAE_WGRAD_FAST")) == 0;
+      const bool fast = !fast_off && d->Wo % 64 == 0 && d->in_pix_stride >= (long long)n_ci * 64 && g_ps >= (long long)n_co * 128 &&
+                        hi - lo < (1ull << 32) && (long long)d->Wo * g_ps * (long long)sizeof(T) < (1ll << 31);
+      if (fast) hipLaunchKernelGGL((wgrad_dma_kernel<T, SW, true>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (void*)zero);
+      else hipLaunchKernelGGL((wgrad_dma_kernel<T, SW, false>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (void*)zero);
     } else {
       hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p);
     }
