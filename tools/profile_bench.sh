@@ -27,5 +27,7 @@ for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" GRBM_GUI_ACTIVE \
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$tag -- $BENCH > $O/pmc_$tag.log 2>&1
 done
 python $R/tools/pmc_summary.py $O --json=$O/pmc_traffic.json --sq=$O/pmc_sq.json --steps=$STEPS > $O/pmc_summary.txt 2>&1
+# (the per-dispatch counter tables are small: kept compressed, so that the summaries can be re-derived off the box)
+(cd $O && find . -name "*counter_collection.csv" | tar czf raw_counters.tgz -T - 2>/dev/null)
 rm -rf $O/trace $O/pmc_*/   # raw traces are large; the summaries are what is kept
 ls -la $O
