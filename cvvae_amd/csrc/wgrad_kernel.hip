@@ -252,15 +252,15 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
     }
     __syncthreads();
   }
-  // partial tile: part[slab][tap][co block][ci block][128 co][64 ci] (see wgrad_reduce_kernel); accumulator register i of a lane =
+  // partial tile: part[slab][co block][ci block][128 co][tap][64 ci] (see wgrad_reduce_kernel); accumulator register i of a lane =
   // output channel 8*(i/4) + 4*(lane/32) + i%4 of the fragment, input channel lane % 32
   const int ntaps = p.kT * NSP;
 #pragma unroll
   for (int t = 0; t < NSP; ++t) {
-    float* o = p.part + ((((long long)slab * ntaps + dt * NSP + t) * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * (CO * CI) +
-               (cof * 32) * CI + cif * 32 + (lane & 31);
+    float* o = p.part + (((((long long)slab * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * CO + cof * 32) * ntaps + dt * NSP + t) * CI +
+               cif * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * CI] = acc[t][i];
+    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * ntaps * CI] = acc[t][i];
   }
 }
 
@@ -362,7 +362,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
   // of the other wave of a SIMD is not hidden under MFMAs: the round-2 probe, profiles/r2_peak_probe.txt).  Here an input load is
   // add / clamp / multiply-add (+ compare / select under zero padding) relative to `lo` = the lower of the two addresses, a
   // gradient load is no vector instruction at all.
-  const unsigned long long lo64 = FAST ? ((size_t)ap < (size_t)zp ? (unsigned long long)(size_t)ap : (unsigned long long)(size_t)zp) : 0ull;
+  // (a layer with replicate padding on every axis never reads the zero page: its base is the tensor's, wherever the workspace lies --
+  //  in a full training step the allocator puts most workspaces more than 4 GB from the activations)
+  const bool needs_zero = p.mode_hw == 0 || p.mode_t == 0;
+  const unsigned long long lo64 = !FAST ? 0ull : (!needs_zero || (size_t)ap < (size_t)zp) ? (unsigned long long)(size_t)ap : (unsigned long long)(size_t)zp;
   const unsigned zvoff = (unsigned)((unsigned long long)(size_t)zp - lo64) + (unsigned)(lane & 31) * 16u;
   const unsigned gvoff = (unsigned)gr4 * gpitch + lcg;                   // (FAST) my offset inside the gradient panel
   constexpr unsigned NONE = 0xffffffffu;
@@ -573,33 +576,32 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
 #pragma unroll
   for (int a = 0; a < NSP; ++a) {
     const int t = a == 8 ? 8 : 4 * tg + (a >> 1), cof = (a == 8 || !(a & 1)) ? cof0 : cof1;
-    float* o = p.part + ((((long long)slab * ntaps + dt * NSP + t) * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * (CO * CI) +
-               (cof * 32) * CI + cif * 32 + (lane & 31);
+    float* o = p.part + (((((long long)slab * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * CO + cof * 32) * ntaps + dt * NSP + t) * CI +
+               cif * 32 + (lane & 31);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) o[(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * CI] = acc[a][i];
+    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * ntaps * CI] = acc[a][i];
   }
 }
 
-// dW[co][ci][tap] = sum over slabs (index order) of the partial tiles.  part[slab][tap][co block][ci block][128][64]: the 128 x 64
-// tile a workgroup writes per tap is CONTIGUOUS (32 KB; until round 5 the layout was [slab][tap][Coutp][Cinp], 256-byte pieces at a
-// pitch of Cinp floats -- measured the same, tools/r5_call17.sh: the stores were not what the call waits for).
+// dW[co][ci][tap] = sum over slabs (index order) of the partial tiles.  part[slab][co block][ci block][128 co][tap][64 ci]: for one
+// output channel and one block of 64 input channels, all taps are one contiguous run of ntaps x 256 bytes -- in the partial buffer AND
+// (transposed: [64 ci][taps]) in the [Cout][Cin][taps] result.  One block per (co, ci block): 16-byte coalesced slab reads, the sums
+// transposed through LDS, one contiguous store.  (Until round 5 a thread stored its four sums as four dwords 4 x ntaps bytes apart:
+// 70 launches = 3.4 ms of a training step for 8 GB of partial tiles, profiles/r5_train_step_kernel_breakdown.txt.)
+constexpr int WGRAD_RED_MAXTAPS = 27;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int ntaps, int Coutp, int Cinp,
                                                            int Cout, int Cin, float* __restrict__ dw) {
-  // One thread = four consecutive input channels of one (tap, co), in the order of the partial buffer: the slab reads are 16-byte
-  // and coalesced (the partial buffer is ~100x the weight tensor; an earlier revision indexed by OUTPUT element -- tap fastest --
-  // and read 4 bytes per 128-byte line).  The 4-byte stores into [Cout][Cin][taps] are scattered, but they are 1/nslab of the traffic.
-  const int n_co = Coutp >> 7, n_ci = Cinp >> 6;
-  const long long n4 = (long long)ntaps * Coutp * (Cinp >> 2);
-  const long long slab_stride4 = n4;  // float4 units
-  const float4* __restrict__ part4 = reinterpret_cast<const float4*>(part);
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-    const int within = (int)(i & 2047);            // float4 index inside the 128 x 64 tile
-    const long long tile = i >> 11;
-    const int ci = (int)(tile % n_ci) * 64 + (within & 15) * 4;
-    const int co = (int)((tile / n_ci) % n_co) * 128 + (within >> 4);
-    const int tap = (int)(tile / ((long long)n_ci * n_co));
-    if (co >= Cout || ci >= Cin) continue;
-    const float4* s = part4 + i;
+  __shared__ float sm[64 * (WGRAD_RED_MAXTAPS + 1)];
+  const int n_ci = Cinp >> 6;
+  const int ci_blk = blockIdx.x % n_ci, co = blockIdx.x / n_ci;       // co = co block * 128 + row
+  if (co >= Cout) return;
+  const int ci0 = ci_blk * 64;
+  const long long slab_stride4 = (long long)Coutp * Cinp * ntaps / 4;  // float4 units
+  const float4* __restrict__ src = reinterpret_cast<const float4*>(part) +
+                                   ((((long long)(co >> 7) * n_ci + ci_blk) * 128 + (co & 127)) * ntaps) * 16;
+  const int n4 = ntaps * 16, pitch = ntaps + 1;
+  for (int i = threadIdx.x; i < n4; i += 256) {
+    const float4* s = src + i;
     float4 acc = {0.f, 0.f, 0.f, 0.f};
     int sl = 0;
     for (; sl + 8 <= nslab; sl += 8) {  // eight loads in flight, summed in slab order (deterministic)
@@ -613,12 +615,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       const float4 v = s[sl * slab_stride4];
       acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
-    float* o = dw + ((long long)co * Cin + ci) * ntaps + tap;
-    o[0] = acc.x;
-    if (ci + 1 < Cin) o[ntaps] = acc.y;
-    if (ci + 2 < Cin) o[2 * ntaps] = acc.z;
-    if (ci + 3 < Cin) o[3 * ntaps] = acc.w;
+    const int tap = i >> 4, c = (i & 15) * 4;
+    sm[(c + 0) * pitch + tap] = acc.x;
+    sm[(c + 1) * pitch + tap] = acc.y;
+    sm[(c + 2) * pitch + tap] = acc.z;
+    sm[(c + 3) * pitch + tap] = acc.w;
   }
+  __syncthreads();
+  const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;                    // stored input channels of this block
+  float* o = dw + ((long long)co * Cin + ci0) * ntaps;
+  for (int e = threadIdx.x; e < nci * ntaps; e += 256) o[e] = sm[(e / ntaps) * pitch + e % ntaps];
 }
 
 static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_ci) {
@@ -686,7 +692,8 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
       // input tensor and the zero page inside one 4 GB window
       const unsigned long long a0 = (unsigned long long)(size_t)a, z0 = (unsigned long long)(size_t)zero;
       const unsigned long long a1 = a0 + (unsigned long long)d->B * d->Ti * d->Hi * d->Wi * d->in_pix_stride * sizeof(T);
-      const unsigned long long lo = a0 < z0 ? a0 : z0, hi = a1 > z0 + 512 ? a1 : z0 + 512;
+      const bool needs_zero = d->pad_mode_hw == 0 || d->pad_mode_t == 0;   // (else the zero page is never read: see the kernel)
+      const unsigned long long lo = !needs_zero || a0 < z0 ? a0 : z0, hi = !needs_zero || a1 > z0 + 512 ? a1 : z0 + 512;
       static const bool fast_off = getenv("CVVAE_WGRAD_FAST") && atoi(getenv("CVVAE_WGRAD_FAST")) == 0;
       const bool fast = !fast_off && d->Wo % 64 == 0 && d->in_pix_stride >= (long long)n_ci * 64 && g_ps >= (long long)n_co * 128 &&
                         hi - lo < (1ull << 32) && (long long)d->Wo * g_ps * (long long)sizeof(T) < (1ll << 31);
@@ -701,9 +708,8 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
   rc = (int)hipGetLastError();
   if (rc) return rc;
   const int ntaps = d->kT * d->kH * d->kW;
-  long long blocks = ((long long)ntaps * p.Coutp * (p.Cinp / 4) + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp,
+  if (ntaps > WGRAD_RED_MAXTAPS) return (int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(p.Coutp * n_ci)), dim3(256), 0, s, (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp,
                      d->Cout, d->Cin, dw);
   return (int)hipGetLastError();
 }

@@ -246,10 +246,22 @@ sd3_decoder_backward = sd3_net_backward
 
 
 def _grads_out(names, pmeta, grads):
-    out = []
+    """the fp32 gradients in the parameters' order, shapes and dtypes.  The conversions of a 16-bit model are ONE multi-tensor copy
+    (a `.to(dt)` per parameter was 244 five-microsecond launches per training step of the sd3 pair)."""
+    out, src, dst = [], [], []
     for name, (dt, req, shape) in zip(names, pmeta):
         gq = grads.get(name)
-        out.append(gq.reshape(shape).to(dt) if (req and gq is not None) else None)
+        if not (req and gq is not None):
+            out.append(None)
+            continue
+        gq = gq.reshape(shape)
+        if gq.dtype != dt:
+            src.append(gq)
+            gq = torch.empty(shape, dtype=dt, device=gq.device)
+            dst.append(gq)
+        out.append(gq)
+    if dst:
+        torch._foreach_copy_(dst, src)
     return out
 
 

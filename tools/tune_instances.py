@@ -14,10 +14,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--family", default="sd3")
 ap.add_argument("--shape", default="1,3,17,512,512")
 ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--train", action="store_true", help="sweep the convolutions of one TRAINING step (taped forward + backward: the input-gradient convs too)")
 a = ap.parse_args()
 torch.manual_seed(0)
 dtype = torch.bfloat16
-vae = (cvvae_amd.CVVAESD3Model if a.family == "sd3" else cvvae_amd.CVVAEModel)().to(dtype).cuda().eval()
+vae = (cvvae_amd.CVVAESD3Model if a.family == "sd3" else cvvae_amd.CVVAEModel)().to(dtype).cuda()
+vae = vae.train() if a.train else vae.eval()
 x = (torch.rand(tuple(int(v) for v in a.shape.split(","))) * 2 - 1).to(dtype).cuda()
 
 # every X(...) row of the instance table -> a force string
@@ -34,8 +36,13 @@ def obs(d, pw, launch):
     launch()
 
 ops.PROFILE = obs
-z = vae.encode(x).latent_dist.mode()
-y = vae.decode(z).sample
+if a.train:
+    mom = vae.encoder(x)
+    xrec = vae.decoder(mom[:, :mom.shape[1] // 2].contiguous())
+    (xrec.float() - x.float()).pow(2).mean().backward()
+else:
+    z = vae.encode(x).latent_dist.mode()
+    y = vae.decode(z).sample
 torch.cuda.synchronize()
 ops.PROFILE = None
 
