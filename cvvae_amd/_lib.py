@@ -12,7 +12,7 @@ F16, BF16, F32, F32Q, F32Q6 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 class ConvDesc(ctypes.Structure):
@@ -73,6 +73,8 @@ PROTOTYPES = {
     "cvvae_upsample2x_sum": (_i32, [_i32, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "cvvae_conv_wgrad_workspace_bytes": (_i64, [ctypes.POINTER(ConvDesc)]),
     "cvvae_conv_wgrad": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _i64, _vp, _vp, _vp]),
+    "cvvae_conv_wgrad_fuses_bias": (_i32, [ctypes.POINTER(ConvDesc)]),
+    "cvvae_conv_wgrad_bias": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     "cvvae_channel_sums_workspace_bytes": (_i64, [_i32, _i64, _i32]),
     "cvvae_channel_sums": (_i32, [_i32, _vp, _vp, _i64, _i32, _i64, _i32, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "cvvae_temporal_attention_bwd": (_i32, [_i32, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _i32, _vp, _vp, _vp, _vp]),

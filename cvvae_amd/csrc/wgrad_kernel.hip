@@ -40,6 +40,7 @@ struct WgradArgs {
   const void* a;
   const void* g;
   float* part;
+  float* bias_part;  // wgrad_dma_kernel: per-slab sums of gy over the pixels, [nslab][Coutp] (nullptr: not wanted)
   int B, Ti, Hi, Wi, Cin;
   long long a_ps;
   int To, Ho, Wo, Cout;
@@ -336,6 +337,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
   for (int t = 0; t < NSP; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // the BIAS gradient (sum of gy over the pixels) as a by-product: the gy^T fragments are in registers anyway, and one more MFMA per
+  // k16 step against a matrix of ones sums them over the pixels.  Done once per output channel: by the workgroups of input-channel
+  // block 0 and time tap 0, in the four waves (cif = 0) whose first co-fragments cover the 128 channels.  (A separate pass over gy
+  // per convolution was 70 launches = 2.7 ms of a training step.)
+  f32x16 accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
 
   // ---- my wave-loads of a panel.  An input image row dy is C = XRP / 8 wave-loads (8 pixels x 128 bytes each), the gradient image
   //      KP / 4 = 16 (4 pixels x 256 bytes).  Wave w issues, in this order: for dy = 0, 1, 2 the input chunks w, w + 8, .. of row dy
@@ -478,6 +486,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
   //      4 + 10 = 14 reads per step instead of 20 (the LDS pipe moved 327 KB per panel per CU; now 229 KB).
   const int tg = wave >> 2, cif = (wave >> 1) & 1, cp = wave & 1;
   const int cof0 = 2 * cp + tg, cof1 = 2 * cp + (1 - tg);   // (my first co-fragment is the one whose tap 8 is mine)
+  const bool do_bias = p.bias_part != nullptr && ci_blk == 0 && dt == 0 && cif == 0;   // (wave-uniform)
+  v8 ones;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
   // ---- fragment addresses.  A transpose read: the 16 lanes of a group give the 8-byte chunks of a [4 rows][16 columns] block in
   //      row-major chunk order (lane i: row i / 4, columns 4 (i % 4) .. +3) and lane i receives column i of the four rows.  Group g of
   //      an operand: 16-channel half g & 1 of the wave's 32-channel fragment, k half g >> 1 (the MFMA's lanes 32-63 carry k 8..15).
@@ -564,6 +576,10 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
       if (CVVAE_WGRAD_ABLATE & 8) asm volatile("" ::"v"(aq[st & 1][0]), "v"(bcur));
       else acc[2 * j] = Tr<T>::mfma(aq[st & 1][0], bcur, acc[2 * j]);       // (tap 8: j = 4 -> acc[8])
       __builtin_amdgcn_sched_barrier(0);
+      if (j == 0 && do_bias) {
+        accb = Tr<T>::mfma(aq[st & 1][0], ones, accb);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       if (j < 4) {
         if (CVVAE_WGRAD_ABLATE & 8) asm volatile("" ::"v"(aq[st & 1][1]), "v"(bcur));
         else acc[2 * j + 1] = Tr<T>::mfma(aq[st & 1][1], bcur, acc[2 * j + 1]);
@@ -581,6 +597,11 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * ntaps * CI] = acc[a][i];
   }
+  if (do_bias && (lane & 31) == 0) {   // (every column of the 32 x 32 product holds the same sums)
+    float* o = p.bias_part + (long long)slab * p.Coutp + co0 + cof0 * 32;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)] = accb[i];
+  }
 }
 
 // dW[co][ci][tap] = sum over slabs (index order) of the partial tiles.  part[slab][co block][ci block][128 co][tap][64 ci]: for one
@@ -590,9 +611,19 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
 // 70 launches = 3.4 ms of a training step for 8 GB of partial tiles, profiles/r5_train_step_kernel_breakdown.txt.)
 constexpr int WGRAD_RED_MAXTAPS = 27;
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslab, int ntaps, int Coutp, int Cinp,
-                                                           int Cout, int Cin, float* __restrict__ dw) {
+                                                           int Cout, int Cin, float* __restrict__ dw,
+                                                           const float* __restrict__ bias_part, float* __restrict__ db) {
   __shared__ float sm[64 * (WGRAD_RED_MAXTAPS + 1)];
   const int n_ci = Cinp >> 6;
+  if ((int)blockIdx.x >= Coutp * n_ci) {   // the blocks behind the weight blocks: db[co] = sum over slabs of the fused bias sums
+    const int co = ((int)blockIdx.x - Coutp * n_ci) * 256 + (int)threadIdx.x;
+    if (co < Cout) {
+      float acc = 0.f;
+      for (int sl = 0; sl < nslab; ++sl) acc += bias_part[(long long)sl * Coutp + co];
+      db[co] = acc;
+    }
+    return;
+  }
   const int ci_blk = blockIdx.x % n_ci, co = blockIdx.x / n_ci;       // co = co block * 128 + row
   if (co >= Cout) return;
   const int ci0 = ci_blk * 64;
@@ -625,6 +656,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int nci = Cin - ci0 < 64 ? Cin - ci0 : 64;                    // stored input channels of this block
   float* o = dw + ((long long)co * Cin + ci0) * ntaps;
   for (int e = threadIdx.x; e < nci * ntaps; e += 256) o[e] = sm[(e / ntaps) * pitch + e % ntaps];
+}
+
+// does the weight-gradient launch of this convolution also produce the bias gradient?  (wgrad_dma_kernel: 16-bit operands, 3x3 taps)
+static bool wgrad_fuses_bias(const cvvae_conv_desc* d) {
+  static const bool dma_off = getenv("CVVAE_WGRAD_DMA") && atoi(getenv("CVVAE_WGRAD_DMA")) == 0;
+  return !dma_off && d->dtype < CVVAE_F32 && d->kH == 3;
 }
 
 static void wgrad_plan(const cvvae_conv_desc* d, int& nslab, int& n_co, int& n_ci) {
@@ -667,11 +704,11 @@ static long long wgrad_partial_bytes(const cvvae_conv_desc* d, int nslab, int n_
 }
 
 template <typename T, int KHW, bool XP, int SW>
-static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
+static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, float* db, void* ws, hipStream_t s) {
   int nslab, n_co, n_ci;
   wgrad_plan(d, nslab, n_co, n_ci);
   WgradArgs p{};
-  p.a = a; p.g = gy; p.part = (float*)ws;
+  p.a = a; p.g = gy; p.part = (float*)ws; p.bias_part = nullptr;
   p.B = d->B; p.Ti = d->Ti; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.a_ps = d->in_pix_stride;
   p.To = d->To; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout; p.g_ps = g_ps;
   p.kT = d->kT; p.sT = d->sT; p.sH = d->sH; p.sW = d->sW; p.pt = d->pad_t; p.ph = d->pad_h; p.pw = d->pad_w;
@@ -682,12 +719,14 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
   p.n_members = n_co * n_ci * d->kT;
   const int nslab8 = (nslab + 7) / 8 * 8;  // (blocks of the padding slabs exit at once)
   int rc = 0;
+  if (db && !wgrad_fuses_bias(d)) return CVVAE_EUNSUPPORTED;
   // CVVAE_WGRAD_DMA=0: the register-staged kernel for every layer (A/B aid; read once)
   static const bool dma_off = getenv("CVVAE_WGRAD_DMA") && atoi(getenv("CVVAE_WGRAD_DMA")) == 0;
   if constexpr (KHW == 3 && !XP) {
     if (!dma_off) {
       // the zero page behind the partial tiles (cvvae_conv_wgrad_workspace_bytes reserves it)
       char* zero = reinterpret_cast<char*>(ws) + wgrad_partial_bytes(d, nslab, n_co, n_ci);
+      if (db) p.bias_part = reinterpret_cast<float*>(zero + 512);   // [nslab][Coutp] behind the zero page
       // the scalar-base form of the wave-loads (FAST, see the kernel): whole gradient panels, every channel of the tiles stored, the
       // input tensor and the zero page inside one 4 GB window
       const unsigned long long a0 = (unsigned long long)(size_t)a, z0 = (unsigned long long)(size_t)zero;
@@ -709,14 +748,14 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
   if (rc) return rc;
   const int ntaps = d->kT * d->kH * d->kW;
   if (ntaps > WGRAD_RED_MAXTAPS) return (int)hipErrorInvalidValue;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(p.Coutp * n_ci)), dim3(256), 0, s, (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp,
-                     d->Cout, d->Cin, dw);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(p.Coutp * n_ci + (p.bias_part ? (d->Cout + 255) / 256 : 0))), dim3(256), 0, s,
+                     (const float*)ws, nslab, ntaps, p.Coutp, p.Cinp, d->Cout, d->Cin, dw, (const float*)p.bias_part, db);
   return (int)hipGetLastError();
 }
 
 template <typename T, int KHW, bool XP>
-static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, void* ws, hipStream_t s) {
-  return d->sW == 2 ? wgrad_launch_sw<T, KHW, XP, 2>(d, a, gy, g_ps, dw, ws, s) : wgrad_launch_sw<T, KHW, XP, 1>(d, a, gy, g_ps, dw, ws, s);
+static int wgrad_launch(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t g_ps, float* dw, float* db, void* ws, hipStream_t s) {
+  return d->sW == 2 ? wgrad_launch_sw<T, KHW, XP, 2>(d, a, gy, g_ps, dw, db, ws, s) : wgrad_launch_sw<T, KHW, XP, 1>(d, a, gy, g_ps, dw, db, ws, s);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1051,11 +1090,22 @@ int64_t cvvae_conv_wgrad_workspace_bytes(const cvvae_conv_desc* d) {
   if (!d || d->Cout <= 0 || d->Cin <= 0 || d->kT <= 0) return CVVAE_EINVAL;
   int nslab, n_co, n_ci;
   wgrad_plan(d, nslab, n_co, n_ci);
-  return (int64_t)wgrad_partial_bytes(d, nslab, n_co, n_ci) + 512;  // + the zero page of wgrad_dma_kernel
+  // + the zero page of wgrad_dma_kernel + its per-slab bias sums
+  return (int64_t)wgrad_partial_bytes(d, nslab, n_co, n_ci) + 512 + ((int64_t)nslab * n_co * 128 * 4 + 255) / 256 * 256;
+}
+
+int cvvae_conv_wgrad_fuses_bias(const cvvae_conv_desc* d) {
+  if (!d) return CVVAE_EINVAL;
+  return wgrad_fuses_bias(d) ? 1 : 0;
 }
 
 int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, void* workspace,
                      void* stream_) {
+  return cvvae_conv_wgrad_bias(d, a, gy, gy_pix_stride, dw, nullptr, workspace, stream_);
+}
+
+int cvvae_conv_wgrad_bias(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, float* dbias,
+                          void* workspace, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (!d || !a || !gy || !dw || !workspace) return CVVAE_EINVAL;
   if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0) return CVVAE_EINVAL;
@@ -1067,16 +1117,16 @@ int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, in
   const bool k3 = d->kH == 3;
   switch (d->dtype) {
     case CVVAE_BF16:
-      return k3 ? wgrad_launch<__bf16, 3, false>(d, a, gy, gy_pix_stride, dw, workspace, stream)
-                : wgrad_launch<__bf16, 1, false>(d, a, gy, gy_pix_stride, dw, workspace, stream);
+      return k3 ? wgrad_launch<__bf16, 3, false>(d, a, gy, gy_pix_stride, dw, dbias, workspace, stream)
+                : wgrad_launch<__bf16, 1, false>(d, a, gy, gy_pix_stride, dw, dbias, workspace, stream);
     case CVVAE_F16:
-      return k3 ? wgrad_launch<_Float16, 3, false>(d, a, gy, gy_pix_stride, dw, workspace, stream)
-                : wgrad_launch<_Float16, 1, false>(d, a, gy, gy_pix_stride, dw, workspace, stream);
+      return k3 ? wgrad_launch<_Float16, 3, false>(d, a, gy, gy_pix_stride, dw, dbias, workspace, stream)
+                : wgrad_launch<_Float16, 1, false>(d, a, gy, gy_pix_stride, dw, dbias, workspace, stream);
     case CVVAE_F32:
     case CVVAE_F32Q:
     case CVVAE_F32Q6:
-      return k3 ? wgrad_launch<__bf16, 3, true>(d, a, gy, gy_pix_stride, dw, workspace, stream)
-                : wgrad_launch<__bf16, 1, true>(d, a, gy, gy_pix_stride, dw, workspace, stream);
+      return k3 ? wgrad_launch<__bf16, 3, true>(d, a, gy, gy_pix_stride, dw, dbias, workspace, stream)
+                : wgrad_launch<__bf16, 1, true>(d, a, gy, gy_pix_stride, dw, dbias, workspace, stream);
     default:
       return CVVAE_EINVAL;
   }

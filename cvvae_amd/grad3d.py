@@ -55,9 +55,11 @@ def _conv_param_grads(wc: WeightCache, grads: Optional[Dict[str, torch.Tensor]],
     if callable(a):
         a = a()
     w = wc.p(pre + ".weight")
-    grads[pre + ".weight"] = ops.conv_wgrad(a, g, k, cin=w.shape[1], cout=w.shape[0], **geom).reshape(w.shape)
-    if wc.has(pre + ".bias"):
-        grads[pre + ".bias"] = ops.bias_grad(g, cout=w.shape[0])
+    if wc.has(pre + ".bias"):   # (the bias gradient comes out of the weight-gradient launch where the kernel fuses it)
+        dw, grads[pre + ".bias"] = ops.conv_wgrad(a, g, k, cin=w.shape[1], cout=w.shape[0], bias=True, **geom)
+    else:
+        dw = ops.conv_wgrad(a, g, k, cin=w.shape[1], cout=w.shape[0], **geom)
+    grads[pre + ".weight"] = dw.reshape(w.shape)
 
 
 def _gn_backward(grads, name: str, x, g, tabs, affine, silu: bool, add=None):

@@ -583,10 +583,12 @@ def gn_bwd_input_params(x: torch.Tensor, gy: torch.Tensor, tabs: Tuple[torch.Ten
 
 def conv_wgrad(a: torch.Tensor, gy: torch.Tensor, k: Tuple[int, int, int], *, stride=(1, 1, 1),
                pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO, cin: Optional[int] = None,
-               cout: Optional[int] = None) -> torch.Tensor:
+               cout: Optional[int] = None, bias: bool = False):
     """Weight gradient of conv(a, W, stride, pad, modes) given gy = dL/d(output) (cvvae_conv_wgrad).  a: [B,Ti,Hi,Wi,Cs] -- the
     operand the forward multiplied (AFTER its GroupNorm + SiLU, before padding); gy: [B,To,Ho,Wo,Cg].  cin / cout: the weight's real
-    channel counts (default: the tensors' last dims).  Returns fp32 [cout, cin, kT, kH, kW] (nn.Conv3d's layout)."""
+    channel counts (default: the tensors' last dims).  Returns fp32 [cout, cin, kT, kH, kW] (nn.Conv3d's layout); with bias = True
+    the pair (dW, fp32 [cout] bias gradient = sum of gy over the pixels) -- from the same launch where the kernel fuses it
+    (cvvae_conv_wgrad_bias), else from bias_grad."""
     lib = L.load()
     _need_gpu(a)
     assert a.dim() == 5 and gy.dim() == 5 and a.is_contiguous() and gy.is_contiguous() and a.dtype == gy.dtype
@@ -616,8 +618,15 @@ def conv_wgrad(a: torch.Tensor, gy: torch.Tensor, k: Tuple[int, int, int], *, st
         L.check(nb, "cvvae_conv_wgrad_workspace_bytes")
     ws = torch.empty(nb, dtype=torch.uint8, device=a.device)
     dw = torch.empty((d.Cout, d.Cin, kT * kH * kW), dtype=torch.float32, device=a.device)
-    L.check(lib.cvvae_conv_wgrad(d, a.data_ptr(), gy.data_ptr(), Cg, dw.data_ptr(), ws.data_ptr(), _stream(a)), "cvvae_conv_wgrad")
-    return dw[:cout, :cin].reshape(cout, cin, kT, kH, kW)
+    db = None
+    if bias and lib.cvvae_conv_wgrad_fuses_bias(d) == 1:
+        db = torch.empty(d.Cout, dtype=torch.float32, device=a.device)
+    L.check(lib.cvvae_conv_wgrad_bias(d, a.data_ptr(), gy.data_ptr(), Cg, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                      ws.data_ptr(), _stream(a)), "cvvae_conv_wgrad_bias")
+    dw = dw[:cout, :cin].reshape(cout, cin, kT, kH, kW)
+    if not bias:
+        return dw
+    return dw, (db[:cout] if db is not None else bias_grad(gy, cout=cout))
 
 
 def bias_grad(gy: torch.Tensor, cout: Optional[int] = None) -> torch.Tensor:

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 11
+#define CVVAE_ABI_VERSION 12
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
@@ -335,8 +335,15 @@ int cvvae_upsample2x_sum(int32_t dtype, const void* g, int64_t N, int32_t H, int
  * tensors, every product as three bf16 MFMAs (hi/lo split of both operands, ~2^-16 relative).  Accumulation is fp32 and
  * deterministic (per-slab partial tiles summed in index order).  workspace: cvvae_conv_wgrad_workspace_bytes(d) bytes.
  * Cin % 8 == 0, Cout % 8 == 0.
+ * cvvae_conv_wgrad_bias (ABI 12): the same launch also writes dbias[Cout] (fp32) = sum of gy over the pixels -- the bias half of
+ * aten::convolution_backward -- where cvvae_conv_wgrad_fuses_bias(d) returns 1 (16-bit operands, 3x3 spatial taps: the sums are
+ * one more MFMA per 16 pixels on the gy tile the kernel holds anyway); elsewhere it returns CVVAE_EUNSUPPORTED for dbias != NULL
+ * and the caller sums gy with cvvae_channel_sums.  dbias = NULL is cvvae_conv_wgrad.
  */
 int64_t cvvae_conv_wgrad_workspace_bytes(const cvvae_conv_desc* d);
+int cvvae_conv_wgrad_fuses_bias(const cvvae_conv_desc* d);
+int cvvae_conv_wgrad_bias(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, float* dbias,
+                          void* workspace, void* stream);
 int cvvae_conv_wgrad(const cvvae_conv_desc* d, const void* a, const void* gy, int64_t gy_pix_stride, float* dw, void* workspace,
                      void* stream);
 

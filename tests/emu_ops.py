@@ -347,7 +347,7 @@ def gn_bwd_input(x, gy, tabs, gamma, beta, silu, add=None, per_frame=False, grou
 
 
 def conv_wgrad(a, gy, k, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO, cin=None,
-               cout=None):
+               cout=None, bias=False):
     """dW of conv(a, W) given gy (cvvae_conv_wgrad): autograd of the plain convolution over the padded operand"""
     cin = a.shape[-1] if cin is None else cin
     cout = gy.shape[-1] if cout is None else cout
@@ -357,6 +357,8 @@ def conv_wgrad(a, gy, k, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_
         y = F.conv3d(f, w, None, stride=stride)
         assert tuple(y.shape[2:]) == tuple(gy.shape[1:4]), (tuple(y.shape), tuple(gy.shape))
         (y * gy.float()[..., :cout].permute(0, 4, 1, 2, 3)).sum().backward()
+    if bias:
+        return w.grad.detach(), bias_grad(gy, cout=cout)
     return w.grad.detach()
 
 

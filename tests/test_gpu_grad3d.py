@@ -85,6 +85,12 @@ def test_conv_wgrad(case, dtype):
     assert e <= WGRAD_TOL[dtype]
     again = ops.conv_wgrad(a.cuda(), gy.cuda(), k, stride=stride, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, cin=cin, cout=cout)
     assert torch.equal(got, again), "not deterministic"
+    # the bias gradient out of the same launch (ABI 12: fused by the 16-bit 3x3 kernel, cvvae_channel_sums elsewhere)
+    dw2, db = ops.conv_wgrad(a.cuda(), gy.cuda(), k, stride=stride, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, cin=cin, cout=cout, bias=True)
+    want = gy.float()[..., :cout].reshape(-1, cout).sum(0)
+    eb = rel(db, want)
+    _log(f"[wgrad {name} {str(dtype)[6:]}] db rel {eb:.2e}")
+    assert torch.equal(dw2, got) and db.shape == (cout,) and db.dtype == torch.float32 and eb <= 5e-5
 
 
 @pytest.mark.parametrize("dtype", DT)
