@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call 18 (final kernel sources): smoke, rocprofv3 kernel stats + PMC passes of the bench command, the default bench line
+# round 5, GPU call 18 / 23 (final kernel sources): smoke, rocprofv3 kernel stats + PMC passes of the bench command, the default bench line
 # (in-run CPU baseline), the training step with gradient parity
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
