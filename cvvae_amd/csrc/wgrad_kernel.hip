@@ -604,283 +604,6 @@ __global__ __launch_bounds__(512, 1) void wgrad_dma_kernel(const WgradArgs p, vo
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// wgrad_ring_kernel (round 5, last step): wgrad_dma_kernel for stride-1 layers with the scalar-base wave-loads, with the input ROWS
-// kept in LDS across consecutive output rows.  The panel of output row y needs input rows y - 1, y, y + 1; the panel below it (same
-// 64 columns) needs y, y + 1, y + 2: two of its three rows are already there.  So the panels of a workgroup run COLUMN-major (output
-// row fastest inside a 64-pixel column of a frame), the input rows live in a ring of seven row slots (9 KB each: three rows of the
-// panel being multiplied, the new rows of the two panels in flight, two more where a column starts and three rows are new at once)
-// and a panel requests ONE input row + its gradient tile: 25.6 KB of wave-loads instead of 44, 3 (one wave: 4) wave-loads per wave
-// instead of 5-6 -- the ablation builds priced exactly those two items (the wave-loads' landing 0.12 ms, their request code 0.09 ms
-// of the 1.0 ms of the 128 -> 128 layer).  Everything else -- tile, products per wave, transpose reads, bias by-product, partial
-// tiles -- is wgrad_dma_kernel's; the summation order over the pixels differs (column-major), the result is as deterministic.
-// ---------------------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(512, 1) void wgrad_ring_kernel(const WgradArgs p, void* __restrict__ zero_page) {
-  using v8 = typename Tr<T>::v8;
-  constexpr int KP = 64, CO = 128, CI = 64, NSP = 9;
-  constexpr int XR = KP + 2, XRP = (XR + 7) / 8 * 8, C = XRP / 8;      // 66 input pixels under a panel, 72 stored, 9 chunks of 8
-  constexpr int RS = XRP * 128, NSLOT = 7, XS_B = NSLOT * RS;           // row slots
-  constexpr int GS_B = KP * 256, NG = 3;                                // gradient tiles
-  static_assert(C == 9 && XS_B + NG * GS_B <= 160 * 1024, "LDS budget");
-  __shared__ __attribute__((aligned(1024))) char smem[XS_B + NG * GS_B];
-  typedef __attribute__((address_space(3))) void* lptr_t;
-  typedef __attribute__((address_space(3))) s16x4* lrd_t;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int member = idx % p.n_members, slab = (idx / p.n_members) * 8 + xcd;
-  if (slab >= p.nslab) return;
-  const int coci = member % p.n_coci, dt = member / p.n_coci;
-  const int co_blk = coci / p.n_ci_blk, ci_blk = coci % p.n_ci_blk;
-  const int co0 = co_blk * CO, ci0 = ci_blk * CI;
-  const int npanel_row = (p.Wo + KP - 1) / KP;
-  const long long ptotal = (long long)p.rows_total * npanel_row;
-  const long long pbeg = ptotal * slab / p.nslab, npanels = ptotal * (slab + 1) / p.nslab - pbeg;
-  const T* __restrict__ ap = reinterpret_cast<const T*>(p.a);
-  const T* __restrict__ gp = reinterpret_cast<const T*>(p.g);
-  const char* const zp = reinterpret_cast<const char*>(zero_page);
-  if (tid < 128) __atomic_store_n(reinterpret_cast<unsigned*>(zero_page) + tid, 0u, __ATOMIC_RELAXED);   // (as wgrad_dma_kernel)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  f32x16 acc[NSP], accb;
-#pragma unroll
-  for (int t = 0; t < NSP; ++t)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) accb[i] = 0.f;
-
-  // ---- lane constants of the wave-loads (as wgrad_dma_kernel's FAST form)
-  const int xr8 = lane >> 3;
-  const int xq = (lane & 7) ^ (((xr8 >> 1) & 1) << 2);
-  const unsigned lcx = (unsigned)((ci0 + xq * 8) * (int)sizeof(T));
-  const int gr4 = wave * 4 + (lane >> 4);
-  const int gq = (lane & 15) ^ ((gr4 & 3) << 2);
-  const unsigned apitch = (unsigned)(p.a_ps * sizeof(T)), gpitch = (unsigned)(p.g_ps * sizeof(T));
-  const bool needs_zero = p.mode_hw == 0 || p.mode_t == 0;
-  const unsigned long long lo64 = (!needs_zero || (size_t)ap < (size_t)zp) ? (unsigned long long)(size_t)ap : (unsigned long long)(size_t)zp;
-  const unsigned zvoff = (unsigned)((unsigned long long)(size_t)zp - lo64) + (unsigned)(lane & 31) * 16u;
-  const unsigned gvoff = (unsigned)gr4 * gpitch + (unsigned)((co0 + gq * 8) * (int)sizeof(T));
-  constexpr unsigned NONE = 0xffffffffu;
-  const int wi1 = p.Wi - 1;
-  const bool zero_hw = p.mode_hw == 0;
-  const unsigned sm0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(lptr_t)smem);
-
-  // ---- position of the next panel to request: column-major inside a frame (output row fastest)
-  int q_yo = (int)(pbeg % p.Ho), q_xp, q_to, q_b;
-  {
-    const long long t1 = pbeg / p.Ho;
-    q_xp = (int)(t1 % npanel_row);
-    const long long t2 = t1 / npanel_row;
-    q_to = (int)(t2 % p.To);
-    q_b = (int)(t2 / p.To);
-  }
-  bool q_first = true;                    // the next panel starts a column (or the workgroup): all three of its rows are new
-  int q_nxt = 0, q_s1 = 0, q_s2 = 0;      // ring allocator; the row slots of the last requested panel's rows dy = 1, 2
-
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"   // (m0 is a reserved register: nothing else of this kernel uses it)
-  auto dma = [&](unsigned voff, unsigned long long sbase, unsigned la) __attribute__((always_inline)) {
-    if (CVVAE_WGRAD_ABLATE & 2) asm volatile("s_mov_b32 m0, %2\n\ts_nop 0" ::"v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
-    else asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(la) : "memory", "m0");
-  };
-#pragma clang diagnostic pop
-  // one input chunk: pixels xs .. xs + 7 (xs wave-uniform) of the row at `rel` from lo64 (NONE: a row of zero padding) to LDS address la
-  auto xload = [&](unsigned rel, int xs, unsigned la) __attribute__((always_inline)) {
-    const int xi = xs + xr8;
-    const int xc = min(max(xi, 0), wi1);
-    unsigned voff = zvoff;
-    if (rel != NONE) {                      // (wave-uniform)
-      voff = __umul24((unsigned)xc, apitch) + lcx + rel;
-      if (zero_hw) voff = xi == xc ? voff : zvoff;
-    }
-    dma(voff, lo64, la);
-  };
-  // the source of input row dy under output row (b, to, yo), relative to lo64
-  auto row_rel = [&](int b, int to, int yo, int dy) __attribute__((always_inline)) -> unsigned {
-    bool z = false;
-    const int ts = map_coord(to * p.sT + dt - p.pt, p.Ti, p.mode_t, z);
-    const int ys = map_coord(yo + dy - p.ph, p.Hi, p.mode_hw, z);
-    const unsigned long long a = (unsigned long long)(size_t)ap + (unsigned long long)((((long long)b * p.Ti + ts) * p.Hi + ys) * p.Wi) * apitch;
-    return z ? NONE : (unsigned)(a - lo64);
-  };
-  // request the next panel into gradient tile `gbuf`; returns its descriptor: row slots s0 | s1 << 4 | s2 << 8, my loads << 12
-  auto issue = [&](unsigned gbuf) __attribute__((always_inline)) -> unsigned {
-    if (CVVAE_WGRAD_ABLATE & 4) return 0u;
-    const bool first = q_first;
-    const int b = q_b, to = q_to, yo = q_yo, x0 = q_xp * KP;
-    int s0, s1, s2;
-    if (first) {
-      s0 = q_nxt;
-      s1 = s0 + 1 >= NSLOT ? s0 + 1 - NSLOT : s0 + 1;
-      s2 = s1 + 1 >= NSLOT ? s1 + 1 - NSLOT : s1 + 1;
-    } else {
-      s0 = q_s1;
-      s1 = q_s2;
-      s2 = q_nxt;
-    }
-    q_nxt = s2 + 1 >= NSLOT ? s2 + 1 - NSLOT : s2 + 1;
-    q_s1 = s1;
-    q_s2 = s2;
-    q_first = false;
-    if (++q_yo == p.Ho) {
-      q_yo = 0;
-      q_first = true;
-      if (++q_xp == npanel_row) {
-        q_xp = 0;
-        if (++q_to == p.To) {
-          q_to = 0;
-          ++q_b;
-        }
-      }
-    }
-    const int xbase = x0 - p.pw;
-    if (first) {
-#pragma unroll
-      for (int dy = 0; dy < 2; ++dy) {
-        const unsigned rel = row_rel(b, to, yo, dy);
-        const unsigned la = sm0 + (unsigned)((dy == 0 ? s0 : s1) * RS);
-        xload(rel, xbase + wave * 8, la + (unsigned)wave * 1024u);
-        if (wave == dy + 1) xload(rel, xbase + (C - 1) * 8, la + (unsigned)((C - 1) * 1024));
-      }
-    }
-    {
-      const unsigned rel = row_rel(b, to, yo, 2);
-      const unsigned la = sm0 + (unsigned)(s2 * RS);
-      xload(rel, xbase + wave * 8, la + (unsigned)wave * 1024u);
-      if (wave == 0) xload(rel, xbase + (C - 1) * 8, la + (unsigned)((C - 1) * 1024));
-    }
-    const unsigned long long gbase = (unsigned long long)(size_t)gp +
-                                     (unsigned long long)((((long long)b * p.To + to) * p.Ho + yo) * p.Wo + x0) * gpitch;
-    const unsigned lg = sm0 + (unsigned)XS_B + gbuf + (unsigned)wave * 1024u;
-    dma(gvoff, gbase, lg);
-    dma(gvoff, gbase + (unsigned long long)(32u * gpitch), lg + 8192u);
-    const int cnt = first ? (wave < 3 ? 6 : 5) : (wave == 0 ? 4 : 3);   // (first: rows 0, 1 leftovers by waves 1, 2; row 2's by wave 0)
-    return (unsigned)s0 | ((unsigned)s1 << 4) | ((unsigned)s2 << 8) | ((unsigned)cnt << 12);
-  };
-  auto wait_loads = [&](int n) __attribute__((always_inline)) {   // (n wave-uniform: the immediate needs a branch)
-    if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-    else if (n == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if (n == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-    else if (n == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  };
-
-  // ---- which products a wave owns, fragment addresses: as wgrad_dma_kernel, the kernel row's offset being the row's SLOT
-  const int tg = wave >> 2, cif = (wave >> 1) & 1, cp = wave & 1;
-  const int cof0 = 2 * cp + tg, cof1 = 2 * cp + (1 - tg);
-  const bool do_bias = p.bias_part != nullptr && ci_blk == 0 && dt == 0 && cif == 0;
-  v8 ones;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) ones[i] = (T)1.0f;
-  const int li = lane & 15, lg = lane >> 4;
-  const int rsub = li >> 2;
-  const int khalf8 = (lg >> 1) * 8;
-  auto ga_of = [&](int cof) __attribute__((always_inline)) -> unsigned {
-    const int c8 = (cof * 32 + (lg & 1) * 16) / 4 + (li & 3);
-    return (unsigned)(XS_B + (khalf8 + rsub) * 256 + (((c8 >> 1) ^ (rsub << 2)) * 16) + (c8 & 1) * 8);
-  };
-  const unsigned ga[2] = {ga_of(cof0), ga_of(cof1)};
-  const int xb_c8 = (cif * 32 + (lg & 1) * 16) / 4 + (li & 3);
-  constexpr int NTW = 5;
-  unsigned xb[NTW];      // lane part of a tap's fragment address (pixel row khalf8 + rsub + dx of the slot)
-  int tdy[NTW];          // (wave-uniform) the kernel row of my j-th tap
-#pragma unroll
-  for (int j = 0; j < NTW; ++j) {
-    const int t = j < 4 ? 4 * tg + j : 8;
-    const int dy = t / 3, dx = t - 3 * dy;
-    const int r = khalf8 + rsub + dx;
-    xb[j] = (unsigned)(r * 128 + (((xb_c8 >> 1) ^ (((r >> 1) & 1) << 2)) * 16) + (xb_c8 & 1) * 8);
-    tdy[j] = dy;
-  }
-  auto tr8 = [&](unsigned off, int imm0, int imm1) __attribute__((always_inline)) -> v8 {
-    if (CVVAE_WGRAD_ABLATE & 1) {
-      typedef short s16x8 __attribute__((ext_vector_type(8)));
-      s16x8 v = (short)(off + imm0);
-      asm volatile("" : "+v"(v));
-      return __builtin_bit_cast(v8, v);
-    }
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lrd_t)(smem + off + imm0));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lrd_t)(smem + off + imm1));
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-    return __builtin_bit_cast(v8, v);
-  };
-
-  // ---- pipeline: two panels in flight ahead of the one being multiplied; d0, d1 = descriptors of panels pi, pi + 1
-  unsigned d0 = 0u, d1 = 0u;
-  if (npanels > 0) d0 = issue(0u);
-  if (npanels > 1) d1 = issue((unsigned)GS_B);
-  unsigned g_cur = 0u, g_fill = (unsigned)(2 * GS_B);
-#pragma unroll 1
-  for (long long pi = 0; pi < npanels; ++pi) {
-    // panel pi (and every row it shares with earlier panels) has landed once only the loads of panel pi + 1 are outstanding
-    wait_loads(pi + 1 < npanels ? (int)(d1 >> 12) : 0);
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // ... for every wave; and the slots of panel pi - 1's first row are free
-    const bool request_first = wave < 4 || !CVVAE_WGRAD_STAGGER;     // (the two waves of a SIMD in opposite orders: wgrad_dma_kernel)
-    const bool more = pi + 2 < npanels;
-    unsigned dn = 0u;
-    if (more && request_first) dn = issue(g_fill);
-    const unsigned lbg = g_cur, g_fill_now = g_fill;
-    g_cur = g_cur + GS_B == (unsigned)(NG * GS_B) ? 0u : g_cur + GS_B;
-    g_fill = g_fill + GS_B == (unsigned)(NG * GS_B) ? 0u : g_fill + GS_B;
-    asm volatile("" : "+s"(g_cur), "+s"(g_fill));
-    const unsigned so0 = (d0 & 15u) * RS, so1 = ((d0 >> 4) & 15u) * RS, so2 = ((d0 >> 8) & 15u) * RS;
-    unsigned xa[NTW];    // my taps' fragment addresses in this panel's slots
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) xa[j] = (tdy[j] == 0 ? so0 : (tdy[j] == 1 ? so1 : so2)) + xb[j];
-    constexpr int DEPTH = CVVAE_WGRAD_DEPTH < 6 ? CVVAE_WGRAD_DEPTH : 5, NS = KP / 16, NU = NS * NTW;
-    auto b_of = [&](int u) __attribute__((always_inline)) -> v8 {
-      const int st = u / NTW, j = u % NTW;
-      return tr8(xa[j], (st * 16) * 128, (st * 16 + 4) * 128);
-    };
-    auto a_of = [&](int st, int c) __attribute__((always_inline)) -> v8 { return tr8(lbg + ga[c], (st * 16) * 256, (st * 16 + 4) * 256); };
-    v8 aq[2][2], bq[DEPTH];
-    aq[0][0] = a_of(0, 0);
-    aq[0][1] = a_of(0, 1);
-#pragma unroll
-    for (int u = 0; u < DEPTH; ++u) bq[u] = b_of(u);
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-      const int st = u / NTW, j = u % NTW;
-      const v8 bcur = bq[u % DEPTH];
-      if (u + DEPTH < NU) bq[u % DEPTH] = b_of(u + DEPTH);
-      if (st + 1 < NS && (j == 1 || j == 2)) aq[(st + 1) & 1][j - 1] = a_of(st + 1, j - 1);
-      if (CVVAE_WGRAD_ABLATE & 8) asm volatile("" ::"v"(aq[st & 1][0]), "v"(bcur));
-      else acc[2 * j] = Tr<T>::mfma(aq[st & 1][0], bcur, acc[2 * j]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (j == 0 && do_bias) {
-        accb = Tr<T>::mfma(aq[st & 1][0], ones, accb);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (j < 4) {
-        if (CVVAE_WGRAD_ABLATE & 8) asm volatile("" ::"v"(aq[st & 1][1]), "v"(bcur));
-        else acc[2 * j + 1] = Tr<T>::mfma(aq[st & 1][1], bcur, acc[2 * j + 1]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
-    if (more && !request_first) dn = issue(g_fill_now);
-    d0 = d1;
-    d1 = dn;
-  }
-  const int ntaps = p.kT * NSP;
-#pragma unroll
-  for (int a = 0; a < NSP; ++a) {
-    const int t = a == 8 ? 8 : 4 * tg + (a >> 1), cof = (a == 8 || !(a & 1)) ? cof0 : cof1;
-    float* o = p.part + (((((long long)slab * (p.Coutp / CO) + co_blk) * p.n_ci_blk + ci_blk) * CO + cof * 32) * ntaps + dt * NSP + t) * CI +
-               cif * 32 + (lane & 31);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[(long long)(8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)) * ntaps * CI] = acc[a][i];
-  }
-  if (do_bias && (lane & 31) == 0) {
-    float* o = p.bias_part + (long long)slab * p.Coutp + co0 + cof0 * 32;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[8 * (i >> 2) + 4 * (lane >> 5) + (i & 3)] = accb[i];
-  }
-}
-
 // dW[co][ci][tap] = sum over slabs (index order) of the partial tiles.  part[slab][co block][ci block][128 co][tap][64 ci]: for one
 // output channel and one block of 64 input channels, all taps are one contiguous run of ntaps x 256 bytes -- in the partial buffer AND
 // (transposed: [64 ci][taps]) in the [Cout][Cin][taps] result.  One block per (co, ci block): 16-byte coalesced slab reads, the sums
@@ -1013,11 +736,9 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
       static const bool fast_off = getenv("CVVAE_WGRAD_FAST") && atoi(getenv("CVVAE_WGRAD_FAST")) == 0;
       const bool fast = !fast_off && d->Wo % 64 == 0 && d->in_pix_stride >= (long long)n_ci * 64 && g_ps >= (long long)n_co * 128 &&
                         hi - lo < (1ull << 32) && (long long)d->Wo * g_ps * (long long)sizeof(T) < (1ll << 31);
-      // ... and for stride-1 layers the form that keeps the input rows in LDS across consecutive output rows (wgrad_ring_kernel)
-      static const bool ring_off = getenv("CVVAE_WGRAD_RING") && atoi(getenv("CVVAE_WGRAD_RING")) == 0;
-      if (fast && SW == 1 && d->sH == 1 && d->Ho >= 2 && !ring_off)
-        hipLaunchKernelGGL((wgrad_ring_kernel<T>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (void*)zero);
-      else if (fast) hipLaunchKernelGGL((wgrad_dma_kernel<T, SW, true>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (void*)zero);
+      // (a form that keeps the input rows in LDS across consecutive output rows -- column-major panels, one new row per panel, 25.6 instead
+      //  of 44 KB of wave-loads -- was built and measured 1-3 % slower: commit aa16cd7, profiles/r5_ab_wgrad_rounds.log)
+      if (fast) hipLaunchKernelGGL((wgrad_dma_kernel<T, SW, true>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (void*)zero);
       else hipLaunchKernelGGL((wgrad_dma_kernel<T, SW, false>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p, (void*)zero);
     } else {
       hipLaunchKernelGGL((wgrad_kernel<T, KHW, XP, SW>), dim3((unsigned)(nslab8 * p.n_members)), dim3(512), 0, s, p);
