@@ -880,6 +880,11 @@ def compact_record(out: dict) -> dict:
             tr = t.get("roofline")
             if tr:
                 r[key].update(kernel=tr.get("kernel"), frac=tr.get("frac"), avg_launch_ms=tr.get("avg_launch_ms"))
+    # the cheapest mode inside north_star's tolerance (|delta| <= 1e-3 on the latents, frames within fp16 tolerance), by name and rate
+    inside = [(r[k]["value"], k) for k in ("tolerance_mode", "tolerance_mode_mixed")
+              if isinstance(r.get(k), dict) and r[k].get("meets_north_star_tolerance") and r[k].get("value")]
+    if inside:
+        r["fastest_mode_inside_tolerance"] = {"mode": max(inside)[1], "value": max(inside)[0]}
     if r:
         o["roofline"] = r
     cb = out.get("cpu_baseline")
