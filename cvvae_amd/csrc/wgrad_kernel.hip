@@ -282,8 +282,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_kernel(const WgradArgs p) {
 //     the LDS side of a wave-load is lane-linear) so that the 32 lanes of a transpose-read half cover all 64 banks (sW = 1).
 //   * padding = the source address of a lane: replicate clamps it, zero padding / pixels past the row end / channels past the stored
 //     ones read a 512-byte zero page at the end of the workspace (cleared by every workgroup before its first wave-load).
-//   * every wave issues the same number of wave-loads per panel (the tail repeats a load), so "panel i has landed" is an exact
-//     s_waitcnt vmcnt(NLW) -- nothing else of this loop touches vector memory -- and ONE barrier per panel orders landing and reuse.
+//   * the wave-loads of a panel are dealt to the waves statically, the same number per panel for a wave (waves 0-2: one more), so
+//     "panel i has landed" is an exact s_waitcnt vmcnt(my loads per panel) -- nothing else of this loop touches vector memory -- and
+//     ONE barrier per panel orders landing and reuse.
+//   * a wave owns a pair of co-fragments x four taps (+ tap 8 for one of them): 9 MFMAs per k16 step from 14 transpose reads; the
+//     bias gradient (sum of gy over the pixels) is one more MFMA per step against ones in the workgroups that own it (ABI 12).
+//   * FAST (per launch): wave-loads as scalar base + 32-bit lane offset; the per-lane 64-bit form serves ragged tiles and far zero pages.
 // ---------------------------------------------------------------------------------------------------------
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 #ifndef CVVAE_WGRAD_DEPTH
