@@ -737,7 +737,8 @@ static int wgrad_launch_sw(const cvvae_conv_desc* d, const void* a, const void* 
       const unsigned long long a1 = a0 + (unsigned long long)d->B * d->Ti * d->Hi * d->Wi * d->in_pix_stride * sizeof(T);
       const bool needs_zero = d->pad_mode_hw == 0 || d->pad_mode_t == 0;   // (else the zero page is never read: see the kernel)
       const unsigned long long lo = !needs_zero || a0 < z0 ? a0 : z0, hi = !needs_zero || a1 > z0 + 512 ? a1 : z0 + 512;
-      static const bool fast_off = getenv("CVVAE_WGRAD_FAST") && atoi(getenv("CVVAE_WGRAD_FAST")) == 0;
+      const char* fenv = getenv("CVVAE_WGRAD_FAST");   // (read per call: tests compare the two address forms inside one process)
+      const bool fast_off = fenv && atoi(fenv) == 0;
       const bool fast = !fast_off && d->Wo % 64 == 0 && d->in_pix_stride >= (long long)n_ci * 64 && g_ps >= (long long)n_co * 128 &&
                         hi - lo < (1ull << 32) && (long long)d->Wo * g_ps * (long long)sizeof(T) < (1ll << 31);
       // (a form that keeps the input rows in LDS across consecutive output rows -- column-major panels, one new row per panel, 25.6 instead

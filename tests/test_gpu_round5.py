@@ -400,3 +400,33 @@ def test_four_wave_selfcheck_and_switch():
         else:
             os.environ["CVVAE_FOUR_WAVE"] = old
     assert float((z0.float() - z1.float()).abs().max()) <= 0.05
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bfloat16", "float16"])
+def test_weight_gradient_scalar_base_form_equals_the_per_lane_form(dtype, monkeypatch):
+    """wgrad_dma_kernel's two address forms of the wave-loads (FAST: scalar base + 32-bit lane offset, chosen per launch; the per-lane
+    64-bit form for ragged tiles and far zero pages) fetch the same bytes to the same LDS places: weight and bias gradients are
+    bit-identical, on replicate-padded 3-D layers (no zero page), a zero-padded per-frame layer and a strided one."""
+    from cvvae_amd import ops
+    REP, ZERO = 1, 0
+    cases = [("k333 replicate 128->128", 128, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (1, 5, 24, 128)),
+             ("k333 replicate 256->128", 256, 128, (3, 3, 3), (1, 1, 1), ((2, 0), (1, 1), (1, 1)), REP, REP, (2, 3, 9, 64)),
+             ("k133 zero 128->128", 128, 128, (1, 3, 3), (1, 1, 1), ((0, 0), (1, 1), (1, 1)), ZERO, ZERO, (1, 4, 17, 192)),
+             ("k333 stride 2 128->128", 128, 128, (3, 3, 3), (2, 2, 2), ((2, 0), (0, 1), (0, 1)), REP, ZERO, (1, 5, 32, 128))]
+    for name, cin, cout, k, st, pad, mt, mhw, (B, T, H, W) in cases:
+        torch.manual_seed(len(name))
+        a = torch.randn(B, T, H, W, cin, device="cuda").to(dtype)
+        To = (T + pad[0][0] + pad[0][1] - k[0]) // st[0] + 1
+        Ho = (H + pad[1][0] + pad[1][1] - k[1]) // st[1] + 1
+        Wo = (W + pad[2][0] + pad[2][1] - k[2]) // st[2] + 1
+        assert Wo % 64 == 0, "the case must be eligible for the scalar-base form"
+        g = torch.randn(B, To, Ho, Wo, cout, device="cuda").to(dtype)
+        kw = dict(stride=st, pad=pad, pad_mode_t=mt, pad_mode_hw=mhw, bias=True)
+        monkeypatch.setenv("CVVAE_WGRAD_FAST", "1")
+        dw1, db1 = ops.conv_wgrad(a, g, k, **kw)
+        monkeypatch.setenv("CVVAE_WGRAD_FAST", "0")
+        dw0, db0 = ops.conv_wgrad(a, g, k, **kw)
+        monkeypatch.delenv("CVVAE_WGRAD_FAST")
+        assert torch.equal(dw1, dw0) and torch.equal(db1, db0), name
+        assert float(dw1.abs().max()) > 0 and float(db1.abs().max()) > 0
