@@ -70,3 +70,52 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libcvvae_hip.so")
     with pytest.raises(_lib.CvvaeError, match="no CPU/eager fallback"):
         _lib.load()
+
+
+def _wgrad_desc(_lib, dtype, cin, cout, k, stride, T, H, W):
+    d = _lib.ConvDesc()
+    d.dtype, d.B, d.Ti, d.Hi, d.Wi, d.Cin, d.in_pix_stride = dtype, 1, T, H, W, cin, cin
+    d.kT, d.kH, d.kW = k
+    d.sT, d.sH, d.sW = stride
+    d.pad_t, d.pad_h, d.pad_w = k[0] - 1, k[1] // 2, k[2] // 2
+    d.To, d.Ho, d.Wo, d.Cout = (T - 1) // stride[0] + 1, (H - 1) // stride[1] + 1, (W - 1) // stride[2] + 1, cout
+    return d
+
+
+def test_weight_gradient_plan_without_gpu():
+    """cvvae_conv_wgrad_workspace_bytes is pure host code: it pins the plan of the weight-gradient launch -- the number of slabs the
+    pixel range is cut into (round 5's rounds rule for the DMA kernel: the fewest rounds of 32 workgroups per XCD that whole slabs
+    fill to >= 90 %; 768 workgroups for the register-staged kernel) -- and which launches also produce the bias gradient (ABI 12)."""
+    from cvvae_amd import _lib
+    lib = _lib.load()
+
+    def slabs(d):
+        n_co, n_ci, taps = (d.Cout + 127) // 128, (d.Cin + 63) // 64, d.kT * d.kH * d.kW
+        tile = taps * n_co * 128 * n_ci * 64 * 4
+        nb = int(lib.cvvae_conv_wgrad_workspace_bytes(d))
+        assert nb > 0
+        # partial tiles (a multiple of 256 bytes) + the 512-byte zero page + the per-slab bias sums (nslab x Coutp floats, 256-aligned)
+        for n in range(1, 4097):
+            if (n * tile + 255) // 256 * 256 + 512 + (n * n_co * 128 * 4 + 255) // 256 * 256 == nb:
+                return n
+        raise AssertionError(f"workspace of {nb} bytes is not a whole number of slabs")
+
+    BF16, F32 = _lib.BF16, _lib.F32
+    # 128 -> 128 3x3x3: 6 members per slab -> 5 slabs per XCD in ONE round of 32 workgroups per XCD
+    assert slabs(_wgrad_desc(_lib, BF16, 128, 128, (3, 3, 3), (1, 1, 1), 17, 256, 256)) == 40
+    # per-frame 3x3: 2 members -> 16 slabs per XCD in one round
+    assert slabs(_wgrad_desc(_lib, BF16, 128, 128, (1, 3, 3), (1, 1, 1), 17, 256, 256)) == 128
+    # 256 -> 256 (24 members) and 512 -> 512 (96): three rounds = the 768 workgroups of the old rule
+    assert slabs(_wgrad_desc(_lib, BF16, 256, 256, (3, 3, 3), (1, 1, 1), 9, 128, 128)) == 32
+    assert slabs(_wgrad_desc(_lib, BF16, 512, 512, (3, 3, 3), (1, 1, 1), 9, 64, 64)) == 8
+    # 128 -> 256 (12 members): two rounds, 5 slabs per XCD
+    assert slabs(_wgrad_desc(_lib, BF16, 128, 256, (3, 3, 3), (1, 1, 1), 9, 128, 128)) == 40
+    # fp32 models and 1x1 layers stay on the register-staged kernel's 768-workgroup rule
+    assert slabs(_wgrad_desc(_lib, F32, 128, 128, (3, 3, 3), (1, 1, 1), 17, 256, 256)) == 128
+    assert slabs(_wgrad_desc(_lib, BF16, 512, 512, (1, 1, 1), (1, 1, 1), 1, 32, 32)) == 24  # (32 members: 768 / 32)
+    # the bias gradient rides along exactly where the DMA kernel runs
+    assert lib.cvvae_conv_wgrad_fuses_bias(_wgrad_desc(_lib, BF16, 128, 128, (3, 3, 3), (1, 1, 1), 5, 64, 64)) == 1
+    assert lib.cvvae_conv_wgrad_fuses_bias(_wgrad_desc(_lib, _lib.F16, 128, 128, (1, 3, 3), (1, 2, 2), 5, 64, 64)) == 1
+    assert lib.cvvae_conv_wgrad_fuses_bias(_wgrad_desc(_lib, F32, 128, 128, (3, 3, 3), (1, 1, 1), 5, 64, 64)) == 0
+    assert lib.cvvae_conv_wgrad_fuses_bias(_wgrad_desc(_lib, BF16, 512, 512, (1, 1, 1), (1, 1, 1), 1, 32, 32)) == 0
+    assert lib.cvvae_conv_wgrad_fuses_bias(None) < 0
