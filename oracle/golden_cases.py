@@ -74,6 +74,8 @@ DEC_CASES = {
 # name -> (family, config overrides, pixel shape, weight seed, input seed, cotangent seeds (enc, dec), latent seed, strides (dx, dz))
 GRAD_CASES = {
     "grad_sd3_t17_256": ("sd3", {}, (1, 3, 17, 256, 256), 0, 31, (32, 33), 34, (4, 1)),
+    # the other family (models/modeling_vae.py's vae3d networks: temporal attention in the mid blocks, 4 latent channels)
+    "grad_vae3d_t17_256": ("vae3d", {}, (1, 3, 17, 256, 256), 0, 41, (42, 43), 44, (4, 1)),
 }
 
 

@@ -42,21 +42,22 @@ compare_grads_with_fixture = P.compare_grads_with_fixture
 
 
 @pytest.mark.parametrize("dtype", DT, ids=["float32", "float16", "bfloat16"])
-def test_full_size_backward_golden(dtype, golden_dir):
-    name = "grad_sd3_t17_256"
+@pytest.mark.parametrize("name", sorted(GRAD_CASES))
+def test_full_size_backward_golden(name, dtype, golden_dir):
     path = os.path.join(golden_dir, name + ".npz")
     if not os.path.isfile(path):
         pytest.skip(f"fixture {name}.npz not generated")
     import cvvae_amd
     family, over, shape, wseed, xseed, cseeds, zseed, strides = GRAD_CASES[name]
     gold = np.load(path)
-    m = cvvae_amd.CVVAESD3Model(**over)
+    m = (cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel)(**over)
     sd = P.load_seeded(m, wseed)
     assert abs(float(sum(v.double().abs().sum() for v in sd.values())) - float(gold["weight_abs_sum"])) < 1e-6 * float(gold["weight_abs_sum"])
+    zc = int(gold["enc_out_shape"][1]) // 2
     m = m.to(dtype).cuda().train()
     tol = GRAD_TOL[dtype]
     for part, net, inp, cseed in (("enc", m.encoder, seeded_input(shape, xseed), cseeds[0]),
-                                  ("dec", m.decoder, seeded_input(tuple(int(v) for v in (shape[0], 16) + tuple(gold["enc_out_shape"][2:])), zseed), cseeds[1])):
+                                  ("dec", m.decoder, seeded_input(tuple(int(v) for v in (shape[0], zc) + tuple(gold["enc_out_shape"][2:])), zseed), cseeds[1])):
         xin = inp.to(dtype).cuda().requires_grad_(True)
         y = net(xin)
         assert tuple(y.shape) == tuple(int(v) for v in gold[part + "_out_shape"])
@@ -64,7 +65,7 @@ def test_full_size_backward_golden(dtype, golden_dir):
         (y.float() * cot.float()).sum().backward()
         e_y, e_x, errs = compare_grads_with_fixture(gold, part, net, y, xin.grad)
         conv_w = [e for e, n in errs if n.endswith("weight") and ("conv" in n or "to_" in n)]
-        _log(f"[full-size backward {part} {str(dtype)[6:]} {tuple(inp.shape)}] vs the reference's own modules: forward rel {e_y:.2e}; "
+        _log(f"[full-size backward {family} {part} {str(dtype)[6:]} {tuple(inp.shape)}] vs the reference's own modules: forward rel {e_y:.2e}; "
              f"dL/d(input) rel {e_x:.2e}; {len(errs)} parameter tensors: worst {errs[0][0]:.2e} ({errs[0][1]}), median "
              f"{errs[len(errs) // 2][0]:.2e}, conv / linear weights worst {max(conv_w):.2e}")
         assert e_y <= tol[0], e_y
