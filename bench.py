@@ -511,7 +511,9 @@ def main():
     cls = cvvae_amd.CVVAESD3Model if family == "sd3" else cvvae_amd.CVVAEModel
     vae = cls()
     P.load_seeded(vae, 0)  # random weights of the named architecture with PyTorch's default-init statistics (no checkpoint access)
-    vae = vae.to(dtype).cuda().eval()
+    # frozen, as the reference's script loads it (cvvae_inference_video.py:11-12: `.cuda()`, `requires_grad_(False)`): a network with
+    # trainable parameters re-checks its parameter checksum -- one host sync -- on every inference pass (modeling._Net.forward)
+    vae = vae.to(dtype).cuda().eval().requires_grad_(False)
     if dtype == torch.float32:
         vae.fp32_mode = "fast" if args.dtype == "f32q" else "exact"
     if args.hip_graphs:
@@ -728,7 +730,7 @@ def main():
         # baseline child starts.
         vq = cls()
         P.load_seeded(vq, 0)
-        vq = vq.float().cuda().eval()
+        vq = vq.float().cuda().eval().requires_grad_(False)
         vq.fp32_mode = "fast"
         xq = x.float()
 

@@ -1,8 +1,8 @@
-// explicit instantiations of conv_fwd_kernel, fast-fp32 instances with fp6 corrections (fp16 MFMA + bf6 K = 64 MFMA; conv_table.h XQ6_A: the 256- / 128-pixel tiles)
+// explicit instantiations of conv_fwd_kernel, fast-fp32 instances with fp6 corrections (fp16 MFMA + bf6 K = 64 MFMA; conv_table.h XQ6_B: planar layout, eight fragments per wave: 3x3x3)
 #include "conv_kernel.h"
 #include "conv_table.h"
 namespace cvvae {
 #define CVVAE_INST(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3>(const ConvArgs&, int, hipStream_t);
-CVVAE_CONV_XQ6_A(CVVAE_INST)
+CVVAE_CONV_XQ6_B(CVVAE_INST)
 }  // namespace cvvae

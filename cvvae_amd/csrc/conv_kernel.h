@@ -219,14 +219,27 @@ struct Geo {
   // LD: planes of NPIXP = NPIX rounded up to whole 64-pixel wave-loads, 16 bytes per pixel; plane q of a buffer at q * PLB
   static constexpr int NQ = 2 * KSUB;                 // 8-channel planes per K chunk
   static constexpr int NGRP = (NPIX + 63) / 64;       // 64-pixel groups = DMA wave-loads per plane
-  static constexpr int PLB = NGRP * 64 * 16;          // bytes per plane
+  // PL ("planar" fast-fp32 layout, XP == 3 instances with eight fragments per wave): the register-staged XP pixel is 80 bytes per 16
+  // channels (hi fp16 32 B + 24 B of bf6 codes, padded to the next conflict-free pitch), which confines the fast-fp32 instances to
+  // 256- / 128-pixel tiles with MREP = 4.  Here the three fields live in separate LDS regions, each a plane with its own pitch and NO
+  // padding: hi as the two 8-channel planes of the DMA layout (16 B per pixel), the codes as a 16-byte plane (dwords 0-3 of the
+  // pixel's 24-byte field) and an 8-byte plane (dwords 4-5) -- 56 bytes per pixel and 16 channels.  A fragment row is 32 consecutive
+  // pixels, so every operand read (ds_read_b128 / ds_read_b64) covers contiguous LDS: conflict-free without padding, tap offsets stay
+  // immediates.  The two-frame 512-pixel tile of the 128-channel 3x3x3 layers (2 x 76 KB) and the all-waves-in-N 256-pixel tile of the
+  // 256- / 512-channel ones (2 x 57 KB) then exist for the fp6 form, with MREP = 8: every weight record feeds 8 MFMAs instead of 4.
+  static constexpr bool PL = (XP == 3 && MREP >= 8 && SW == 1 && TW >= 32);
+  // bytes per plane.  PL: + 256 / (2 KSUB) so that the 16 lanes of a staging write (8 or 4 consecutive pixels x the chunk's 2 or 4 hi
+  // planes) spread over all 64 banks
+  static constexpr int PLB = PL ? (NPIX * 16 + 255) / 256 * 256 + 256 / (2 * KSUB) : NGRP * 64 * 16;
   static constexpr int NDMA = NQ * NGRP;              // wave-loads per chunk, dealt to the 8 waves round-robin
   static constexpr int NDI = (NDMA + 7) / 8;          // ... per wave
-  static constexpr int PIXB = LD ? 16 : (XP ? CK * 4 : CK * 2) + 16;
-  static constexpr int KSB = LD ? 2 * PLB : (XP ? 64 : 32);  // byte offset of k16 sub-chunk ks inside a buffer: ks * KSB
-  static constexpr int KHB = LD ? PLB : 16;                  // ... of the upper k half (lanes 32-63 of an operand): + KHB
+  static constexpr int PIXB = (LD || PL) ? 16 : (XP ? CK * 4 : CK * 2) + 16;
+  static constexpr int KSB = (LD || PL) ? 2 * PLB : (XP ? 64 : 32);  // byte offset of k16 sub-chunk ks inside a buffer: ks * KSB
+  static constexpr int KHB = (LD || PL) ? PLB : 16;                  // ... of the upper k half (lanes 32-63 of an operand): + KHB
+  // PL: code plane A (16 B per pixel) of sub-chunk ks at CQA + ks * PLB, code plane B (8 B per pixel) at CQB + ks * PLB / 2
+  static constexpr int CQA = 2 * KSUB * PLB, CQB = 3 * KSUB * PLB;
   static constexpr int XPM = XP ? 3 : 1;  // weight records per k16 sub-chunk and tap (XP == 1: one MFMA each)
-  static constexpr int BUFB = LD ? NQ * PLB : NPIX * PIXB;
+  static constexpr int BUFB = LD ? NQ * PLB : (PL ? KSUB * (PLB / 2) * 7 : NPIX * PIXB);
   static constexpr int LDSB = 2 * BUFB;
   static constexpr int NWV = WM * WN * KG;  // waves per workgroup: 8 (one workgroup per CU) or 4 (TWO workgroups per CU)
   static constexpr int IPP = 2 * KSUB;   // 16-byte items per pixel
@@ -238,7 +251,10 @@ struct Geo {
   // place: the read for (st+1, r) is issued right after the MFMA of (st, r) and is needed MREP MFMAs (>= 256 cycles) later.  The
   // 32 registers this frees hold ALL staging loads of a chunk at once (one exposed memory latency per chunk instead of two).
   static constexpr int NAB = MREP >= 8 ? 1 : 2;
-  static constexpr int SBATCH = (NAB == 1 && NPASS <= 6) ? NPASS : (NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4));
+  // (PL: fp32 loads are eight registers per pass beside 128 accumulators, the weight ring and the 16 GroupNorm terms: half the
+  //  passes per batch, or the staging spills its LDS addresses and reloads them -- with a full wait -- per item)
+  static constexpr int SBATCH = PL ? (NPASS + 1) / 2
+                                   : (NAB == 1 && NPASS <= 6) ? NPASS : (NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4));
   static constexpr int STEPS = NTAPS * KSUB * XPM;   // k16 steps per chunk, ordered ks-major: st = (ks * NTAPS + tap) * XPM + part
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
   // weight fragments kept in flight per wave: deeper when a wave issues few MFMAs per fragment (small MREP)
@@ -352,6 +368,27 @@ __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...
 template <int N, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
   static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+// helpers of the planar fast-fp32 K loop (conv_fwd_kernel, Geo::PL): one-instruction address sums the compiler can neither hoist nor
+// merge (volatile), and a wave-uniform 64-bit offset made visibly so (an SGPR pair: the weight records are then addressed as the
+// kernel argument's pointer + scalar offset + the lane's 32-bit offset -- offsets, not laundered pointers: a pointer rebuilt from
+// integers is a FLAT pointer, and flat loads count in lgkmcnt, i.e. every weight request would drain the LDS reads in flight)
+__device__ __forceinline__ unsigned pl_addv(unsigned a, unsigned b) {  // a + b
+  unsigned d;
+  asm volatile("v_add_u32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ unsigned pl_add2x(unsigned a, unsigned b) {  // 2 a + b
+  unsigned d;
+  asm volatile("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b));
+  return d;
+}
+__device__ __forceinline__ long long pl_uniform(long long q) {
+  const unsigned long long v = (unsigned long long)q;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
 // out-of-range tap handling: replicate = clamp, zero = flag
@@ -597,7 +634,8 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       }
     }
   };
-  const int lds_w0 = (pstart + spl) * PIXB + (XP ? (sq >> 1) * 64 + (sq & 1) * 16 : sq * 16);  // XP: my hi slice; lo = +32
+  // (PL: my hi slice is pixel slot (pstart + spl) of hi plane sq)
+  const int lds_w0 = (pstart + spl) * PIXB + (G::PL ? sq * G::PLB : (XP ? (sq >> 1) * 64 + (sq & 1) * 16 : sq * 16));  // XP: my hi slice; lo = +32
   // (XP == 2: my 8 bf8 lo values at +32 + (sq & 1) * 8 and my 8 bf8 hi values at +48 + (sq & 1) * 8 of the k16 group)
   const int lds_q8 = (pstart + spl) * PIXB + (sq >> 1) * 64 + 32 + (sq & 1) * 8;
   const TIO* __restrict__ inp = reinterpret_cast<const TIO*>(p.in);
@@ -625,7 +663,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
-        if (k < NPASS && ((passmask >> k) & 1)) {
+        // (fast-fp32 instances: EVERY pass loads, needed or not -- straight-line code.  With a wave-uniform branch per pass hipcc merged each load's
+        //  block with the same pass's block of the processing loop below: load, wait, GroupNorm arithmetic, next load ... -- one
+        //  exposed memory latency per pass; in-kernel stamps: 7-10 k cycles "issuing" six passes against 0.9 k in the 16-bit kernel,
+        //  profiles/r6_probe_fast_fp32_timelines.log)
+        if (k < NPASS && (XP >= 2 || ((passmask >> k) & 1))) {
           // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
           const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
           if constexpr (KT == 3 && KH == 3 && KW == 1 && !std::is_same<TIO, float>::value) {
@@ -645,6 +687,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         CVVAE_PROBE_MARK();
       }
 #endif
+      if constexpr (XP >= 2) __builtin_amdgcn_sched_barrier(0);  // (all loads of the batch are requested before the first is consumed)
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
@@ -678,10 +721,21 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               }
               // dense 24-byte field at +32: item 0 = dwords 0-2, item 1 = dwords 3-5 -> an 8-byte and a 4-byte store each
               const bool odd = (sq & 1) != 0;
-              char* d6 = smem + bufsel * G::BUFB + lds_q8 - (sq & 1) * 8 + k * (G::PPP * PIXB);
               *reinterpret_cast<uint4*>(dst + k * (G::PPP * PIXB)) = oh;
+              if constexpr (G::PL) {
+                // the same 24-byte field, split over code plane A (dwords 0-3, 16 B per pixel) and code plane B (dwords 4-5, 8 B per
+                // pixel) of my k16 sub-chunk: item 0 -> A[0..11]; item 1 -> A[12..15] and B[0..7]
+                // (branch-free: every thread issues one 8-byte and one 4-byte store; parity selects addresses and data)
+                const int hp = pstart + spl + k * G::PPP;
+                const int oA = bufsel * G::BUFB + G::CQA + (sq >> 1) * G::PLB + hp * 16;
+                const int oB = bufsel * G::BUFB + G::CQB + (sq >> 1) * (G::PLB / 2) + hp * 8;
+                *reinterpret_cast<uint2*>(smem + (odd ? oB : oA)) = odd ? make_uint2(q.y, q.z) : make_uint2(q.x, q.y);
+                *reinterpret_cast<unsigned*>(smem + oA + (odd ? 12 : 8)) = odd ? q.x : q.z;
+              } else {
+              char* d6 = smem + bufsel * G::BUFB + lds_q8 - (sq & 1) * 8 + k * (G::PPP * PIXB);
               *reinterpret_cast<uint2*>(d6 + (odd ? 16 : 0)) = odd ? make_uint2(q.y, q.z) : make_uint2(q.x, q.y);
               *reinterpret_cast<unsigned*>(d6 + (odd ? 12 : 8)) = odd ? q.x : q.z;
+              }
             } else if constexpr (XP == 2) {  // hi fp16 | bf8(lo) | bf8(hi)
               uint4 oh = pack8<T>(f);
               uint2 l8 = pack8_bf8(fl), h8 = pack8_bf8(f);
@@ -734,6 +788,13 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     aoff[r] = (unsigned)((((tt * ST) * G::FH + ty * SH) * G::FW + tx * SW) * PIXB + (lane >> 5) * G::KHB +
                          kgrp * (KSUB / KG) * G::KSB);
   }
+  // PL: ONE per-fragment array -- the fragment's pixel in 8-byte units (the pitch of code plane B; the 16-byte planes are addressed
+  // as 2 x + base) -- instead of aoff[] (dead in those instances: the shortcut / 16-bit paths that read it are not instantiated)
+  unsigned aoff8[G::PL ? MREP : 1];
+  if constexpr (G::PL) {
+#pragma unroll
+    for (int r = 0; r < MREP; ++r) aoff8[r] = (aoff[r] - (unsigned)((lane >> 5) * G::KHB)) >> 1;
+  }
   // step i of a time group: k16 sub-chunk i / NSP, spatial tap i % NSP
   auto tf_rec = [&](int i) -> long long {
     const int j = i / XPM, part = i % XPM;
@@ -753,7 +814,11 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #ifndef CVVAE_XQ_DEPTH
 #define CVVAE_XQ_DEPTH 2
 #endif
-  constexpr int XQD = CVVAE_XQ_DEPTH;
+#ifndef CVVAE_XQ_DEPTH8
+#define CVVAE_XQ_DEPTH8 1
+#endif
+  // (eight fragments per wave: a pair of taps lasts 768 cycles -- one pair in flight covers an L2 round trip)
+  constexpr int XQD = MREP >= 8 ? CVVAE_XQ_DEPTH8 : CVVAE_XQ_DEPTH;
   static_assert(XQD == 1 || XQD == 2, "fast-fp32 weight ring: one or two pairs of taps in flight");
   constexpr int NWF = XP >= 2 ? 4 * XQD : PF;
   static_assert(XP < 2 || TFOLD || KT == 1, "fast-fp32 instances: 3-tap time kernels walk time groups, the others have KT = 1");
@@ -761,6 +826,10 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   const T* wqx = reinterpret_cast<const T*>(p.w) + (size_t)b * (size_t)p.w_bstride +
                  (UPS == 2 ? (size_t)phase * (size_t)p.w_phase_stride : 0) +
                  (size_t)(active ? nb : 0) * (size_t)p.nchunks * (size_t)wq_cs + lane * 8;
+  // (PL: the same as a wave-uniform base -- SGPRs -- plus the lane's byte offset)
+  const long long wqu = (long long)b * p.w_bstride + (UPS == 2 ? (long long)phase * p.w_phase_stride : 0) +
+                        (long long)(active ? nb : 0) * (long long)p.nchunks * wq_cs;  // (element offset from p.w)
+  const unsigned wlane = (unsigned)lane * 16u;
   // elements between the packed weights of consecutive 32-channel blocks (NB = 2: the wave's second block)
   const long long wq_nbs = (long long)p.nchunks * (TFOLD ? w_cs : (long long)(STEPS * 512));
   v8 wf[NB][NWF];
@@ -868,6 +937,132 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
       //      correction terms of both taps on ONE bf8 K = 64 MFMA.  A run with an odd tap count ends with a half-empty pair (the
       //      packer zero-fills its second half; the B operand repeats tap a so that 0 x finite = 0).  LDS fragments and weight
       //      records of the next sub-step are requested while the MFMAs of this one issue, as in the loops below.
+      if constexpr (G::PL) {
+        // ---- the same walk on the PLANAR layout with eight fragments per wave (Geo::PL).  One operand slot per fragment, updated IN
+        //      PLACE: the LDS read for the next sub-step's fragment r is issued right after the MFMA that consumed fragment r and is
+        //      needed eight MFMAs (>= 256 cycles) later -- fp16 tap a -> fp16 tap b -> the 24 bytes of codes -> next pair's tap a all
+        //      pass through the same six registers, so the three operand kinds of a pair cost 48 registers per wave instead of 112
+        //      beside the 128 accumulators.  With that few registers to spare, hipcc has to be held to the plan: (1) a slot is ONE
+        //      six-dword value whose parts are replaced (and which an empty asm keeps whole), so a refill cannot be given fresh
+        //      registers; (2) a scheduling fence after every MFMA + refill keeps the refill behind the MFMA that reads the slot;
+        //      (3) every LDS address is formed right at its read by a volatile one-instruction asm from ONE per-fragment array (the
+        //      pixel's offset in 8-byte units; the 16-byte planes use (x << 1) + base) -- left to itself the compiler hoists the
+        //      loop-invariant sums (fragment offset + the lane's tap select) of all pairs out of the chunk loop, ~80 registers;
+        //      (4) the weight records are addressed as a wave-uniform base (SGPRs) + the lane's 32-bit byte offset.
+        if (active) {
+          constexpr int R = KH * KW, PR = (R + 1) / 2, NPAIR = PR * KSUB;
+          const unsigned lb = (unsigned)(cur * G::BUFB);
+          const long long wcb = wqu + (long long)c * wq_cs;  // (element offsets from p.w)
+          const long long wnx = more ? wcb + wq_cs : wcb;    // the last chunk's read-ahead re-reads its own records
+          const int ngq = TFOLD ? tf_ng : 1;
+          i32x4_t s4[MREP];
+          i32x2_t s2[MREP];
+#define CVVAE_LDW(eo) (*reinterpret_cast<const v8*>(reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.w) + (eo)) + wlane))  /* eo: wave-uniform element offset */
+          // refill the low four dwords (an fp16 fragment) / all six (codes) of slot r  (macros, not lambdas: one more level of closures
+          // inside the time-group loop and the optimiser leaves every captured array -- the accumulators included -- in scratch)
+#define CVVAE_PUT4(r, ADDR) s4[r] = *reinterpret_cast<const i32x4_t*>(&smem[ADDR])
+#define CVVAE_PUT6(r, ADDRA, ADDRB)                                                              \
+          do {                                                                                   \
+            s4[r] = *reinterpret_cast<const i32x4_t*>(&smem[ADDRA]);                             \
+            s2[r] = *reinterpret_cast<const i32x2_t*>(&smem[ADDRB]);                             \
+          } while (0)
+#define CVVAE_LO4(r) s4[r]
+          const unsigned khb = (unsigned)((lane >> 5) * G::KHB);  // the fp16 k split: lanes 32-63 read the next plane
+          // the lane's tap inside a pair: lanes 0-31 read the codes of tap a, lanes 32-63 of tap b = a fixed pixel distance further
+          // (+1 in a row, or -- the pair that wraps to the next kernel row -- + FW - (KW - 1)): two per-lane constants
+          const unsigned hi1 = (unsigned)((lane >> 5) * 16), hiw = (unsigned)((lane >> 5) * (G::FW - (KW - 1)) * 16);
+          {
+            const unsigned b0 = lb + (TFOLD ? tf_l0 : 0u) + khb;
+#pragma unroll
+            for (int r = 0; r < MREP; ++r) {
+              CVVAE_PUT4(r, pl_add2x(aoff8[r], b0));
+            }
+          }
+          // one time group: LDS frame offset fo / weight slot ws of this group, fon / wsn of the next one (values, not `g == 0 ? .. : ..`
+          // over the captured plan: hipcc turns that into a load through a SELECTED ADDRESS inside the closure object, which then
+          // -- and with it every array it refers to, the accumulators included -- stays in scratch memory)
+          auto group_body = [&](const unsigned fo, const long long ws, const unsigned fon, const long long wsn, const bool lastg) __attribute__((always_inline)) {
+            const unsigned lbg = lb + fo + khb;                       // hi planes: 16 bytes per pixel
+            const unsigned lba = lb + fo + (unsigned)G::CQA;          // code plane A: 16 bytes per pixel, read by the lane's own tap
+            const unsigned lbh = lb + (fo >> 1) + (unsigned)G::CQB;   // code plane B: 8 bytes per pixel
+            const unsigned lba1 = lba + hi1, lbaw = lba + hiw, lbh1 = lbh + (hi1 >> 1), lbhw = lbh + (hiw >> 1);
+            const long long wg = pl_uniform(wcb + ws);
+            const long long wn = pl_uniform(lastg ? wnx + wsn : wcb + wsn);  // pair 0 of the next group / of the next chunk's first group
+            const unsigned lbn = lb + fon + khb;
+            static_for<NPAIR>([&](auto q_tag) __attribute__((always_inline)) {
+              constexpr int q = decltype(q_tag)::value;
+              constexpr int ks = q / PR, ta = 2 * (q % PR), tb = ta + 1;
+              constexpr bool hasb = tb < R, lastq = q + 1 == NPAIR;
+              constexpr unsigned pa = (unsigned)((ta / KW) * G::FW + (ta % KW)), pb = (unsigned)((tb / KW) * G::FW + (tb % KW));
+              static_assert(!hasb || pb - pa == 1 || pb - pa == (unsigned)(G::FW - (KW - 1)), "tap b of a pair: next in the row, or first of the next row");
+              constexpr unsigned ob = pb * 16 + ks * G::KSB;  // fp16 fragment of tap b
+              constexpr unsigned oca = pa * 16 + ks * G::PLB, och = pa * 8 + ks * (G::PLB / 2);  // codes of tap a
+              constexpr int nks = (q + 1) / PR, nta = 2 * ((q + 1) % PR);
+              constexpr unsigned ona = (unsigned)(((nta / KW) * G::FW + (nta % KW)) * 16 + nks * G::KSB);
+              constexpr int qf = q + XQD;
+              constexpr bool wrapf = qf >= NPAIR;
+              constexpr int qw = qf - NPAIR;
+              constexpr int qq = !wrapf ? qf : ((XQD == 2 && (NPAIR & 1)) ? 1 - qw : qw);
+              constexpr int fks = qq / PR, fta = 2 * (qq % PR);
+              const long long ne = (wrapf ? wn : wg) + (long long)fks * wq_ks + fta * (3 * 512);  // its record [0]
+              constexpr bool nhasb = fta + 1 < R;
+              constexpr int S = XQD == 2 ? 4 * (q & 1) : 0;  // this pair's ring set
+              // my tap's pixel: tap a + (lanes 32-63 of a full pair) the distance to tap b
+              const unsigned ba = !hasb ? lba : (pb - pa == 1 ? lba1 : lbaw), bh = !hasb ? lbh : (pb - pa == 1 ? lbh1 : lbhw);
+#define CVVAE_CODES(r) CVVAE_PUT6(r, pl_add2x(aoff8[r], ba) + oca, pl_addv(aoff8[r], bh) + och)
+              // Whi.hi of tap a
+#pragma unroll
+              for (int r = 0; r < MREP; ++r) {
+                acc[r] = Tr<T>::mfma(wf[0][S + 0], __builtin_bit_cast(v8, CVVAE_LO4(r)), acc[r]);
+                if (hasb) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbg) + ob);
+                else CVVAE_CODES(r);
+                if (r == MREP - 1) wf[0][S + 0] = CVVAE_LDW(ne);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+              if (hasb) {  // Whi.hi of tap b
+#pragma unroll
+                for (int r = 0; r < MREP; ++r) {
+                  acc[r] = Tr<T>::mfma(wf[0][S + 3], __builtin_bit_cast(v8, CVVAE_LO4(r)), acc[r]);
+                  CVVAE_CODES(r);
+                  if (r == MREP - 1) wf[0][S + 3] = CVVAE_LDW(ne + (nhasb ? 3 * 512 : 0));
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              } else {
+                wf[0][S + 3] = CVVAE_LDW(ne + (nhasb ? 3 * 512 : 0));
+              }
+              // q(Whi).q(lo) + q(Wlo).q(hi) of both taps on the block-scaled bf6 K = 64 MFMA
+#pragma unroll
+              for (int r = 0; r < MREP; ++r) {
+                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), CVVAE_LO4(r), s2[r], p.q6_eb, acc[r]);
+                if (!lastq) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbg) + ona);
+                else if (!lastg) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbn));
+                if (r == MREP - 1) {
+                  wf[0][S + 1] = CVVAE_LDW(ne + 512);
+                  wf[0][S + 2] = CVVAE_LDW(ne + 1024);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            });
+          };
+          if constexpr (TFOLD) {
+            unsigned fo = tf_l0, fon = tf_l1;
+            long long ws = tf_w0, wsn = tf_w1;
+            for (int g = 0; g < ngq; ++g) {
+              const bool lastg = g + 1 == ngq;
+              group_body(fo, ws, fon, lastg ? tf_w0 : wsn, lastg);
+              fo = fon; ws = wsn;
+              fon = tf_l2; wsn = tf_w2;
+            }
+          } else {
+            group_body(0u, 0ll, 0u, 0ll, true);
+          }
+#undef CVVAE_PUT4
+#undef CVVAE_LDW
+#undef CVVAE_PUT6
+#undef CVVAE_LO4
+#undef CVVAE_CODES
+        }
+      } else
       if (active) {
         constexpr int R = KH * KW, PR = (R + 1) / 2, NPAIR = PR * KSUB;
         const unsigned lb = (unsigned)(cur * G::BUFB);

@@ -190,12 +190,26 @@
 #define CVVAE_CONV_XQ(X) CVVAE_CONV_XQ_A(X) CVVAE_CONV_XQ_B(X)
 // Fast-fp32 with fp6 corrections (XP = 3, dtype CVVAE_F32Q6): the GroupNorm + SiLU prologue instances of the list above -- the layers
 // whose operand has a bound the host can derive from the GroupNorm affine (cvvae_conv_desc.act_bound)
-#define CVVAE_CONV_XQ6(X) \
+// The first list: the 256- / 128-pixel tiles of rounds 3-5 (register-staged 80-byte pixel, four fragments per wave), which also
+// serve small frames and the odd-frame sibling launch.  The second list (round 6): the PLANAR layout (conv_kernel.h Geo::PL -- hi
+// planes and code planes in separate LDS regions, 56 bytes per pixel and 16 channels) with EIGHT fragments per wave: the two-frame
+// 512-pixel tile of the 128-channel 3x3x3 layers (+ its one-frame sibling on the old layout), the all-waves-in-N 256-pixel tiles
+// of the 256- / 512-channel 3x3x3 layers, the 16-row tile of the 128-channel per-frame conv.
+#define CVVAE_CONV_XQ6_A(X) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 2,4,32, 8,1,1, 1, 1,0) \
   X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0)
+#define CVVAE_CONV_XQ6_B(X) \
+  X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0)
+// (the all-waves-in-N 256-pixel per-frame tile, X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0), compiles with an accumulator spilled inside
+//  its K loop -- hipcc's allocator fragments the file around the 16-register accumulator tuples -- and is not in the list)
+#define CVVAE_CONV_XQ6_C(X) \
+  X(1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 1,0)
+#define CVVAE_CONV_XQ6(X) CVVAE_CONV_XQ6_A(X) CVVAE_CONV_XQ6_B(X) CVVAE_CONV_XQ6_C(X)
 
 // DMA-staged instances (LD = 1, conv_kernel.h): 16-bit models, PRO = 0 -- the folded upsample convs, the strided downsamplers, the
 // 1x1 layers and the decoder's conv_in as they are, and every other conv when its GroupNorm + SiLU is applied by the pass

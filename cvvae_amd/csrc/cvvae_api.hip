@@ -115,7 +115,12 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
   double cost = (double)tiles * (double)bm * (double)ntn * (double)bn;
   // staging share: halo pixels staged per output pixel, once per N tile (grows as BN shrinks)
   const double halo = (double)((e.tt - 1) * e.st + e.kt) * ((e.th - 1) * e.sh + e.kh) * ((e.tw - 1) * e.sw + e.kw) / (double)bm;
-  cost *= 1.0 + 0.04 * halo * 256.0 / (double)bn;
+  // (fp32 models: staging an element costs about three times as much -- 32-byte loads, the GroupNorm + SiLU in fp32, the hi / lo
+  //  split, the code conversion, three LDS writes.  Measured in round 6: with the planar XQ6 tiles in the list, the 0.04 of the 16-bit
+  //  kernels sent the 256- / 512-channel per-frame convs to the 128-channel 16-row tile -- every halo element staged once per N
+  //  tile, eight fragments per wave -- and they ran 20 % slower than on the all-waves-in-N tile with four)
+  const bool fp32inst = e.fn[CVVAE_F32] || e.fn[CVVAE_F32Q] || e.fn[CVVAE_F32Q6];
+  cost *= 1.0 + (fp32inst ? 0.12 : 0.04) * halo * 256.0 / (double)bn;
   // weight traffic share grows as a weight record feeds fewer MFMAs (pixels per wave = BM / WM)
   cost *= 1.0 + 0.05 * 256.0 / ((double)bm / (double)e.wm);
   if (e.kg == 2) cost *= 1.08;  // accumulator reduction through LDS (three barriers and 64 KiB of LDS traffic per tile)

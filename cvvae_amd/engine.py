@@ -54,9 +54,15 @@ class WeightCache:
     #      leaves `p._version` alone) -- which is exactly how the reference's EMA swaps weights for validation / log_images
     #      (LitEma.copy_to / restore, /root/reference/lvdm/modules/ema.py:61-86).  Three answers, cheapest first:
     #        * invalidate(): drop everything (the caller knows it wrote through .data): `model.refresh_weights()`;
-    #        * guard(): one fused device-side checksum over the masters, compared with the last one -- run by the TRAINING path
-    #          (grad3d.run_trainable) before every taped pass, where a sync per step is free; opt-in for inference (`weight_guard`);
-    #        * nothing, for the inference path's default: its weights come from from_pretrained / load_state_dict.
+    #        * guard(): a fused device-side checksum over the masters (three multi-tensor reductions, ONE host sync), compared with the
+    #          last one.  modeling._Net.forward runs it (a) on the first pass after every train() / eval() transition, and (b) on EVERY
+    #          inference-branch pass (eval() or no_grad) of a network that still has a parameter with requires_grad: LitEma.copy_to /
+    #          restore write exactly those parameters, and the reference's validation_step / log_images run a plain pass FIRST and enter
+    #          ema_scope() afterwards, in the same mode (lvdm/models/autoencoder.py:379-384, 1193, 1426) -- a check on transitions alone
+    #          would hand the EMA pass the live weights' packed forms.  A frozen model (`requires_grad_(False)`: what
+    #          cvvae_inference_video.py:12 does) cannot be written by the EMA and pays no sync per pass; `weight_guard` forces (b);
+    #        * the taped training pass (grad3d.run_trainable) checks on transitions only: optimizer steps move `_version`, and the EMA's
+    #          restore() precedes the train() call that re-arms the check.
     def invalidate(self):
         """forget every packed / converted form (call after writing parameters through `.data`, e.g. an EMA swap)"""
         self._c.clear()
@@ -65,8 +71,9 @@ class WeightCache:
         self._sum = None
 
     def guard(self) -> bool:
-        """compare a checksum (per-tensor L1 and L2 norms, one fused launch each, ONE host sync) of the module's parameters with the
-        one taken at the previous call; on a difference drop every cached form.  Returns True when the cache was dropped."""
+        """compare a checksum (_checksum: three norms per tensor accumulated in fp64, fused multi-tensor launches, ONE host sync) of the module's
+        parameters with the one taken at the previous call; on a difference drop every cached form.  Returns True when the cache was
+        dropped."""
         cur = self._checksum()
         if cur is None:
             return False
@@ -80,11 +87,17 @@ class WeightCache:
         return changed
 
     def _checksum(self) -> Optional[torch.Tensor]:
+        """per tensor: L1 and L2 norms and the L2 norm of (p + 1/2) -- the last one moves under sign flips, which the plain norms are
+        blind to -- all ACCUMULATED IN FP64 whatever the parameters' dtype (in fp16 the L1 norm of a 512 x 512 x 27 conv weight
+        overflows to inf, and inf == inf; a bf16 L2 norm carries 8 bits; an fp32 sum over 7 M elements hides a change of one)"""
         ps = [p.detach() for p in self.m.parameters()]
         if not ps:
             return None
         with torch.no_grad():
-            return torch.stack(list(torch._foreach_norm(ps, 1)) + list(torch._foreach_norm(ps, 2))).double()
+            f64 = torch.float64
+            sums = (list(torch._foreach_norm(ps, 1, dtype=f64)) + list(torch._foreach_norm(ps, 2, dtype=f64)) +
+                    list(torch._foreach_norm(torch._foreach_add(ps, 0.5), 2, dtype=f64)))
+            return torch.stack(sums)
 
     def computing_in(self, dtype: Optional[torch.dtype]):
         """context manager: `compute_dtype` = dtype inside, the previous value afterwards (the dtype is per PASS, not per cache: a

@@ -111,16 +111,20 @@ class _Net(nn.Module):
         # main.py:905-912): the pass runs on 16-bit copies of the weights and returns the autocast dtype, as F.conv3d would
         # (the dtype is set for THIS pass and restored afterwards: WeightCache.computing_in)
         cd = self._pass_dtype(x)
-        if self.weight_guard or self._guard_pending:
-            # parameters written through `.data` (EMA swaps: lvdm/modules/ema.py:61-86) do not move the cache's keys; a device-side
-            # checksum does.  It costs a host sync (measured: the host then trails the GPU for the first ~7 ms of a training step), so
-            # by default it runs ONCE after every train() / eval() transition -- the trainers swap EMA weights between those calls and
-            # the passes (eval() -> copy_to -> validation passes -> restore -> train()) -- and on every pass only with `weight_guard`
+        taped = (self._trainable and self.training and torch.is_grad_enabled()
+                 and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+        # parameters written through `.data` (EMA swaps: lvdm/modules/ema.py:61-86) do not move the cache's keys; a device-side
+        # checksum does.  It costs a host sync (measured: the host then trails the GPU for the first ~7 ms of a training step), so the
+        # TAPED pass runs it once after every train() / eval() transition (restore() precedes train()).  The inference branch -- where
+        # the reference's validation_step / log_images run a plain pass and THEN enter ema_scope() in the same mode
+        # (lvdm/models/autoencoder.py:379-384, 1193, 1426) -- runs it on EVERY pass while any parameter of the network still has
+        # requires_grad, which is exactly the set LitEma.copy_to writes (ema.py:61-68); a frozen model (cvvae_inference_video.py:12:
+        # `vae3d.requires_grad_(False)`) pays nothing.  `weight_guard` forces the per-pass check.
+        if self.weight_guard or self._guard_pending or (not taped and self._ema_writable()):
             object.__setattr__(self, "_guard_pending", False)
             self.refresh_weights(only_if_changed=True)
         with self._cache().computing_in(cd):
-            if (self._trainable and self.training and torch.is_grad_enabled()
-                    and (x.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            if taped:
                 # training the codec itself (lvdm/models/autoencoder.py:1057-1090 runs the 3-D networks under autograd): the same
                 # launches with a tape, two autograd nodes (body + tail) over (x, parameters).  eval() mode / no_grad: the inference pass below
                 from . import grad3d
@@ -133,14 +137,21 @@ class _Net(nn.Module):
     # encoder: latents inside north_star's 1e-3 bound; 16-bit decoder).  None = the parameters' own dtype.
     compute_dtype_override: Optional[torch.dtype] = None
     # every pass re-checks a device-side checksum of the parameters first (one sync per pass) and drops stale packed forms: for
-    # callers that write weights through `.data` at arbitrary moments and cannot call refresh_weights() themselves.  Default: the
-    # check runs once after each train() / eval() transition (see forward).
+    # callers that write FROZEN weights through `.data` at arbitrary moments and cannot call refresh_weights() themselves.  Default:
+    # after each train() / eval() transition, and on every inference-branch pass of a network with trainable parameters (see forward).
     weight_guard: bool = os.environ.get("CVVAE_WEIGHT_GUARD", "0") == "1"
     _guard_pending: bool = False
 
     def train(self, mode: bool = True):
         object.__setattr__(self, "_guard_pending", True)
         return super().train(mode)
+
+    def _ema_writable(self) -> bool:
+        """does any parameter still have requires_grad (what an EMA swap through `.data` can touch)?  Not during a hipGraph capture:
+        the checksum synchronises"""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return False
+        return next((True for p in self.parameters() if p.requires_grad), False)
 
     def _pass_dtype(self, x: torch.Tensor) -> Optional[torch.dtype]:
         if self.conv_in.weight.dtype != torch.float32:

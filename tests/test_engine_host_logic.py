@@ -277,3 +277,41 @@ def test_fp6_form_is_refused_when_the_norm_affine_spreads_over_many_binades():
         assert wc.act_bound(name + ".norm1") == 0.0
         assert wc.conv(name + ".conv1", (3, 3, 3), time_folds=True, act_norm=name + ".norm1").dt == L.F32Q
         m.decode(z)  # and the whole decoder still runs (mixed forms)
+
+
+def test_ema_swap_after_a_plain_pass_in_the_same_mode_is_seen():
+    """The reference's validation_step / log_images run a plain pass and THEN enter ema_scope() without another train() / eval() call
+    (lvdm/models/autoencoder.py:379-384, 1193, 1426); LitEma.copy_to / restore write every parameter with requires_grad through `.data`
+    (lvdm/modules/ema.py:61-86), which does not move `_version`.  The inference branch of a network that still has such parameters
+    therefore re-checks the parameter checksum on EVERY pass; a frozen network (cvvae_inference_video.py:12) is not checked per pass
+    and needs refresh_weights() after a `.data` write."""
+    over = {}
+    m = build("sd3", over, 7)
+    x = seeded_input((1, 3, 5, 32, 32), 3)
+    params = [p for p in m.encoder.parameters() if p.requires_grad]
+    assert params, "a freshly built model is trainable: the EMA can write it"
+    with emu_ops.patched(whole_model=True), torch.no_grad():
+        y_live = m.encoder(x)                      # validation_step: the plain pass (consumes the eval() transition's check)
+        stored = [p.detach().clone() for p in params]
+        for p in params:                           # ema_scope(): LitEma.copy_to
+            p.data.mul_(0.5)
+        v = [p._version for p in params]
+        y_ema = m.encoder(x)                       # the EMA pass, same mode, no refresh_weights() call
+        assert [p._version for p in params] == v
+        assert not torch.equal(y_ema, y_live), "the EMA pass reused the live weights' packed forms"
+        for p, s in zip(params, stored):           # LitEma.restore
+            p.data.copy_(s)
+        assert torch.equal(m.encoder(x), y_live)
+        # the same through a FRESH model that holds the halved weights from the start: what the EMA pass must equal
+        m2 = build("sd3", over, 7)
+        for p in m2.encoder.parameters():
+            p.data.mul_(0.5)
+        m2.encoder.refresh_weights()
+        assert torch.equal(m2.encoder(x), y_ema)
+        # frozen network: no per-pass check (the staleness itself is shown on the device, tests/test_gpu_round5.py: the emulated
+        # packed forms alias the parameters); the checksum still sees the write when asked
+        m.requires_grad_(False)
+        assert not m.encoder._ema_writable()
+        m.encoder(x)
+        m.encoder.conv_in.weight.data.mul_(2.0)
+        assert m.encoder.refresh_weights(only_if_changed=True)

@@ -124,20 +124,22 @@ def test_training_through_the_windowed_and_tiled_wrapper(dtype, recompute):
 
 
 def test_weights_written_through_data_and_refresh_weights():
-    """`p.data.copy_()` (LitEma.copy_to / restore, lvdm/modules/ema.py:61-86) does not move `p._version`: the packed weights go stale
-    until refresh_weights() -- or, opted in, the per-pass checksum guard; the training path always checks"""
+    """`p.data.copy_()` (LitEma.copy_to / restore, lvdm/modules/ema.py:61-86) does not move `p._version`: on a FROZEN network (what
+    cvvae_inference_video.py:12 loads) the packed weights go stale until refresh_weights() -- or, opted in, the per-pass checksum
+    guard; a network with TRAINABLE parameters (the only ones the EMA writes) re-checks the checksum on every inference-branch pass,
+    so the reference's `plain pass, then ema_scope()` sequence inside one eval() window sees the swap (round 6)"""
     import cvvae_amd
     over = dict(block_out_channels=[128, 256, 256], layers_per_block=1)
     m = cvvae_amd.CVVAESD3Model(**over)
     sd = seeded_state_dict({k: v.shape for k, v in m.state_dict().items()}, 3)
     m.load_state_dict(sd, strict=True)
-    m = m.cuda().eval()
+    m = m.cuda().eval().requires_grad_(False)
     x = seeded_input((1, 3, 5, 32, 32), 2).cuda()
     y0 = m.encoder(x)
     w = m.encoder.conv_in.weight
     v0 = w._version
     w.data.mul_(1.5)
-    assert w._version == v0 and torch.equal(m.encoder(x), y0)   # stale, by construction of the key
+    assert w._version == v0 and torch.equal(m.encoder(x), y0)   # stale, by construction of the key (frozen: no per-pass check)
     assert m.refresh_weights()
     y1 = m.encoder(x)
     sd2 = dict(sd, **{"encoder.conv_in.weight": sd["encoder.conv_in.weight"] * 1.5})
@@ -157,14 +159,24 @@ def test_weights_written_through_data_and_refresh_weights():
     assert torch.equal(m.encoder(x), y3) and not torch.equal(y3, y2)
     m.encoder.weight_guard = False
     m.enable_hip_graphs(False)
-    # train() / eval() transitions arm one check: the trainers' EMA swaps sit between a transition and the passes that follow it
+    # ---- a TRAINABLE network: the reference's validation_step (lvdm/models/autoencoder.py:379-384) -- eval(), a plain pass, then
+    #      ema_scope(): copy_to / pass / restore -- with NO train() / eval() call in between
+    m.requires_grad_(True)
     m.train()
     ya = m.encoder(x.clone().requires_grad_(True))
     m.eval()
-    w.data.mul_(2.0)                        # LitEma.copy_to after pl_module.eval()
+    with torch.no_grad():
+        y_live = m.encoder(x)               # the plain pass consumes the transition's check
+        w.data.mul_(2.0)                    # LitEma.copy_to
+        y_ema = m.encoder(x)
+        assert not torch.equal(y_ema, y_live), "the EMA pass reused the live weights' packed forms"
+        w.data.mul_(0.5)                    # LitEma.restore
+        assert torch.equal(m.encoder(x), y_live)
+    assert torch.equal(ya.detach(), y_live)
+    w.data.mul_(2.0)                        # (swap again; restore precedes pl_module.train())
     yv = m.encoder(x)
-    assert not torch.equal(ya.detach(), yv)
-    w.data.mul_(0.5)                        # LitEma.restore, then pl_module.train()
+    assert torch.equal(yv, y_ema)
+    w.data.mul_(0.5)
     m.train()
     yb = m.encoder(x.clone().requires_grad_(True))
     assert torch.equal(ya.detach(), yb.detach())
@@ -172,6 +184,26 @@ def test_weights_written_through_data_and_refresh_weights():
         w.mul_(1.01)
     with pytest.raises(RuntimeError, match="modified"):
         yb.sum().backward()
+
+
+def test_parameter_checksum_is_accumulated_in_fp64_and_sees_sign_flips():
+    """WeightCache._checksum: an fp16 L1 norm of a large conv weight overflows to inf (inf == inf), a 16-bit L2 norm
+    carries 8-11 bits, an fp32 sum over millions of elements hides a change of one, and the plain norms are blind to sign flips"""
+    from cvvae_amd import engine
+    lin = torch.nn.Conv3d(512, 512, 3).half().cuda()
+    with torch.no_grad():
+        lin.weight.fill_(0.02)
+    wc = engine.WeightCache(lin)
+    c0 = wc._checksum()
+    assert bool(torch.isfinite(c0).all())
+    with torch.no_grad():
+        lin.weight.view(-1)[12345] *= -1.0            # a sign flip: same L1 and L2 norms
+    c1 = wc._checksum()
+    assert not torch.equal(c0, c1)
+    with torch.no_grad():
+        lin.weight.view(-1)[12345] *= -1.0
+        lin.weight.view(-1)[777] += 0.002             # an EMA-sized change of ONE element of 7 M
+    assert not torch.equal(wc._checksum(), c0)
 
 
 @pytest.mark.parametrize("name", ["cfg1_vae3d_t1_256", "cfg2_vae3d_t17_256", "cfg3_sd3_t17_512"])

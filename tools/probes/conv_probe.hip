@@ -46,6 +46,18 @@ static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
 #define INST 3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0
 #define XPV 1
 static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 15 // enc128 fast fp32, fp6 corrections, PLANAR layout + eight fragments per wave (round 6: Geo::PL)
+#define INST 3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0
+#define XPV 3
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 16 // ... WITHOUT prologue (no GroupNorm + SiLU arithmetic; the hi / lo split and the bf6 conversion remain)
+#define INST 3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 0,0
+#define XPV 3
+static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 2;
+#elif CFG == 17 // enc256 fast fp32, fp6 corrections, planar, all waves in N
+#define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0
+#define XPV 3
+static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
 #elif CFG == 4 // c2d512
 #define INST 1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0
 static const int CIN = 512, COUT = 512, TT_ = 9, HH = 128, WW = 128, PT = 0;
