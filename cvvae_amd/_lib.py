@@ -12,7 +12,7 @@ F16, BF16, F32, F32Q, F32Q6 = 0, 1, 2, 3, 4
 PAD_ZERO, PAD_REPLICATE = 0, 1
 PRO_NONE, PRO_GN_SILU, PRO_GN = 0, 1, 2
 OUT_NDHWC, OUT_NCDHW, OUT_TIME_SHUFFLE = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 
 class ConvDesc(ctypes.Structure):
@@ -39,6 +39,7 @@ class ConvDesc(ctypes.Structure):
         ("sc_Cin", ctypes.c_int32), ("w_time_folds", ctypes.c_int32),
         ("sc_in_pix_stride", ctypes.c_int64),
         ("in_overlap", ctypes.c_int32), ("act_bound", ctypes.c_float),
+        ("four_wave", ctypes.c_int32),
     ]
 
 
@@ -56,7 +57,6 @@ PROTOTYPES = {
     "cvvae_pack_weights_fold": (_i32, [_i32, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i32, _i32, _vp, _vp]),
     "cvvae_conv_fwd": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "cvvae_conv_kernel_name": (ctypes.c_char_p, [ctypes.POINTER(ConvDesc)]),
-    "cvvae_conv_set_four_wave": (_i32, [ctypes.c_double]),
     "cvvae_conv_gn_slabs": (_i64, [ctypes.POINTER(ConvDesc), _i32]),
     "cvvae_conv_fwd_gn": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "cvvae_conv_fwd_gn_sc": (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp, _vp]),

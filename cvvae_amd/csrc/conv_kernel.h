@@ -182,6 +182,13 @@ struct ConvArgs {
 #define CVVAE_PROBE_MARK() do { } while (0)
 #endif
 
+// Ablation builds (scratch libraries loaded through CVVAE_LIB; results meaningless, times not -- the method of round 5's weight-gradient
+// work): -DCVVAE_ABLATE_STAGE=1 stages every other pass of the register-staged halo (HALF the loads, the GroupNorm + SiLU arithmetic
+// and the LDS writes: what a kernel that re-uses two of three halo frames across time steps would still have to do), =2 stages
+// chunk 0 only (no staging at all inside the K loop).  An upper bound on what any scheme that cuts the staging can buy (round 6).
+#ifndef CVVAE_ABLATE_STAGE
+#define CVVAE_ABLATE_STAGE 0
+#endif
 #ifndef CVVAE_LD_PF
 #define CVVAE_LD_PF 0  // tuning aid: weight-ring depth of the DMA-staged instances (0: as deep as divides the time group)
 #endif
@@ -667,6 +674,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
         //  block with the same pass's block of the processing loop below: load, wait, GroupNorm arithmetic, next load ... -- one
         //  exposed memory latency per pass; in-kernel stamps: 7-10 k cycles "issuing" six passes against 0.9 k in the 16-bit kernel,
         //  profiles/r6_probe_fast_fp32_timelines.log)
+        if (CVVAE_ABLATE_STAGE == 1 && (k & 1)) continue;
         if (k < NPASS && (XP >= 2 || ((passmask >> k) & 1))) {
           // unconditional load (slot 0 of the tensor for padding / foreign slots) keeps the loads branch-free
           const int sp = srcpix[k] < 0 ? 0 : srcpix[k];
@@ -691,6 +699,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
       for (int kk = 0; kk < SB; ++kk) {
         const int k = k0 + kk;
+        if (CVVAE_ABLATE_STAGE == 1 && (k & 1)) continue;
         if (k < NPASS && ((passmask >> k) & 1)) {
           if (srcpix[k] == -2) continue;
           if constexpr (XP != 0) {  // fp32 source -> (GroupNorm affine, SiLU in fp32) -> hi = fp16(x), lo = fp16(x - hi)
@@ -773,6 +782,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
     }
   };
   auto stage = [&](int chunk, int bufsel) {
+    if (CVVAE_ABLATE_STAGE == 2 && chunk != 0) return;
     stage_from(std::integral_constant<int, PRO>{}, inp, (size_t)p.in_ps, chunk, bufsel);
   };
 

@@ -85,11 +85,13 @@
 // FOUR-wave instances (WM x WN x KG = 4: 256 threads, <= 80 KiB of LDS, two workgroups resident per CU) for the 128-channel
 // layers at full resolution, whose staging VALU work (GroupNorm + SiLU of every halo element for only 128 output channels) and store
 // tail are too large a share of a tile to hide inside one workgroup: see conv_kernel.h (NWV) and DESIGN.md section 3.1.
-// The per-frame instance (+6 % on the ResnetBlock conv2 of the 128-channel level) is BUILT, and selected only after the host's
-// self-check on the device at hand (cvvae_conv_set_four_wave; engine.four_wave_selfcheck): round 2 saw about one fused GroupNorm
-// record in 10^4 come out wrong with two workgroups co-resident on one box of the pool, round 3 could not reproduce it on four
-// others (150 repetitions each) -- a box-dependent fault is what a per-device check at load time is for.  The two 3x3x3 forms were
-// slower than the 8-wave two-frame tile (-4 %) and stay behind make NW4=1.
+// The per-frame instance (+6 % on the ResnetBlock conv2 of the 128-channel level) is built, and a candidate of the instance choice when
+// the launch's descriptor says so (cvvae_conv_desc.four_wave; the Python layer sets it unless CVVAE_FOUR_WAVE=0).  History: round 2
+// saw about one fused GroupNorm record in 10^4 come out wrong with two workgroups co-resident on one box of the pool; rounds 3-6
+// could not reproduce it on any other box with either tree (150-repetition stresses, tools/probes/nw4_stress.py; the per-device
+// self-check of round 5 never failed) -- the bit-for-bit repetition check now runs as a GPU TEST
+// (tests/test_gpu_round6.py::test_four_wave_records_are_reproducible_under_co_residency), not at model load.  The two 3x3x3 forms
+// were slower than the 8-wave two-frame tile (-4 %) and stay behind make NW4=1.
 #ifdef CVVAE_BUILD_NW4
 #define CVVAE_CONV_G11(X) \
   X(1,3,3, 1,1,1, 1,8,32, 1,4,1, 2, 1,0) \
@@ -194,7 +196,7 @@
 // serve small frames and the odd-frame sibling launch.  The second list (round 6): the PLANAR layout (conv_kernel.h Geo::PL -- hi
 // planes and code planes in separate LDS regions, 56 bytes per pixel and 16 channels) with EIGHT fragments per wave: the two-frame
 // 512-pixel tile of the 128-channel 3x3x3 layers (+ its one-frame sibling on the old layout), the all-waves-in-N 256-pixel tiles
-// of the 256- / 512-channel 3x3x3 layers, the 16-row tile of the 128-channel per-frame conv.
+// of the 256- / 512-channel 3x3x3 layers.
 #define CVVAE_CONV_XQ6_A(X) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0) \
@@ -205,11 +207,12 @@
   X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0)
-// (the all-waves-in-N 256-pixel per-frame tile, X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0), compiles with an accumulator spilled inside
-//  its K loop -- hipcc's allocator fragments the file around the 16-register accumulator tuples -- and is not in the list)
-#define CVVAE_CONV_XQ6_C(X) \
-  X(1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 1,0)
-#define CVVAE_CONV_XQ6(X) CVVAE_CONV_XQ6_A(X) CVVAE_CONV_XQ6_B(X) CVVAE_CONV_XQ6_C(X)
+// (per-frame planar tiles were built and measured too: the 16-row tile of the 128-channel conv2 layers, X(1,3,3, 1,1,1, 1,16,32,
+//  2,4,1, 2, 1,0): 3.40 vs 3.14 ms for the 8-row four-fragment tile at 17x512^2 with residual + statistics -- its K loop is short
+//  (10 pairs of taps per chunk) and the longer store tail of a 512-pixel tile is exposed; the all-waves-in-N 256-pixel tile,
+//  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0), compiles with an accumulator spilled inside its K loop.  Neither is in the list;
+//  profiles/r6_ab_planar_fast_fp32_v2.log)
+#define CVVAE_CONV_XQ6(X) CVVAE_CONV_XQ6_A(X) CVVAE_CONV_XQ6_B(X)
 
 // DMA-staged instances (LD = 1, conv_kernel.h): 16-bit models, PRO = 0 -- the folded upsample convs, the strided downsamplers, the
 // 1x1 layers and the decoder's conv_in as they are, and every other conv when its GroupNorm + SiLU is applied by the pass

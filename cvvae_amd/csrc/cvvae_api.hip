@@ -84,9 +84,6 @@ static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
 
-// cost factor of the four-wave instances (0: not selected), set by cvvae_conv_set_four_wave
-static double g_four_wave_factor = 0.0;
-
 // compute units of the current device (256 on MI355X); used by the instance cost model only
 static int cu_count() {
   static int cus = 0;
@@ -133,12 +130,12 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
     static const double nb2 = getenv("CVVAE_CONV_NB2") ? atof(getenv("CVVAE_CONV_NB2")) : 1.0;
     cost *= nb2;
   }
-  // four-wave instances (two workgroups per CU): selected only after cvvae_conv_set_four_wave(factor > 0) -- the host calls it when
-  // its self-check on this device came back clean (engine.four_wave_selfcheck: +6 % on the per-frame 128-channel conv with residual
-  // + statistics, 1.71 -> 1.62 ms at 17x512^2; profiles/r2_ab_4wave_*.log).  CVVAE_CONV_NW4=<factor> overrides (tuning / debugging aid).
+  // four-wave instances (two workgroups per CU): candidates only when the DESCRIPTOR says so (cvvae_conv_desc.four_wave, ABI 13: a
+  // per-launch field, no library state) -- +6 % on the per-frame 128-channel conv with residual + statistics, 1.71 -> 1.62 ms at
+  // 17x512^2 (profiles/r2_ab_4wave_*.log, r5_ab_four_wave.log).  CVVAE_CONV_NW4=<factor> overrides the cost factor (tuning aid).
   if (e.wm * e.wn * e.kg == 4) {
     static const double nw4_env = getenv("CVVAE_CONV_NW4") ? atof(getenv("CVVAE_CONV_NW4")) : -1.0;
-    const double nw4 = nw4_env >= 0.0 ? nw4_env : g_four_wave_factor;
+    const double nw4 = nw4_env >= 0.0 ? nw4_env : (d->four_wave ? 0.95 : 0.0);
     cost *= nw4 > 0.0 ? nw4 : 100.0;
   }
   // strided convs do 4-8x fewer MFMAs per staged byte and their halos (430 KiB per workgroup at 128 channels) do not survive in
@@ -287,6 +284,7 @@ static int check_desc(const cvvae_conv_desc* d) {
     return CVVAE_EUNSUPPORTED;
   if (d->gn_rows_per_batch < 1) return CVVAE_EINVAL;
   if (d->gn_rows_per_batch > 1 && (d->kT != 1 || d->gn_rows_per_batch != d->Ti)) return CVVAE_EINVAL;
+  if (d->four_wave != 0 && d->four_wave != 1) return CVVAE_EINVAL;
   if ((long long)d->B * d->Ti * d->Hi * d->Wi >= (1LL << 31)) return CVVAE_EUNSUPPORTED;
   if ((long long)d->B * (2LL * d->To) * d->Ho * d->Wo >= (1LL << 31)) return CVVAE_EUNSUPPORTED;  // 32-bit pixel indices
   return CVVAE_OK;
@@ -297,12 +295,6 @@ static int check_desc(const cvvae_conv_desc* d) {
 using namespace cvvae;
 
 extern "C" {
-
-int cvvae_conv_set_four_wave(double factor) {
-  if (!(factor >= 0.0) || factor > 100.0) return CVVAE_EINVAL;
-  g_four_wave_factor = factor;
-  return CVVAE_OK;
-}
 
 const char* cvvae_conv_kernel_name(const cvvae_conv_desc* d) {
   if (check_desc(d) != CVVAE_OK) return nullptr;

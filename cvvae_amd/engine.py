@@ -383,7 +383,7 @@ def switches_key(wc=None) -> tuple:
     so that flipping one in a live process re-captures instead of replaying the other setting's graph"""
     return (fold_upsample(), fold_t1(), fuse_shortcut(), fold_time(), rowpack_conv_in(), tapsn_conv_out(), fused_attention(),
             per_frame_stats_from_records(), os.environ.get("CVVAE_PREPASS", "auto"), os.environ.get("CVVAE_CONV_FORCE", ""),
-            tuple(sorted(_FOUR_WAVE.items())), None if wc is None else (wc.fast, wc.fast6, wc.fp6_bound_cap, str(wc.compute_dtype)))
+            ops.four_wave(), None if wc is None else (wc.fast, wc.fast6, wc.fp6_bound_cap, str(wc.compute_dtype)))
 
 
 def fold_upsample() -> bool:
@@ -449,93 +449,8 @@ def _cout(wc: "WeightCache", pre: str) -> int:
     return int(wc.p(pre + ".weight").shape[0])
 
 
-# ---- four-wave conv instances (two workgroups resident per CU; csrc/conv_table.h G11): +6 % on the per-frame 128-channel conv of the
-#      top level (ResnetBlock conv2 with residual + fused statistics).  Round 2 saw irreproducible GroupNorm records from them on one
-#      box of the pool -- about one record in 10^4, only with two workgroups co-resident, stored outputs always right -- and round 3
-#      could not reproduce it on four other boxes.  They are therefore switched on per PROCESS only after this check on the device at
-#      hand: the cfg-3-shaped launch (every CU double-occupied for several rounds) repeated, every record and every output compared bit
-#      for bit between the repetitions, the finalized tables against the 8-wave instance's.  A box that fails keeps the 8-wave
-#      instances and says so once.  CVVAE_FOUR_WAVE=0 skips check and instances, =1 forces them on without the check (tuning aid).
-_FOUR_WAVE: Dict[int, bool] = {}
-FOUR_WAVE_FACTOR = 0.95
-
-
-def four_wave_selfcheck(device: torch.device, dtype: torch.dtype, reps: int = 6) -> bool:
-    """run the check described above on `device` (current stream; ~30 ms, ~1 GB of transient memory) -> clean?"""
-    lib = L.load()
-    with torch.cuda.device(device):
-        g = torch.Generator(device=device).manual_seed(4)
-        shape = (1, 4, 512, 512, 128)
-        x = torch.randn(shape, generator=g, device=device, dtype=torch.float32).to(dtype)
-        res = torch.randn(shape, generator=g, device=device, dtype=torch.float32).to(dtype)
-        gsc = 1.0 + 0.1 * torch.randn((1, 128), generator=g, device=device)
-        gsh = 0.1 * torch.randn((1, 128), generator=g, device=device)
-        w = (torch.randn((128, 128, 9), generator=g, device=device) / (128 * 9) ** 0.5).to(dtype)
-        pw = ops.pack_weight(w, torch.zeros(128, device=device), (1, 3, 3))
-        kw = dict(pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=(gsc.contiguous(), gsh.contiguous()), residual=res, gn_out=G32)
-        one, zero = torch.ones(128, device=device), torch.zeros(128, device=device)
-        try:
-            L.check(lib.cvvae_conv_set_four_wave(0.0), "cvvae_conv_set_four_wave")
-            y8, p8 = ops.conv(x, pw, **kw)
-            t8 = ops.gn_finalize(p8, one, zero, 1e-6)
-            L.check(lib.cvvae_conv_set_four_wave(0.01), "cvvae_conv_set_four_wave")  # (forced: far below every other cost)
-            names = []
-            prev = ops.PROFILE
-
-            def obs(d, pw_, launch):
-                names.append(ops.conv_kernel_name(d))
-                launch()
-            ops.PROFILE = obs
-            try:
-                y4, p4 = ops.conv(x, pw, **kw)
-            finally:
-                ops.PROFILE = prev
-            if not names or "w1x4x1" not in (names[-1] or ""):
-                return False  # (the instance is not in this build)
-            ok = True
-            for _ in range(reps):
-                yr, pr = ops.conv(x, pw, **kw)
-                ok = ok and bool(torch.equal(pr.buf, p4.buf)) and bool(torch.equal(yr, y4))
-            t4 = ops.gn_finalize(p4, one, zero, 1e-6)
-            ok = ok and bool(torch.allclose(t4[0], t8[0], rtol=2e-5)) and bool(torch.allclose(t4[1], t8[1], rtol=2e-5, atol=2e-6))
-            ok = ok and float((y4.float() - y8.float()).abs().max()) <= (2.0 ** -4 if dtype == torch.bfloat16 else 2.0 ** -7)
-            return ok
-        finally:
-            lib.cvvae_conv_set_four_wave(0.0)
-
-
-def four_wave_ready(x: torch.Tensor) -> bool:
-    """decide once per device whether the four-wave instances may be selected (and tell the library); False during a hipGraph capture
-    of a device that has not been checked yet (the check synchronises)"""
-    idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
-    hit = _FOUR_WAVE.get(idx)
-    if hit is None:
-        mode = os.environ.get("CVVAE_FOUR_WAVE", "check")
-        if mode == "check" and "CVVAE_CONV_TUNE_NOSTATS" in os.environ:
-            mode = "0"  # (tools/tune_instances.py launches without statistics records: nothing to check them against)
-        if mode == "0":
-            hit = False
-        elif mode == "1":
-            hit = True
-        else:
-            if torch.cuda.is_current_stream_capturing():
-                return False
-            hit = four_wave_selfcheck(x.device, x.dtype)
-            if not hit:
-                import warnings
-                warnings.warn(f"cvvae_amd: the four-wave conv instances failed their self-check on device {idx} "
-                              f"({torch.cuda.get_device_name(idx)}): irreproducible or deviating GroupNorm records with two workgroups per "
-                              f"CU.  The 8-wave instances are used (about 0.7 % slower on 512x512 clips); please report the device.")
-        _FOUR_WAVE[idx] = hit
-        # process-wide switch: on only while every device seen so far is clean
-        L.check(L.load().cvvae_conv_set_four_wave(FOUR_WAVE_FACTOR if all(_FOUR_WAVE.values()) else 0.0), "cvvae_conv_set_four_wave")
-    return hit
-
-
 def resnet_tail(wc: WeightCache, x: torch.Tensor, h: torch.Tensor, pre: str, sc_name: str, g2, want_stats: bool):
     """conv2 (per-frame 3x3 over GN+SiLU(h), zero pad) + shortcut(x) + add -- vae_blocks3d_sd3.py:559-567, vae_models.py:404-410."""
-    if h.dtype != torch.float32 and h.shape[-1] == 128 and h.is_cuda:
-        four_wave_ready(h)  # (first 128-channel per-frame conv on this device: the four-wave self-check; a dictionary lookup afterwards)
     fused = _fused_prologue(h, (1, 3, 3), _cout(wc, pre + ".conv2"))
     pw2 = wc.conv(pre + ".conv2", (1, 3, 3), act_norm=pre + ".norm2" if fused else None)
     kw = dict(pad=P2D, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=g2, gn_out=G32 if want_stats else 0)

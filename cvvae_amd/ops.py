@@ -5,6 +5,8 @@ dtype torch.float16 or torch.bfloat16, on a ROCm device.  Nothing here computes 
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib as L
@@ -364,6 +366,7 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.alpha = alpha / pw.wscale
     d.w_batch_stride = pw.batch_stride
     d.w_time_folds = 1 if pw.time_folds else 0
+    d.four_wave = 1 if four_wave() else 0
     if shortcut is not None:
         x2, pw2 = shortcut
         assert residual is None and x2.shape[:4] == x.shape[:4] and x2.is_contiguous() and x2.dtype == x.dtype
@@ -447,6 +450,15 @@ def gn_finalize(part: GNPartials, gamma: torch.Tensor, beta: torch.Tensor, eps: 
 # Optional launch observer used by bench.py's roofline pass: called as PROFILE(desc, packed, launch) where launch()
 # performs the kernel launch on the current stream.  None (the default) = launch directly.
 PROFILE = None
+
+
+def four_wave() -> bool:
+    """are the four-wave conv instances (two workgroups resident per CU; csrc/conv_table.h G11) candidates of a launch's instance
+    choice?  A per-launch descriptor field (cvvae_conv_desc.four_wave, ABI 13): the library keeps no state.  On unless
+    CVVAE_FOUR_WAVE=0 (read per call: the GPU tests flip it inside one process).  +6 % on the per-frame 128-channel conv at full
+    resolution; their fused GroupNorm records are checked bit for bit under co-residency by
+    tests/test_gpu_round6.py::test_four_wave_records_are_reproducible_under_co_residency and tools/probes/nw4_stress.py."""
+    return os.environ.get("CVVAE_FOUR_WAVE", "1") != "0"
 
 
 def conv_kernel_name(d: "L.ConvDesc") -> Optional[str]:

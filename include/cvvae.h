@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define CVVAE_ABI_VERSION 12
+#define CVVAE_ABI_VERSION 13
 
 /* cvvae dtype.  CVVAE_F32 = the reference's fp32 model path (from_pretrained without torch_dtype, models/modeling_vae.py:41-42
  * force_upcast): activations, residuals, outputs and the source weights are float; the kernels split every fp32 operand into
@@ -116,6 +116,11 @@ typedef struct cvvae_conv_desc {
    * padded 3 -> 16, and a 36 MB instead of a 142 MB input at 17 x 512^2.  The buffer must stay readable 32 bytes past its end. */
   int32_t in_overlap;
   float act_bound;            /* CVVAE_F32Q6 only: upper bound (> 0) of |operand| after the prologue; 0 otherwise */
+  /* (ABI 13) 1: the four-wave conv instances (two workgroups resident per CU; csrc/conv_table.h G11) are candidates of the instance
+   * choice for this launch, 0: they are not.  A per-launch field -- the library keeps NO state between calls (until ABI 12 this was a
+   * process-wide switch, cvvae_conv_set_four_wave).  cvvae_conv_gn_slabs, cvvae_conv_kernel_name and the launch must see the same
+   * value: the instance fixes the layout of the fused GroupNorm records. */
+  int32_t four_wave;
 } cvvae_conv_desc;
 
 /* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */
@@ -418,12 +423,6 @@ int cvvae_ncdhw_to_frames_u8(int32_t dtype, const void* in, int64_t thw, uint8_t
  * rows = B*C*T.  a is [rows][Ha][Wa], b is [rows][Hb][Wb]. */
 int cvvae_blend(int32_t dtype, const void* a, int32_t Ha, int32_t Wa, void* b, int32_t Hb, int32_t Wb, int64_t rows,
                 int32_t overlap, int32_t axis, void* stream);
-
-/* Process-wide switch of the four-wave conv instances (two workgroups resident per CU; csrc/conv_table.h G11): factor > 0 makes them
- * eligible with their cost scaled by `factor` (the host passes ~0.95 after its per-device self-check, cvvae_amd/engine.py
- * four_wave_selfcheck), 0 takes them out (the default).  Not a per-launch argument: the choice of instance fixes the layout of the
- * fused GroupNorm records, so it must not change between cvvae_conv_gn_slabs and the launch.  No reference counterpart. */
-int cvvae_conv_set_four_wave(double factor);
 
 int cvvae_abi_version(void);
 /* name of the kernel instance cvvae_conv_fwd would launch for d (for profiling reports); NULL if unsupported */

@@ -29,8 +29,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from cvvae_amd import _lib
-    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, 2 x i32 + f32 = 160 bytes (ABI 10: the struct is unchanged since 9)
-    assert ctypes.sizeof(_lib.ConvDesc) == 160 and _lib.ConvDesc.w_batch_stride.offset == 128
+    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, i32 + f32, i32 (+pad) = 168 bytes
+    # (ABI 13: `four_wave` appended; everything before it where it was since ABI 9)
+    assert ctypes.sizeof(_lib.ConvDesc) == 168 and _lib.ConvDesc.w_batch_stride.offset == 128
+    assert _lib.ConvDesc.four_wave.offset == 160
     assert _lib.ConvDesc.in_overlap.offset == 152 and _lib.ConvDesc.act_bound.offset == 156
     assert _lib.ConvDesc.sc_Cin.offset == 136 and _lib.ConvDesc.sc_in_pix_stride.offset == 144
     assert _lib.ConvDesc.in_pix_stride.offset == 24 and _lib.ConvDesc.out_pix_stride.offset == 112

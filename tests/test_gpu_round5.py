@@ -386,55 +386,6 @@ def test_whole_model_is_bit_identical_with_and_without_dma_staging():
             os.environ["CVVAE_PREPASS"] = old
 
 
-def test_four_wave_selfcheck_and_switch():
-    """the four-wave (two workgroups per CU) per-frame instance is selected only after the per-device self-check: the check runs,
-    its verdict reaches the library's switch, the selected kernel follows it, and a model pass gives the same latents either way to
-    the last-bit rounding of the residual pre-accumulation"""
-    import cvvae_amd
-    from cvvae_amd import _lib as L
-    from cvvae_amd import engine, ops
-    from tests.test_gpu_round2 import L_desc_name
-    lib = L.load()
-    dev = torch.device("cuda", torch.cuda.current_device())
-    verdict = engine.four_wave_selfcheck(dev, torch.bfloat16)
-    _log(f"[four-wave self-check] device {torch.cuda.get_device_name(dev)}: {'clean' if verdict else 'FAILED'}")
-    assert isinstance(verdict, bool)
-    try:
-        L.check(lib.cvvae_conv_set_four_wave(0.0), "set")
-        assert "w2x4x1" in L_desc_name(ops, torch.bfloat16)
-        L.check(lib.cvvae_conv_set_four_wave(engine.FOUR_WAVE_FACTOR), "set")
-        d = L.ConvDesc()
-        d.dtype = ops._dt(torch.bfloat16)
-        d.B, d.Ti, d.Hi, d.Wi, d.Cin, d.in_pix_stride = 1, 17, 512, 512, 128, 128
-        d.kT, d.kH, d.kW, d.sT, d.sH, d.sW = 1, 3, 3, 1, 1, 1
-        d.pad_t, d.pad_h, d.pad_w, d.prologue, d.gn_rows_per_batch = 0, 1, 1, 1, 1
-        d.To, d.Ho, d.Wo, d.Cout, d.out_pix_stride, d.alpha = 17, 512, 512, 128, 128, 1.0
-        assert "w1x4x1" in ops.conv_kernel_name(d), ops.conv_kernel_name(d)
-        assert lib.cvvae_conv_set_four_wave(-1.0) < 0  # CVVAE_EINVAL
-    finally:
-        engine._FOUR_WAVE.clear()
-        lib.cvvae_conv_set_four_wave(0.0)
-    m = cvvae_amd.CVVAESD3Model()
-    P.load_seeded(m, 0)
-    m = m.to(torch.bfloat16).cuda().eval()
-    x = seeded_input((1, 3, 5, 128, 128), 3).to(torch.bfloat16).cuda()
-    old = os.environ.get("CVVAE_FOUR_WAVE")
-    try:
-        os.environ["CVVAE_FOUR_WAVE"] = "0"
-        z0 = m.encode(x).latent_dist.mode()
-        engine._FOUR_WAVE.clear()
-        os.environ["CVVAE_FOUR_WAVE"] = "1"
-        z1 = m.encode(x).latent_dist.mode()
-    finally:
-        engine._FOUR_WAVE.clear()
-        lib.cvvae_conv_set_four_wave(0.0)
-        if old is None:
-            os.environ.pop("CVVAE_FOUR_WAVE", None)
-        else:
-            os.environ["CVVAE_FOUR_WAVE"] = old
-    assert float((z0.float() - z1.float()).abs().max()) <= 0.05
-
-
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bfloat16", "float16"])
 def test_weight_gradient_scalar_base_form_equals_the_per_lane_form(dtype, monkeypatch):
