@@ -21,8 +21,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DT = [torch.float32, torch.float16, torch.bfloat16]
 # relative L2 bands: (forward output, dL/d input, worst parameter tensor).  fp32 models run the split-precision kernels; the 16-bit
-# figures are the storage rounding of weights, activations and gradients through 60-90 layers against the reference's fp32 run
-GRAD_TOL = {torch.float32: (1e-4, 2e-3, 3e-3), torch.float16: (5e-3, 3e-2, 4e-2), torch.bfloat16: (4e-2, 1.5e-1, 2e-1)}
+# figures are the storage rounding of weights, activations and gradients through 60-90 layers against the reference's fp32 run.
+# Round 6: 1.5 x the LARGEST figure measured over both families and both networks (profiles/r5_parity_backward_both_families.log:
+# fp32 6.2e-6 / 1.3e-5 / 1.1e-3, fp16 2.6e-3 / 4.3e-3 / 4.9e-3, bf16 2.1e-2 / 3.5e-2 / 4.0e-2) -- the round-5 bands were 4-5 x the
+# measured 16-bit figures, so a regression of 3 x would have passed
+GRAD_TOL = {torch.float32: (1e-5, 2e-5, 1.7e-3), torch.float16: (3.9e-3, 6.5e-3, 7.4e-3), torch.bfloat16: (3.1e-2, 5.2e-2, 6.1e-2)}
 
 
 def _log(line):

@@ -15,7 +15,7 @@ ap.add_argument("--shape", default="1,3,17,512,512")
 a = ap.parse_args()
 torch.manual_seed(0)
 dtype = torch.bfloat16
-vae = (cvvae_amd.CVVAESD3Model if a.family == "sd3" else cvvae_amd.CVVAEModel)().to(dtype).cuda().eval()
+vae = (cvvae_amd.CVVAESD3Model if a.family == "sd3" else cvvae_amd.CVVAEModel)().to(dtype).cuda().eval().requires_grad_(False)
 x = (torch.rand(tuple(int(v) for v in a.shape.split(","))) * 2 - 1).to(dtype).cuda()
 rec = []
 
