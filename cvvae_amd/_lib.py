@@ -40,6 +40,7 @@ class ConvDesc(ctypes.Structure):
         ("sc_in_pix_stride", ctypes.c_int64),
         ("in_overlap", ctypes.c_int32), ("act_bound", ctypes.c_float),
         ("four_wave", ctypes.c_int32),
+        ("act_bound_dev", ctypes.c_void_p),
     ]
 
 

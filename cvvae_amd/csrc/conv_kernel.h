@@ -164,6 +164,9 @@ struct ConvArgs {
   // XP == 3 (fp6 corrections): the activations' static power-of-two scale -- codes = value / q6_scale, MFMA scale byte q6_eb
   float q6_scale;
   int q6_eb;
+  // ... or, when the bound is only known on the device (cvvae_conv_desc.act_bound_dev: an operand without a GroupNorm in front, whose
+  // bound is a reduction the producer's stream computes), the kernel derives both from *q6_bound itself
+  const float* q6_bound;
   int probe_nostore;  // probe builds (-DCVVAE_CONV_PROBE) only: run the store tail without its stores
   int stats_noshift;  // debug aid (CVVAE_STATS_NOSHIFT=1): fused statistics as plain sums (shift K = 0)
   int ws_window;      // UPS == 2: weight-stationary window of the tile order (tile_map.h), 0 / 1 = off
@@ -260,7 +263,10 @@ struct Geo {
   static constexpr int NAB = MREP >= 8 ? 1 : 2;
   // (PL: fp32 loads are eight registers per pass beside 128 accumulators, the weight ring and the 16 GroupNorm terms: half the
   //  passes per batch, or the staging spills its LDS addresses and reloads them -- with a full wait -- per item)
-  static constexpr int SBATCH = PL ? (NPASS + 1) / 2
+#ifndef CVVAE_PL_SBATCH_FULL
+#define CVVAE_PL_SBATCH_FULL 0  // tuning aid: all staging passes of a planar tile in one batch
+#endif
+  static constexpr int SBATCH = (PL && !CVVAE_PL_SBATCH_FULL) ? (NPASS + 1) / 2
                                    : (NAB == 1 && NPASS <= 6) ? NPASS : (NPASS <= 4 ? NPASS : (NPASS <= 8 ? (NPASS + 1) / 2 : 4));
   static constexpr int STEPS = NTAPS * KSUB * XPM;   // k16 steps per chunk, ordered ks-major: st = (ks * NTAPS + tap) * XPM + part
   static constexpr int STEPS_W = STEPS / KG;   // steps one wave executes per chunk (K-group g takes ks in [g*KSUB/KG, ..))
@@ -452,6 +458,20 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int grp = NWV == 4 ? 0 : wave >> 2;  // 0: stage-then-compute, 1: compute-then-stage
+  // XP == 3: the activations' power-of-two scale (codes = value / q6_scale) and its E8M0 byte -- from the host's bound (ConvArgs), or
+  // from a bound the device holds: floor(log2(28 / bound)) is the exponent field of the quotient (the host does the same with frexpf)
+  float q6_scale = p.q6_scale;
+  int q6_eb = p.q6_eb;
+  if constexpr (XP == 3) {
+    if (p.q6_bound != nullptr) {
+      const float bnd = *p.q6_bound;
+      const float v = 28.0f / (bnd > 1.0e-30f ? bnd : 1.0e-30f);
+      int sft = (int)((__float_as_uint(v) >> 23) & 0xffu) - 127;
+      sft = sft < -100 ? -100 : (sft > 100 ? 100 : sft);
+      q6_eb = __builtin_amdgcn_readfirstlane(127 - sft);
+      q6_scale = __uint_as_float((unsigned)q6_eb << 23);  // 2^-sft
+    }
+  }
   const int wave_n = wave % WN;
   const int wave_m = (wave / WN) % WM;
   const int kgrp = KG == 2 ? grp : 0;  // K-group: which half of the chunk's k16 sub-chunks this wave multiplies
@@ -723,7 +743,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               for (int j = 0; j < 8; ++j) fl[j] *= 2048.0f;
               uint4 oh = pack8<T>(f);
               const uint4 ol = pack8<T>(fl);
-              uint3 q = cvt16_bf6(ol, oh, p.q6_scale);
+              uint3 q = cvt16_bf6(ol, oh, q6_scale);
               if (srcpix[k] < 0) {
                 oh = make_uint4(0, 0, 0, 0);
                 q = make_uint3(0, 0, 0);
@@ -1043,7 +1063,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               // q(Whi).q(lo) + q(Wlo).q(hi) of both taps on the block-scaled bf6 K = 64 MFMA
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
-                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), CVVAE_LO4(r), s2[r], p.q6_eb, acc[r]);
+                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), CVVAE_LO4(r), s2[r], q6_eb, acc[r]);
                 if (!lastq) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbg) + ona);
                 else if (!lastg) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbn));
                 if (r == MREP - 1) {
@@ -1148,7 +1168,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #pragma unroll
             for (int r = 0; r < MREP; ++r) {
               if constexpr (XP == 3)
-                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), q6a[r], q6b[r], p.q6_eb, acc[r]);
+                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), q6a[r], q6b[r], q6_eb, acc[r]);
               else
                 acc[r] = mfma_bf8_k64(wf[0][S + 1], wf[0][S + 2], qa[r], hasb ? qb[r] : qa[r], acc[r]);
               if (!lastq) fa[r] = *reinterpret_cast<const v8*>(&smem[lbg + aoff[r] + ona]);

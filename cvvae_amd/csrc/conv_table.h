@@ -202,7 +202,11 @@
   X(3,3,3, 1,1,1, 2,4,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 2,4,32, 8,1,1, 1, 1,0) \
   X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
-  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0)
+  X(1,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0) \
+  X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2) \
+  X(3,2,2, 1,1,1, 1,4,32, 1,8,1, 1, 0,2)
+// (the last two, round 6: the folded upsample convs -- no GroupNorm in front, the bound comes from a device-side max-abs reduction,
+//  cvvae_conv_desc.act_bound_dev)
 #define CVVAE_CONV_XQ6_B(X) \
   X(3,3,3, 1,1,1, 2,8,32, 2,4,1, 1, 1,0) \
   X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,0) \

@@ -253,7 +253,11 @@ static int check_desc(const cvvae_conv_desc* d) {
   const bool fastq = d->dtype == CVVAE_F32Q || d->dtype == CVVAE_F32Q6;
   if (fastq && (d->kH * d->kW == 1 || d->sc_Cin || d->w_batch_stride)) return CVVAE_EUNSUPPORTED;
   // fp6 corrections: the activations' scale comes from the caller's bound (finite, > 0)
-  if (d->dtype == CVVAE_F32Q6 ? !(d->act_bound > 0.0f && d->act_bound < 3.0e38f) : d->act_bound != 0.0f) return CVVAE_EINVAL;
+  // ... or points at one on the device (act_bound_dev), never both
+  if (d->dtype == CVVAE_F32Q6) {
+    const bool host_bound = d->act_bound > 0.0f && d->act_bound < 3.0e38f;
+    if (d->act_bound_dev ? d->act_bound != 0.0f : !host_bound) return CVVAE_EINVAL;
+  } else if (d->act_bound != 0.0f || d->act_bound_dev) return CVVAE_EINVAL;
   if (d->B <= 0 || d->Ti <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->To <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0)
     return CVVAE_EINVAL;
   const int ck = cvvae_conv_kchunk(d->kT, d->kH, d->kW);
@@ -439,7 +443,8 @@ static int conv_impl(const cvvae_conv_desc* d, const void* in, const void* w_pac
   a.w_taps = (d->upsample2x == 2 ? d->kT * 4 : d->kT * d->kH * d->kW) * (d->w_time_folds ? 2 : 1) * xpm;
   a.q6_scale = 1.0f;
   a.q6_eb = 127;
-  if (d->dtype == CVVAE_F32Q6) {  // activations: codes = value * 2^s with 2^s * act_bound <= 28 (e3m2's largest value)
+  a.q6_bound = d->dtype == CVVAE_F32Q6 ? d->act_bound_dev : nullptr;  // (a device-side bound: the kernel derives scale and byte)
+  if (d->dtype == CVVAE_F32Q6 && !d->act_bound_dev) {  // activations: codes = value * 2^s with 2^s * act_bound <= 28 (e3m2's largest value)
     int ex = 0;
     const float fr = frexpf(28.0f / d->act_bound, &ex);  // 28 / bound = fr * 2^ex, fr in [0.5, 1)  ->  floor(log2) = ex - 1
     (void)fr;

@@ -270,7 +270,7 @@ __global__ void pack_upfold_kernel(const T* __restrict__ src, int Cout, int Cin,
 
 __global__ void pack_upfold_xp_kernel(const float* __restrict__ src, int Cout, int Cin, int nchunks, _Float16* __restrict__ dst,
                                       long long per_phase_lanes, long long phase_stride_elems, int tfold, int dst_taps,
-                                      int dst_tap0, int qrun) {
+                                      int dst_tap0, int qrun, int q6) {
   const long long gid0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid0 >= 4 * per_phase_lanes) return;
   const int phase = (int)(gid0 / per_phase_lanes);
@@ -313,7 +313,7 @@ __global__ void pack_upfold_xp_kernel(const float* __restrict__ src, int Cout, i
 #pragma unroll
       for (int j = 0; j < 16; ++j) wb[j] = 0.f;
     }
-    xq_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16, wb, start, start, false);
+    xq_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16, wb, start, start, q6 != 0);
   } else {
     xp_store(dst + (long long)phase * phase_stride_elems, rec * 3, lane, w16);
   }
@@ -1410,7 +1410,7 @@ static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t C
                          int32_t dst_taps, int32_t dst_tap0, void* stream) {
   const int nb = (Cout + 31) / 32, nchunks = Cin_pad / 16, ntap = tfold ? 4 : 12;
   const long long per_phase = (long long)nb * nchunks * ntap * 64;
-  const bool f32 = dtype == CVVAE_F32 || dtype == CVVAE_F32Q;
+  const bool f32 = dtype == CVVAE_F32 || dtype == CVVAE_F32Q || dtype == CVVAE_F32Q6;
   const long long stride = (long long)(cvvae_packed_weight_bytes(Cout, Cin_pad, dst_taps * (f32 ? 3 : 1)) / 2);
   const int grid = (int)((4 * per_phase + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
@@ -1422,7 +1422,8 @@ static int upfold_launch(int32_t dtype, const void* src, int32_t Cout, int32_t C
                        (_Float16*)dst, per_phase, stride, tfold, dst_taps, dst_tap0);
   else if (f32)
     hipLaunchKernelGGL(pack_upfold_xp_kernel, dim3(grid), dim3(256), 0, s, (const float*)src, Cout, Cin, nchunks, (_Float16*)dst,
-                       per_phase, stride, tfold, dst_taps, dst_tap0, dtype == CVVAE_F32Q ? 4 : 0);
+                       per_phase, stride, tfold, dst_taps, dst_tap0, (dtype == CVVAE_F32Q || dtype == CVVAE_F32Q6) ? 4 : 0,
+                       dtype == CVVAE_F32Q6 ? 1 : 0);
   else
     return CVVAE_EINVAL;
   CHECK_LAUNCH();

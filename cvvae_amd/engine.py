@@ -215,16 +215,19 @@ class WeightCache:
         self._c[tag] = (key, pw, (pre + ".weight",))
         return pw
 
-    def conv_upfold(self, pre: str, tfold: int = 0, time_folds: bool = False) -> ops.PackedConv:
-        """Upsample3D conv weights folded into the four 3x2x2 (tfold: 1x2x2) phase kernels (ops.pack_weight_upfold)."""
+    def conv_upfold(self, pre: str, tfold: int = 0, time_folds: bool = False, fp6: bool = False) -> ops.PackedConv:
+        """Upsample3D conv weights folded into the four 3x2x2 (tfold: 1x2x2) phase kernels (ops.pack_weight_upfold).
+        fp6 (fast fp32 models, 3x2x2 phases): the fp6-correction form -- the launch then needs a device-side bound of its operand
+        (upsample_conv: the residual stream has no GroupNorm in front)"""
         w = self.p(pre + ".weight")
         b = self.p(pre + ".bias")
         key = self._key(w, b)
-        tag = f"{pre}#upfold{tfold}{'tf' if time_folds else ''}" + self._q()
+        fp6 = bool(fp6 and self.fast and self.fast6 and w.dtype == torch.float32 and not tfold)
+        tag = f"{pre}#upfold{tfold}{'tf' if time_folds else ''}" + ("#q6" if fp6 else self._q())
         hit = self._c.get(tag)
         if hit is not None and hit[0] == key:
             return hit[1]
-        pw = ops.pack_weight_upfold(w.detach(), b.detach(), tfold, time_folds=time_folds, fast=self.fast)
+        pw = ops.pack_weight_upfold(w.detach(), b.detach(), tfold, time_folds=time_folds, fast="fp6" if fp6 else self.fast)
         self._c[tag] = (key, pw, (pre + ".weight", pre + ".bias"))
         return pw
 
@@ -383,6 +386,7 @@ def switches_key(wc=None) -> tuple:
     so that flipping one in a live process re-captures instead of replaying the other setting's graph"""
     return (fold_upsample(), fold_t1(), fuse_shortcut(), fold_time(), rowpack_conv_in(), tapsn_conv_out(), fused_attention(),
             per_frame_stats_from_records(), os.environ.get("CVVAE_PREPASS", "auto"), os.environ.get("CVVAE_CONV_FORCE", ""),
+            os.environ.get("CVVAE_F32_FP6_UPS", "1"),
             ops.four_wave(), None if wc is None else (wc.fast, wc.fast6, wc.fp6_bound_cap, str(wc.compute_dtype)))
 
 
@@ -512,8 +516,14 @@ def upsample_conv(wc: WeightCache, h: torch.Tensor, pre: str, pad, mode_t, mode_
         return ops.conv(h, wc.conv_upfold(pre, 1 if mode_t == REP else 2), pad=((0, 0), pad[1], pad[2]), pad_mode_hw=mode_hw,
                         upsample2x=2, out_mode=om, gn_out=G32)
     if fold_upsample():
-        return ops.conv(h, wc.conv_upfold(pre, time_folds=mode_t == REP and fold_time()), pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, upsample2x=2, out_mode=om,
-                        gn_out=G32)
+        # fast fp32 models: the fp6-correction form (1.5 instead of 2 MFMA units per tap), with the operand's bound taken on the
+        # device -- one max-abs reduction over the input, the residual stream, which no GroupNorm bounds (CVVAE_F32_FP6_UPS=0: bf8)
+        fp6 = (h.dtype == torch.float32 and wc.fast and wc.fast6 and wc.compute_dtype is None
+               and os.environ.get("CVVAE_F32_FP6_UPS", "1") != "0")
+        pw = wc.conv_upfold(pre, time_folds=mode_t == REP and fold_time(), fp6=fp6)
+        bound = torch.linalg.vector_norm(h.reshape(-1), float("inf")).reshape(1) if pw.dt == L.F32Q6 else None
+        return ops.conv(h, pw, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, upsample2x=2, out_mode=om, gn_out=G32,
+                        act_bound_dev=bound)
     return ops.conv(h, wc.conv(pre, (3, 3, 3), time_folds=mode_t == REP and fold_time()), pad=pad, pad_mode_t=mode_t,
                     pad_mode_hw=mode_hw, upsample2x=True, out_mode=om, gn_out=G32)
 

@@ -312,7 +312,7 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
          gn_per_frame=False, residual: Optional[torch.Tensor] = None, upsample2x=False, out_mode=L.OUT_NDHWC,
          shortcut: Optional[Tuple[torch.Tensor, "PackedConv"]] = None, bias: Optional[torch.Tensor] = None,
          out_f32=False, alpha=1.0, out: Optional[torch.Tensor] = None, cout_pad: Optional[int] = None, gn_out: int = 0,
-         row_packed: bool = False):
+         row_packed: bool = False, act_bound_dev: Optional[torch.Tensor] = None):
     """x: [B,T,H,W,Cs] with Cs >= pw.cin.  pad = ((t_front,t_back),(h_front,h_back),(w_front,w_back)).
     Returns [B,To,Ho,Wo,Cout(_pad)] (NDHWC), [B,2To-1,Ho,Wo,Cout/2] (TIME_SHUFFLE) or [B,Cout,To,Ho,Wo] (NCDHW).
     gn_out = G > 0: also returns the GNPartials of the stored tensor for a following G-group GroupNorm (gn_finalize).
@@ -332,8 +332,11 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     if dt == L.F32 and pw.dt in (L.F32Q, L.F32Q6):  # the layout the weights were packed in selects the fp32 arithmetic of this launch
         if shortcut is not None:
             raise ValueError("fast-fp32 weights (CVVAE_F32Q) have no fused-shortcut kernel: run the 1x1 shortcut as its own launch")
-        if pw.dt == L.F32Q6 and not (pw.act_bound > 0.0 and prologue == L.PRO_GN_SILU):
-            raise ValueError("fp6-correction weights (CVVAE_F32Q6) go with the GroupNorm + SiLU prologue and a PackedConv.act_bound > 0")
+        if pw.dt == L.F32Q6 and act_bound_dev is None and not (pw.act_bound > 0.0 and prologue == L.PRO_GN_SILU):
+            raise ValueError("fp6-correction weights (CVVAE_F32Q6) go with the GroupNorm + SiLU prologue and a PackedConv.act_bound > 0, "
+                             "or with a device-side bound of the operand (act_bound_dev)")
+        if act_bound_dev is not None:
+            assert pw.dt == L.F32Q6 and act_bound_dev.dtype == torch.float32 and act_bound_dev.numel() == 1 and act_bound_dev.device == x.device
         dt = pw.dt
     B, Ti, Hi, Wi, Cs = x.shape
     assert row_packed or Cs >= pw.cin, f"input has {Cs} channels, packed weights consume {pw.cin}"
@@ -350,7 +353,8 @@ def conv(x: torch.Tensor, pw: PackedConv, *, stride=(1, 1, 1), pad=((0, 0), (0, 
     d.B, d.Ti, d.Hi, d.Wi, d.Cin = B, Ti, Hi, Wi, pw.cin
     d.in_pix_stride = Cs
     d.in_overlap = 1 if row_packed else 0
-    d.act_bound = float(pw.act_bound) if dt == L.F32Q6 else 0.0
+    d.act_bound = float(pw.act_bound) if (dt == L.F32Q6 and act_bound_dev is None) else 0.0
+    d.act_bound_dev = act_bound_dev.data_ptr() if (dt == L.F32Q6 and act_bound_dev is not None) else None
     if pw.folded != (upsample2x == 2):
         raise ValueError("folded upsample weights (pack_weight_upfold) go with upsample2x=2 and only with it")
     d.upsample2x = int(upsample2x)

@@ -121,6 +121,11 @@ typedef struct cvvae_conv_desc {
    * process-wide switch, cvvae_conv_set_four_wave).  cvvae_conv_gn_slabs, cvvae_conv_kernel_name and the launch must see the same
    * value: the instance fixes the layout of the fused GroupNorm records. */
   int32_t four_wave;
+  /* (ABI 13) CVVAE_F32Q6 with an operand that has NO GroupNorm in front (the folded upsample convs of a fast-fp32 model: their input
+   * is the residual stream): device pointer to ONE float, an upper bound (> 0) of |operand| that the producer's stream computes (a
+   * max-abs reduction) -- read by the kernel at launch time, so no host synchronisation is needed; act_bound must then be 0.
+   * Elements beyond the bound saturate in the fp6 CORRECTION terms only (they fall back to the fp16 model's error). */
+  const float* act_bound_dev;
 } cvvae_conv_desc;
 
 /* bytes of the packed weight buffer for (Cout, Cin, taps); includes the read-ahead tail the kernel needs */

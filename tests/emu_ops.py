@@ -189,8 +189,9 @@ def _pad3(f, pad, mode_t, mode_hw):
 
 def conv(x, pw, *, stride=(1, 1, 1), pad=((0, 0), (0, 0), (0, 0)), pad_mode_t=L.PAD_ZERO, pad_mode_hw=L.PAD_ZERO,
          prologue=L.PRO_NONE, gn=None, gn_per_frame=False, residual=None, upsample2x=False, out_mode=L.OUT_NDHWC, shortcut=None,
-         bias=None, out_f32=False, alpha=1.0, out=None, cout_pad=None, gn_out=0, row_packed=False):
+         bias=None, out_f32=False, alpha=1.0, out=None, cout_pad=None, gn_out=0, row_packed=False, act_bound_dev=None):
     assert pw.folded == (upsample2x == 2)
+    assert act_bound_dev is None  # (the fp6 form of a fast-fp32 model: device only)
     B, T, H, W, Cs = x.shape
     if row_packed:  # x already carries the W padding: columns 0 .. W+1 of the stored row are the padded input row
         assert pw.k == (3, 3, 1) and Cs == 4 and pad[2] == (0, 0) and prologue == L.PRO_NONE and residual is None and shortcut is None

@@ -29,10 +29,10 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from cvvae_amd import _lib
-    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, i32 + f32, i32 (+pad) = 168 bytes
-    # (ABI 13: `four_wave` appended; everything before it where it was since ABI 9)
-    assert ctypes.sizeof(_lib.ConvDesc) == 168 and _lib.ConvDesc.w_batch_stride.offset == 128
-    assert _lib.ConvDesc.four_wave.offset == 160
+    # natural alignment of the C struct: 6 x i32, i64, 20 x i32, i64, f32 (+pad), i64, 2 x i32, i64, i32 + f32, i32 (+pad), pointer = 176 bytes
+    # (ABI 13: `four_wave` and `act_bound_dev` appended; everything before it where it was since ABI 9)
+    assert ctypes.sizeof(_lib.ConvDesc) == 176 and _lib.ConvDesc.w_batch_stride.offset == 128
+    assert _lib.ConvDesc.four_wave.offset == 160 and _lib.ConvDesc.act_bound_dev.offset == 168
     assert _lib.ConvDesc.in_overlap.offset == 152 and _lib.ConvDesc.act_bound.offset == 156
     assert _lib.ConvDesc.sc_Cin.offset == 136 and _lib.ConvDesc.sc_in_pix_stride.offset == 144
     assert _lib.ConvDesc.in_pix_stride.offset == 24 and _lib.ConvDesc.out_pix_stride.offset == 112

@@ -95,11 +95,15 @@ def run_conv_case(dtype, Cin, Cout, k, stride, pad, mode_t, mode_hw, shape, prol
         gn = ops.gn_stats(xd, g.to(DEV), bb.to(DEV), 1e-6)
     if ups == 2:
         pw = ops.pack_weight_upfold(w.to(DEV), bias.to(DEV), time_folds=time_folds, fast=fast)
+    abd = None
     if fast == "fp6":
         assert pw.dt == L.F32Q6
-        pw.act_bound = float(8.0 * gamma.abs().max() + beta.abs().max()) if act_bound is None else act_bound
+        if prologue:
+            pw.act_bound = float(8.0 * gamma.abs().max() + beta.abs().max()) if act_bound is None else act_bound
+        else:  # no GroupNorm in front: the bound is a max-abs reduction on the device (act_bound: a factor on it, for the tests)
+            abd = (torch.linalg.vector_norm(xd.reshape(-1), float("inf")) * (1.0 if act_bound is None else act_bound)).reshape(1)
     out = ops.conv(xd, pw, stride=stride, pad=pad, pad_mode_t=mode_t, pad_mode_hw=mode_hw, prologue=prologue, gn=gn,
-                   residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode)
+                   residual=to_ndhwc(res).to(DEV) if residual else None, upsample2x=ups, out_mode=out_mode, act_bound_dev=abd)
     torch.cuda.synchronize()
     got = out.float().cpu()
     if out_mode != L.OUT_NCDHW:

@@ -4,7 +4,9 @@
     BIT on every padding flavour, time fold, tile overhang and epilogue; the GroupNorm records (laid out per tile) must finalize to
     the same tables; and against fp32 F.conv3d (reference ops: models/vae_blocks3d_sd3.py:16-116, 517-569);
   * the four-wave conv instances as a per-launch DESCRIPTOR field (ABI 13: the library keeps no state), and the bit-for-bit
-    repetition check of their fused GroupNorm records under co-residency that used to run at model load."""
+    repetition check of their fused GroupNorm records under co-residency that used to run at model load;
+  * the fp6-correction form of the folded upsample convs of a fast-fp32 model, with the operand's bound read from the device
+    (cvvae_conv_desc.act_bound_dev; reference op: Upsample3D, models/vae_blocks3d_sd3.py:314-364)."""
 import os
 
 import pytest
@@ -174,3 +176,40 @@ def test_four_wave_records_are_reproducible_under_co_residency(dtype):
             os.environ.pop("CVVAE_FOUR_WAVE", None)
         else:
             os.environ["CVVAE_FOUR_WAVE"] = old
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+@pytest.mark.parametrize("time_folds", [False, True])
+def test_fp6_upsample_folded_with_a_device_side_bound(shuffle, time_folds):
+    """the folded upsample conv in the fp6 form: no GroupNorm bounds its operand (the residual stream), so the kernel reads the bound
+    from the device (one float, a max-abs reduction on the producer's stream) -- same tolerance as the bf8 form; a bound 4x too
+    loose or 100x too tight degrades gracefully (saturation hits the CORRECTION terms only)"""
+    from tests.test_gpu_ops import FAST_ULP, REP, _ops, run_conv_case
+    L = _ops()[1]
+    args = (torch.float32, 256, 512 if shuffle else 256, (3, 3, 3), (1, 1, 1), ((1, 1), (1, 1), (1, 1)), REP, REP, (1, 3, 12, 20))
+    kw = dict(ups=2, out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC, time_folds=time_folds)
+    e6 = run_conv_case(*args, tol=2 * FAST_ULP, fast="fp6", **kw)
+    e8 = run_conv_case(*args, tol=2 * FAST_ULP, fast=True, **kw)
+    loose = run_conv_case(*args, tol=1.0, fast="fp6", act_bound=4.0, **kw)
+    tight = run_conv_case(*args, tol=1.0, fast="fp6", act_bound=0.01, **kw)
+    f16 = run_conv_case(torch.float16, *args[1:], tol=1.0, **kw)
+    print(f"\nfolded upsample shuffle={shuffle} tfolds={time_folds}: fp6 {e6:.2e} bf8 {e8:.2e} fp6 loose {loose:.2e} tight {tight:.2e} fp16 model {f16:.2e}")
+    assert e6 <= 1.5 * e8 + 1e-7 and loose <= 2.5 * e8 + 1e-7 and tight <= 1.5 * f16
+
+
+def test_fp6_upsample_needs_exactly_one_bound():
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+    lib = L.load()
+    w = torch.randn(128, 128, 3, 3, 3).cuda() / 60
+    pw = ops.pack_weight_upfold(w, None, fast="fp6")
+    assert pw.dt == L.F32Q6
+    x = torch.randn(1, 2, 8, 32, 128).cuda()
+    with pytest.raises(ValueError):
+        ops.conv(x, pw, pad=P1, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=2)
+    bound = torch.linalg.vector_norm(x.reshape(-1), float("inf")).reshape(1)
+    y = ops.conv(x, pw, pad=P1, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=2, act_bound_dev=bound)
+    assert tuple(y.shape) == (1, 2, 16, 64, 128) and bool(torch.isfinite(y).all())
+    d = _c2d128_desc(0, torch.float32)
+    d.dtype, d.act_bound, d.act_bound_dev = L.F32Q6, 8.0, bound.data_ptr()
+    assert lib.cvvae_conv_gn_slabs(d, 32) < 0  # both bounds: an argument error
