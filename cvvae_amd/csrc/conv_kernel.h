@@ -237,7 +237,11 @@ struct Geo {
   // pixels, so every operand read (ds_read_b128 / ds_read_b64) covers contiguous LDS: conflict-free without padding, tap offsets stay
   // immediates.  The two-frame 512-pixel tile of the 128-channel 3x3x3 layers (2 x 76 KB) and the all-waves-in-N 256-pixel tile of the
   // 256- / 512-channel ones (2 x 57 KB) then exist for the fp6 form, with MREP = 8: every weight record feeds 8 MFMAs instead of 4.
-  static constexpr bool PL = (XP == 3 && MREP >= 8 && SW == 1 && TW >= 32);
+  // ... or as a 2 x 4 REGISTER BLOCK (NB = 2: two 32-channel blocks x four fragments per wave -- every operand read from LDS feeds TWO
+  // MFMAs with two weight records): half the LDS operand bytes per MFMA.  The fp6 K loop reads 3.5 KiB per fragment and pair of
+  // taps for 96 MFMA cycles: 149 B/clk per CU at the full matrix rate against the LDS pipe's 128 -- the 16-bit kernels' 128 B/clk
+  // sit exactly ON that limit, which is why the same register block bought them nothing in round 3 (section 3.1)
+  static constexpr bool PL = (XP == 3 && (MREP * NB >= 8 || NB == 2) && SW == 1 && TW >= 32);  // (NB = 2 with fewer fragments: the odd-frame sibling)
   // bytes per plane.  PL: + 256 / (2 KSUB) so that the 16 lanes of a staging write (8 or 4 consecutive pixels x the chunk's 2 or 4 hi
   // planes) spread over all 64 banks
   static constexpr int PLB = PL ? (NPIX * 16 + 255) / 256 * 256 + 256 / (2 * KSUB) : NGRP * 64 * 16;
@@ -284,7 +288,7 @@ struct Geo {
   static_assert(LD == 0 || (XP == 0 && NB == 1 && KG == 1 && NWV == 8 && TW >= 16), "DMA-staged instances: 16-bit, 8 waves, no K-group split, "
                 "fragment rows of >= 16 consecutive pixels");
   static_assert(XP == 0 || KG == 1, "split-precision instances: no K-group split");
-  static_assert(NB == 1 || (NB == 2 && KG == 1 && XP == 0), "two N-blocks per wave: 16-bit instances without K-group split");
+  static_assert(NB == 1 || (NB == 2 && KG == 1 && (XP == 0 || PL)), "two N-blocks per wave: 16-bit or planar fast-fp32 instances without K-group split");
   static_assert(NWV == 8 || (NWV == 4 && KG == 1), "8 waves per workgroup, or 4 (two workgroups per CU; no K-group split)");
   static_assert(NWV == 8 || LDSB <= 80 * 1024, "two resident workgroups share the CU's 160 KiB of LDS");
   static_assert(KG == 1 || (KG == 2 && KSUB % 2 == 0 && MREP % 2 == 0 && WM * WN == 4), "K-group split");
@@ -848,7 +852,7 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
 #define CVVAE_XQ_DEPTH8 1
 #endif
   // (eight fragments per wave: a pair of taps lasts 768 cycles -- one pair in flight covers an L2 round trip)
-  constexpr int XQD = MREP >= 8 ? CVVAE_XQ_DEPTH8 : CVVAE_XQ_DEPTH;
+  constexpr int XQD = G::PL ? CVVAE_XQ_DEPTH8 : CVVAE_XQ_DEPTH;
   static_assert(XQD == 1 || XQD == 2, "fast-fp32 weight ring: one or two pairs of taps in flight");
   constexpr int NWF = XP >= 2 ? 4 * XQD : PF;
   static_assert(XP < 2 || TFOLD || KT == 1, "fast-fp32 instances: 3-tap time kernels walk time groups, the others have KT = 1");
@@ -875,7 +879,17 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
   auto wwait = [&](v8& rec) __attribute__((always_inline)) {
     if constexpr (LD) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(rec) : "n"(PF - 1));
   };
+  const long long wqx_nbs = (long long)p.nchunks * wq_cs;  // (fast fp32: elements between a wave's two 32-channel blocks, NB = 2)
   if constexpr (XP >= 2) {
+#pragma unroll
+    for (int n = 1; n < NB; ++n) {  // (NB = 2, planar instances: one pair of taps in flight -- XQD = 1)
+      static_assert(NB == 1 || XQD == 1, "two N-blocks per wave: one pair of taps in flight");
+      const T* e2 = wqx + (TFOLD ? tf_w0 : 0) + n * wqx_nbs;
+      wf[n][0] = *reinterpret_cast<const v8*>(e2);
+      wf[n][1] = *reinterpret_cast<const v8*>(e2 + 512);
+      wf[n][2] = *reinterpret_cast<const v8*>(e2 + 1024);
+      wf[n][3] = *reinterpret_cast<const v8*>(e2 + (KH * KW > 1 ? 3 * 512 : 0));
+    }
     const T* e = wqx + (TFOLD ? tf_w0 : 0);  // chunk 0, time group 0, pair 0 (taps 0 and 1 of k16 sub-chunk 0)
     wf[0][0] = *reinterpret_cast<const v8*>(e);
     wf[0][1] = *reinterpret_cast<const v8*>(e + 512);
@@ -1043,32 +1057,46 @@ __global__ __launch_bounds__(WM * WN * KG * 64, (WM * WN * KG == 4 ? 2 : 1)) voi
               // Whi.hi of tap a
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
-                acc[r] = Tr<T>::mfma(wf[0][S + 0], __builtin_bit_cast(v8, CVVAE_LO4(r)), acc[r]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n) acc[n * MREP + r] = Tr<T>::mfma(wf[n][S + 0], __builtin_bit_cast(v8, CVVAE_LO4(r)), acc[n * MREP + r]);
                 if (hasb) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbg) + ob);
                 else CVVAE_CODES(r);
-                if (r == MREP - 1) wf[0][S + 0] = CVVAE_LDW(ne);
+                if (r == MREP - 1) {
+#pragma unroll
+                  for (int n = 0; n < NB; ++n) wf[n][S + 0] = CVVAE_LDW(ne + n * wqx_nbs);
+                }
                 __builtin_amdgcn_sched_barrier(0);
               }
               if (hasb) {  // Whi.hi of tap b
 #pragma unroll
                 for (int r = 0; r < MREP; ++r) {
-                  acc[r] = Tr<T>::mfma(wf[0][S + 3], __builtin_bit_cast(v8, CVVAE_LO4(r)), acc[r]);
+#pragma unroll
+                  for (int n = 0; n < NB; ++n) acc[n * MREP + r] = Tr<T>::mfma(wf[n][S + 3], __builtin_bit_cast(v8, CVVAE_LO4(r)), acc[n * MREP + r]);
                   CVVAE_CODES(r);
-                  if (r == MREP - 1) wf[0][S + 3] = CVVAE_LDW(ne + (nhasb ? 3 * 512 : 0));
+                  if (r == MREP - 1) {
+#pragma unroll
+                    for (int n = 0; n < NB; ++n) wf[n][S + 3] = CVVAE_LDW(ne + (nhasb ? 3 * 512 : 0) + n * wqx_nbs);
+                  }
                   __builtin_amdgcn_sched_barrier(0);
                 }
               } else {
-                wf[0][S + 3] = CVVAE_LDW(ne + (nhasb ? 3 * 512 : 0));
+#pragma unroll
+                for (int n = 0; n < NB; ++n) wf[n][S + 3] = CVVAE_LDW(ne + (nhasb ? 3 * 512 : 0) + n * wqx_nbs);
               }
               // q(Whi).q(lo) + q(Wlo).q(hi) of both taps on the block-scaled bf6 K = 64 MFMA
 #pragma unroll
               for (int r = 0; r < MREP; ++r) {
-                acc[r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[0][S + 1]), __builtin_bit_cast(i32x4_t, wf[0][S + 2]), CVVAE_LO4(r), s2[r], q6_eb, acc[r]);
+#pragma unroll
+                for (int n = 0; n < NB; ++n)
+                  acc[n * MREP + r] = mfma_bf6_k64(__builtin_bit_cast(i32x4_t, wf[n][S + 1]), __builtin_bit_cast(i32x4_t, wf[n][S + 2]), CVVAE_LO4(r), s2[r], q6_eb, acc[n * MREP + r]);
                 if (!lastq) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbg) + ona);
                 else if (!lastg) CVVAE_PUT4(r, pl_add2x(aoff8[r], lbn));
                 if (r == MREP - 1) {
-                  wf[0][S + 1] = CVVAE_LDW(ne + 512);
-                  wf[0][S + 2] = CVVAE_LDW(ne + 1024);
+#pragma unroll
+                  for (int n = 0; n < NB; ++n) {
+                    wf[n][S + 1] = CVVAE_LDW(ne + 512 + n * wqx_nbs);
+                    wf[n][S + 2] = CVVAE_LDW(ne + 1024 + n * wqx_nbs);
+                  }
                 }
                 __builtin_amdgcn_sched_barrier(0);
               }

@@ -217,6 +217,18 @@
 //  X(1,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0), compiles with an accumulator spilled inside its K loop.  Neither is in the list;
 //  profiles/r6_ab_planar_fast_fp32_v2.log)
 #define CVVAE_CONV_XQ6(X) CVVAE_CONV_XQ6_A(X) CVVAE_CONV_XQ6_B(X)
+// ... and as a 2 x 4 register block (NB = 2: every LDS operand read feeds two MFMAs; conv_kernel.h Geo::PL): the 512-pixel two-frame
+// tile as 4 pixel slabs x 2 waves x 2 blocks (+ its one-frame sibling), the 256-pixel tile as 2 slabs x 4 waves x 2 blocks, the 16-row
+// per-frame tile of the 128-channel conv2 layers, the folded upsample phases
+#define CVVAE_CONV_XQ6_NB2(X) \
+  X(3,3,3, 1,1,1, 2,8,32, 4,2,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 4,2,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 2,4,1, 1, 1,0) \
+  X(1,3,3, 1,1,1, 1,16,32, 4,2,1, 2, 1,0) \
+  X(3,2,2, 1,1,1, 1,8,32, 2,4,1, 1, 0,2)
+// (measured against the tiles of rounds 3-5, profiles/r6_ab_planar_nb2{,_more}.log: 128-channel 3x3x3 +4 %, 256 / 512-channel 3x3x3
+//  +1.5 %, the 128-channel per-frame conv on the 16-row tile +5.7 %, the folded upsample convs +5 %; the 256-pixel per-frame tile,
+//  X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0), +2.6 % at 256 channels and -2 % at 512: not in the list)
 
 // DMA-staged instances (LD = 1, conv_kernel.h): 16-bit models, PRO = 0 -- the folded upsample convs, the strided downsamplers, the
 // 1x1 layers and the decoder's conv_in as they are, and every other conv when its GroupNorm + SiLU is applied by the pass

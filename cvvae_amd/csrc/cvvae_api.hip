@@ -25,6 +25,9 @@ CVVAE_CONV_XQ(CVVAE_EXTERN_XQ)
 #define CVVAE_EXTERN_XQ6(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3>(const ConvArgs&, int, hipStream_t);
 CVVAE_CONV_XQ6(CVVAE_EXTERN_XQ6)
+#define CVVAE_EXTERN_XQ6_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3,2>(const ConvArgs&, int, hipStream_t);
+CVVAE_CONV_XQ6_NB2(CVVAE_EXTERN_XQ6_NB2)
 #define CVVAE_EXTERN_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   extern template int launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t); \
   extern template int launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,2>(const ConvArgs&, int, hipStream_t);
@@ -45,6 +48,7 @@ CVVAE_CONV_LD(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_XP(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_XQ(CVVAE_CHECK_FRAME_TILES)
 CVVAE_CONV_XQ6(CVVAE_CHECK_FRAME_TILES)
+CVVAE_CONV_XQ6_NB2(CVVAE_CHECK_FRAME_TILES)
 
 typedef int (*launch_fn)(const ConvArgs&, int, hipStream_t);
 
@@ -74,12 +78,16 @@ struct Instance {
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 0, \
    {nullptr, nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3>}, ""},
 
+#define CVVAE_ROW_XQ6_NB2(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
+  {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 2, 0, \
+   {nullptr, nullptr, nullptr, nullptr, &launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,3,2>}, ""},
+
 #define CVVAE_ROW_LD(KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS) \
   {KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS, 1, 1, \
    {&launch_conv<_Float16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,1,1>, \
     &launch_conv<__bf16,KT,KH,KW,ST,SH,SW,TT,TH,TW,WM,WN,KG,KSUB,PRO,UPS,0,1,1>, nullptr, nullptr, nullptr}, ""},
 
-static Instance g_table[] = {CVVAE_CONV_LD(CVVAE_ROW_LD) CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ) CVVAE_CONV_XQ6(CVVAE_ROW_XQ6)};
+static Instance g_table[] = {CVVAE_CONV_LD(CVVAE_ROW_LD) CVVAE_CONV_ALL(CVVAE_ROW) CVVAE_CONV_NB2(CVVAE_ROW_NB2) CVVAE_CONV_XP(CVVAE_ROW_XP) CVVAE_CONV_XQ(CVVAE_ROW_XQ) CVVAE_CONV_XQ6(CVVAE_ROW_XQ6) CVVAE_CONV_XQ6_NB2(CVVAE_ROW_XQ6_NB2)};
 static const int g_ntable = (int)(sizeof(g_table) / sizeof(g_table[0]));
 
 static inline long long cdiv(long long a, long long b) { return (a + b - 1) / b; }
@@ -129,6 +137,11 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
   if (e.nbw == 2) {
     static const double nb2 = getenv("CVVAE_CONV_NB2") ? atof(getenv("CVVAE_CONV_NB2")) : 1.0;
     cost *= nb2;
+    // fast-fp32 (fp6) instances: the 2 x 4 register block is the better form of the same tile -- half the LDS operand bytes per MFMA,
+    // where the fp6 K loop reads 3.5 KiB per fragment and pair of taps: measured +4 % on the 128-channel 3x3x3 layers, +1.5 % on the
+    // 256 / 512-channel ones against the eight-fragment planar tiles (profiles/r6_ab_planar_nb2.log); the weight-traffic term above
+    // would otherwise rank it behind them
+    if (e.fn[CVVAE_F32Q6]) cost *= 0.93;
   }
   // four-wave instances (two workgroups per CU): candidates only when the DESCRIPTOR says so (cvvae_conv_desc.four_wave, ABI 13: a
   // per-launch field, no library state) -- +6 % on the per-frame 128-channel conv with residual + statistics, 1.71 -> 1.62 ms at
@@ -241,7 +254,7 @@ static const char* instance_name(Instance* e, int dtype) {
   if (!e->name[0])
     snprintf(e->name, sizeof(e->name), "conv_k%d%d%d_s%d%d%d_t%dx%dx%d_w%dx%dx%d_c%d_pro%d_ups%d%s", e->kt, e->kh, e->kw, e->st,
              e->sh, e->sw, e->tt, e->th, e->tw, e->wm, e->wn, e->kg, 16 * e->ksub, e->pro, e->ups,
-             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->fn[4] ? "_xq6" : (e->nbw == 2 ? "_nb2" : (e->ld ? "_dma" : "")))));
+             e->fn[2] ? "_xp" : (e->fn[3] ? "_xq" : (e->fn[4] ? (e->nbw == 2 ? "_xq6nb2" : "_xq6") : (e->nbw == 2 ? "_nb2" : (e->ld ? "_dma" : "")))));
   (void)dtype;
   return e->name;
 }

@@ -27,6 +27,14 @@ PL_CASES = [
     ("vae3d_zero_time_pad", 128, 128, (3, 3, 3), P1, ZERO, ZERO, (2, 4, 16, 32), "2x8x32:2x4x1:1", "2x4x32:2x4x1:1", dict()),
     ("enc256_causal", 256, 256, (3, 3, 3), PC, REP, REP, (1, 3, 16, 64), "1x8x32:1x8x1:1", "1x4x32:1x8x1:1", dict(tfolds=True, stats=True)),
     ("mid512_overhang", 512, 512, (3, 3, 3), P1, REP, REP, (1, 2, 12, 40), "1x8x32:1x8x1:1", "1x4x32:1x8x1:1", dict()),
+    # the 2 x 4 register-block instances (two 32-channel blocks x four fragments per wave: "...:2" = N-blocks per wave)
+    ("nb2_enc128_causal_tfolds", 128, 128, (3, 3, 3), PC, REP, REP, (1, 6, 32, 64), "2x8x32:4x2x1:1:2", "2x4x32:2x4x1:1", dict(tfolds=True, stats=True)),
+    ("nb2_enc128_odd_frames", 128, 128, (3, 3, 3), PC, REP, REP, (1, 5, 16, 64), "2x8x32:4x2x1:1:2", "2x4x32:2x4x1:1", dict(tfolds=True, stats=True)),
+    ("nb2_dec256to128_sym", 256, 128, (3, 3, 3), P1, REP, REP, (1, 4, 24, 40), "2x8x32:4x2x1:1:2", "2x4x32:2x4x1:1", dict(tfolds=True)),
+    ("nb2_enc256_causal", 256, 256, (3, 3, 3), PC, REP, REP, (1, 3, 16, 64), "1x8x32:2x4x1:1:2", "1x4x32:1x8x1:1", dict(tfolds=True, stats=True)),
+    ("nb2_mid512_overhang", 512, 512, (3, 3, 3), P1, ZERO, ZERO, (2, 2, 12, 40), "1x8x32:2x4x1:1:2", "1x4x32:1x8x1:1", dict()),
+    ("nb2_c2d128_res_stats", 128, 128, (1, 3, 3), P2D, ZERO, ZERO, (1, 3, 32, 64), "1x16x32:4x2x1:2:2", "1x8x32:2x4x1:2", dict(res=True, stats=True)),
+    ("nb2_c2d128_overhang", 128, 128, (1, 3, 3), P2D, ZERO, ZERO, (2, 2, 24, 40), "1x16x32:4x2x1:2:2", "1x8x32:2x4x1:2", dict(res=True)),
 ]
 
 
@@ -70,8 +78,9 @@ def test_planar_fast_fp32_instances_reproduce_the_four_fragment_tiles(case, monk
         else:
             res[label] = (out, None)
     monkeypatch.delenv("CVVAE_CONV_FORCE")
-    tag = "_t" + tile_pl.split(":")[0] + "_"
-    assert names["planar"] and tag in names["planar"][0] and names["planar"][0].endswith("_xq6"), names
+    tag = "_t" + tile_pl.split(":")[0] + "_w" + tile_pl.split(":")[1] + "_"
+    suffix = "_xq6nb2" if tile_pl.count(":") == 3 else "_xq6"
+    assert names["planar"] and tag in names["planar"][0] and names["planar"][0].endswith(suffix), names
     assert names["four"] and tag not in names["four"][0] and names["four"][0].endswith("_xq6"), names
     ya, yb = res["planar"][0], res["four"][0]
     assert torch.equal(ya, yb), (name, names, float((ya - yb).abs().max()))
@@ -213,3 +222,31 @@ def test_fp6_upsample_needs_exactly_one_bound():
     d = _c2d128_desc(0, torch.float32)
     d.dtype, d.act_bound, d.act_bound_dev = L.F32Q6, 8.0, bound.data_ptr()
     assert lib.cvvae_conv_gn_slabs(d, 32) < 0  # both bounds: an argument error
+
+
+@pytest.mark.parametrize("shuffle", [False, True])
+def test_register_block_upsample_instance_reproduces_the_four_fragment_tile(shuffle, monkeypatch):
+    """the folded upsample conv (fp6, device-side bound) on the 2 x 4 register-block planar instance vs the tile of rounds 3-5:
+    same products in the same order -> identical bits"""
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+    torch.manual_seed(3)
+    cout = 512 if shuffle else 256
+    x = torch.randn(1, 3, 24, 40, 256).cuda()
+    pw = ops.pack_weight_upfold((torch.randn(cout, 256, 3, 3, 3) / 83).cuda(), torch.randn(cout).cuda() * 0.1, time_folds=True, fast="fp6")
+    bound = torch.linalg.vector_norm(x.reshape(-1), float("inf")).reshape(1)
+    out, names = {}, {}
+    # (the 16-channel-chunk tile of rounds 3-5: the 32-channel one walks (chunk, time group, k16, tap) in another order -- 3e-6 apart)
+    for label, tile in (("nb2", "1x8x32:2x4x1:1:2"), ("four", "1x4x32:1x8x1:1")):
+        monkeypatch.setenv("CVVAE_CONV_FORCE", tile)
+        seen = []
+        ops.PROFILE = lambda d, pw_, launch: (seen.append(ops.conv_kernel_name(d)), launch())
+        try:
+            y, part = ops.conv(x, pw, pad=P1, pad_mode_t=REP, pad_mode_hw=REP, upsample2x=2,
+                               out_mode=L.OUT_TIME_SHUFFLE if shuffle else L.OUT_NDHWC, gn_out=32, act_bound_dev=bound)
+        finally:
+            ops.PROFILE = None
+        out[label], names[label] = y, seen
+    monkeypatch.delenv("CVVAE_CONV_FORCE")
+    assert names["nb2"][0].endswith("_xq6nb2") and names["four"][0].endswith("_xq6") and "ups2" in names["nb2"][0], names
+    assert torch.equal(out["nb2"], out["four"]), float((out["nb2"] - out["four"]).abs().max())

@@ -85,14 +85,14 @@ def main():
         x = (torch.rand((1, T, H, W, cin), device="cuda") * 2 - 1).to(dt)
         w = (torch.rand((cout, cin) + k, device="cuda") * 2 - 1).to(dt) / (cin * k[0] * k[1] * k[2]) ** 0.5
         def packed(fast, tf=False):
-            fast = True if (fast == "fp6" and not (pro == 1 and not ups and k in ((3, 3, 3), (1, 3, 3)) and not name.startswith("down"))) else fast
+            fast = True if (fast == "fp6" and not ((pro == 1 and not ups and k in ((3, 3, 3), (1, 3, 3)) and not name.startswith("down")) or ups == 2)) else fast
             if ups == 2:
                 q = ops.pack_weight_upfold(w, torch.zeros(cout, device="cuda"), time_folds=tf, fast=fast)
             elif tf:
                 q = ops.pack_weight_tfolds(w, torch.zeros(cout, device="cuda"), fast=fast)
             else:
                 q = ops.pack_weight(w.reshape(cout, cin, -1), torch.zeros(cout, device="cuda"), k, fast=fast)
-            if q.dt == L.F32Q6:
+            if q.dt == L.F32Q6 and pro:
                 q.act_bound = 8.0
             return q
         pw = packed(fasts[0][1])
@@ -105,6 +105,8 @@ def main():
             stride = (1, 1, 1)
         kw = dict(stride=stride, pad=pad, pad_mode_t=L.PAD_REPLICATE, pad_mode_hw=L.PAD_REPLICATE if k[0] == 3 else L.PAD_ZERO, prologue=pro,
                   gn=gn, upsample2x=ups, out_mode=L.OUT_NCDHW if cout <= 32 else L.OUT_NDHWC)
+        if pw.dt == L.F32Q6 and not pro:  # fp6 without a GroupNorm in front (folded upsample): the bound lives on the device
+            kw["act_bound_dev"] = torch.linalg.vector_norm(x.reshape(-1), float("inf")).reshape(1)
         if name.endswith("res"):
             kw["residual"] = (torch.rand((1, T, H, W, cout), device="cuda") * 2 - 1).to(dt)
             kw["gn_out"] = 32
