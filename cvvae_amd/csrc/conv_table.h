@@ -75,6 +75,22 @@
 #define CVVAE_CONV_G7(X) \
   X(1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,16,32, 2,4,1, 2, 1,0)
+// small frames (round 6: image mode at 256^2, the 32x32 / 64x64 levels of a 17x256^2 clip): with 256-pixel tiles a 512-channel
+// per-frame conv at 32x32 is 16 workgroups on 256 CUs and takes the same 61-66 us as the 80-workgroup layer at 5x32x32 -- the time of
+// ONE workgroup's 16 K chunks (profiles/r6_probe_small_layers.log: staging 4.5k + MFMAs 3.2k cycles per chunk and wave).  128- and
+// 64-pixel tiles put the same work on 4x as many CUs.  (The 3x3x3 layers of those levels stream 14 MB of weights per workgroup
+// column and want FEWER, larger tiles: not here.)  64-channel chunks first (a cost tie goes to the first): 8 instead of 16 rounds of
+// load -> GroupNorm + SiLU -> LDS -> barrier, -8 % at 512 channels; 128-channel chunks (74 KB of LDS) another -2 %: not kept
+// (profiles/r6_small_layers_v6.log).
+#define CVVAE_CONV_G14(X) \
+  X(1,3,3, 1,1,1, 1,2,32, 2,4,1, 4, 1,0) \
+  X(1,3,3, 1,1,1, 1,2,32, 1,8,1, 4, 1,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 2,4,1, 2, 1,0) \
+  X(1,3,3, 1,1,1, 1,2,32, 2,4,1, 2, 1,0) \
+  X(1,3,3, 1,1,1, 1,2,32, 1,8,1, 2, 1,0) \
+  X(1,2,2, 1,1,1, 1,4,32, 1,8,1, 2, 0,2) \
+  X(1,1,1, 1,1,1, 1,1,64, 2,4,1, 8, 0,0) \
+  X(1,1,1, 1,1,1, 1,1,64, 2,4,1, 8, 2,0)
 // 1x1x1 (shortcuts, attention projections and the QK^T / PV products), K-chunk 128 channels, 1-D pixel tile
 #define CVVAE_CONV_G8(X) \
   X(1,1,1, 1,1,1, 1,1,256, 1,8,1, 8, 0,0) \
@@ -256,4 +272,5 @@
 
 #define CVVAE_CONV_ALL(X) \
   CVVAE_CONV_G1(X) CVVAE_CONV_G2(X) CVVAE_CONV_G3(X) CVVAE_CONV_G4(X) CVVAE_CONV_G5(X) CVVAE_CONV_G6(X) \
-  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X) CVVAE_CONV_G12(X) CVVAE_CONV_G13(X)
+  CVVAE_CONV_G7(X) CVVAE_CONV_G8(X) CVVAE_CONV_G9(X) CVVAE_CONV_G10(X) CVVAE_CONV_G11(X) CVVAE_CONV_G12(X) CVVAE_CONV_G13(X) \
+  CVVAE_CONV_G14(X)

@@ -174,6 +174,39 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
     //  5x64x64 (160 workgroups of the 256-pixel tile 0.29 ms, 320 of the 128-pixel tile 0.30 ms: +1.3 ms per step).  Not kept;
     //  profiles/r5_ab_four_wave.log, profiles/r5_tune_instances_cfg2.log)
     if (quant && !(e.kt == 1 && e.kh == 1 && e.kw == 1)) cost *= 1.0 + quant_w * (ceil(wgs / cus) / (wgs / cus) - 1.0);
+    // SMALL LAYERS (round 6): where the 256-pixel x 128-channel tiling of the layer is no more than one workgroup per CU, the launch
+    // takes ONE workgroup's time whatever their number (profiles/r6_small_layers.log: a 512-channel per-frame conv takes 61 us at
+    // 1x32x32 = 16 workgroups, 65 us at 1x64x64 = 64, 66 us at 5x32x32 = 80), and that time is far from proportional to the tile's
+    // area (r6_small_layers_v2.log, 512 -> 512 1x3x3 behind GroupNorm + SiLU: 256 x 128 pixels x channels 61-66 us, 128 x 128 44-45,
+    // 64 x 256 40-42, 64 x 128 38-40 -- and 57 us when its 320 workgroups need a second round).  Such layers are ranked by a time
+    // model of their own:
+    //   t(workgroup) = 0.47 + 0.53 x area x shape / (256 x 128)     a K chunk has a latency floor: load -> GroupNorm + SiLU -> LDS ->
+    //                                                               barrier -> MFMAs, ~1.9 us of the 256 x 128 tile's 4.0
+    //   shape = (BN + s x halo) / BN, normalised to the 256 x 128 tile: per chunk a wave pair stages, then multiplies (conv_kernel.h, X / Y
+    //           groups), and the staging of that tile takes 4.4k cycles against 3.2k of MFMAs (r6_probe_small_layers.log) -- a staged
+    //           pixel costs as much as s ~ 130 output channels of MFMAs (~60 without prologue, ~30 as a DMA wave-load)
+    //   rounds  = 0.92 + 0.08 r for r = workgroups / CUs <= 1, else r + 0.3 (ceil(r) - r)
+    // for layers whose weights stay in L2: the 3x3x3 layers at 512 channels stream 14 MB per workgroup column and get SLOWER with
+    // more, smaller tiles (round 5, above).  Per batch item, like every other term.  Measured: cfg 1 (image mode, 256^2) 3.77 ->
+    // 2.9 ms with the small tiles of conv_table.h G14; cfg 3 has no such layer but the 1024-token 1x1 convs.
+    // CVVAE_CONV_SMALL=0 switches the model off (tuning aid, read once).
+    static const bool small_on = !(getenv("CVVAE_CONV_SMALL") && atoi(getenv("CVVAE_CONV_SMALL")) == 0);
+    const double wbytes = (double)d->Cout * (double)d->Cin * (double)(d->kT * d->kH * d->kW) * 2.0;
+    const double opix = fold ? (double)d->To * (d->Ho / 2) * (d->Wo / 2) * 4.0 : (double)d->To * d->Ho * d->Wo;
+    const double wgs_ref = ceil(opix / 256.0) * ceil((double)d->Cout / 128.0);
+    if (small_on && wgs_ref <= cus && !d->w_batch_stride && wbytes <= 8.0e6) {
+      const double sw = e.ld ? 30.0 : (e.pro ? 130.0 : 60.0);
+      const double shape = ((double)bn + sw * halo) / (double)bn * 128.0 / (128.0 + sw * 1.33);
+      const double t_wg = 0.47 + 0.53 * (double)bm * (double)bn * shape / 32768.0;
+      const double r = wgs / cus;
+      const double rounds = r <= 1.0 ? 0.92 + 0.08 * r : r + 0.3 * (ceil(r) - r);
+      double c = t_wg * rounds * (double)d->B;
+      if (e.kg == 2) c *= 1.08;
+      if (e.ld) c *= 0.9;
+      if (e.wm * e.wn * e.kg == 4) c *= 100.0;  // (four-wave instances: measured on full grids only)
+      if (e.st * e.sh * e.sw > 1 && e.ksub == 1) c *= 1.15;
+      return c;
+    }
   }
   return cost;
 }

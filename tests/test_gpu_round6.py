@@ -250,3 +250,105 @@ def test_register_block_upsample_instance_reproduces_the_four_fragment_tile(shuf
     monkeypatch.delenv("CVVAE_CONV_FORCE")
     assert names["nb2"][0].endswith("_xq6nb2") and names["four"][0].endswith("_xq6") and "ups2" in names["nb2"][0], names
     assert torch.equal(out["nb2"], out["four"]), float((out["nb2"] - out["four"]).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# small-frame tiles (conv_table.h G14) and the starved-grid term of the instance cost model
+# ---------------------------------------------------------------------------------------------------------------------------------
+# name, Cin, Cout, k, (B,T,H,W), small tile, the tile of rounds 1-5, extras
+SMALL_CASES = [
+    ("c2d512_32_res_stats_128px", 512, 512, (1, 3, 3), (1, 1, 32, 32), "1x4x32:2x4x1:2", "1x8x32:2x4x1:2", dict(res=True, stats=True)),
+    ("c2d512_32_res_stats_64px", 512, 512, (1, 3, 3), (1, 1, 32, 32), "1x2x32:2x4x1:2", "1x8x32:2x4x1:2", dict(res=True, stats=True)),
+    ("c2d256_overhang_64px_all_n", 256, 256, (1, 3, 3), (2, 2, 20, 40), "1x2x32:1x8x1:2", "1x8x32:1x8x1:2", dict(stats=True)),
+    ("c2d256to512_overhang", 256, 512, (1, 3, 3), (1, 3, 12, 72), "1x2x32:2x4x1:2", "1x8x32:2x4x1:2", dict()),
+    ("c2d512_64ch_chunks", 512, 512, (1, 3, 3), (1, 1, 32, 32), "1x2x32:1x8x1:4", "1x8x32:1x8x1:4", dict(stats=True)),
+    ("c2d128to8_conv_out_like", 128, 8, (1, 3, 3), (1, 1, 32, 32), "1x2x32:2x4x1:2", "1x8x32:2x4x1:2", dict()),
+]
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bfloat16", "float16"])
+@pytest.mark.parametrize("case", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+def test_small_frame_tiles_reproduce_the_256_pixel_tile(case, dtype, monkeypatch):
+    """64- and 128-pixel tiles of the per-frame 3x3 conv (image mode, the 32x32 / 64x64 levels of a short clip): every output is
+    accumulated over the same chunks and taps in the same order as under the 256-pixel tile -> bit-equal outputs (residual pre-accumulated
+    at the same chunk); the GroupNorm records are laid out per tile, their tables agree to fp32 rounding.
+    (reference op: ResnetBlock2D conv2 + residual, lvdm/modules/diffusionmodules/model.py:82-143)"""
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+    name, cin, cout, k, (B, T, H, W), tile_small, tile_old, ex = case
+    torch.manual_seed(len(name))
+    x = (torch.randn(B, T, H, W, cin) * 1.5 + 0.3).to(dtype).cuda()
+    w = (torch.randn(cout, cin, *k) / (cin * 9) ** 0.5).to(dtype)
+    b = torch.randn(cout) * 0.1
+    pw = ops.pack_weight(w.reshape(cout, cin, -1).cuda(), b.cuda(), k)
+    gam, bet = (1.0 + 0.2 * torch.randn(cin)).cuda(), (0.1 * torch.randn(cin)).cuda()
+    gn = ops.gn_stats(x, gam, bet, 1e-6)
+    kw = dict(pad=P2D, pad_mode_t=ZERO, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=gn)
+    if ex.get("res"):
+        kw["residual"] = torch.randn(B, T, H, W, cout).to(dtype).cuda()
+    if ex.get("stats"):
+        kw["gn_out"] = 32
+    one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    res, names = {}, {}
+    for label, tile in (("small", tile_small), ("old", tile_old)):
+        monkeypatch.setenv("CVVAE_CONV_FORCE", tile)
+        seen = []
+        ops.PROFILE = lambda d, pw_, launch: (seen.append(ops.conv_kernel_name(d)), launch())
+        try:
+            out = ops.conv(x, pw, **kw)
+        finally:
+            ops.PROFILE = None
+        names[label] = seen
+        res[label] = (out[0], ops.gn_finalize(out[1], one, zero, 1e-6)) if isinstance(out, tuple) else (out, None)
+    monkeypatch.delenv("CVVAE_CONV_FORCE")
+    tag = "_t" + tile_small.split(":")[0] + "_w" + tile_small.split(":")[1] + "_"
+    assert names["small"] and tag in names["small"][0], names
+    assert names["old"] and "_t1x8x32_" in names["old"][0], names
+    ya, yb = res["small"][0], res["old"][0]
+    if ex.get("res"):
+        # the residual joins a fragment's accumulator at one of the first K chunks -- which one depends on the fragments per wave
+        # (conv_kernel.h res_pre): the same sum in another order, one rounding of the stored type apart at most
+        ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+        d = (ya.float() - yb.float()).abs()
+        assert float((d / yb.float().abs().clamp_min(1.0)).max()) <= 2 * ulp, (name, float(d.max()))
+        assert float((d > 0).float().mean()) < 0.25, float((d > 0).float().mean())
+    else:
+        assert torch.equal(ya, yb), (name, names, float((ya.float() - yb.float()).abs().max()))
+    if ex.get("stats"):
+        for ta, tb in zip(res["small"][1], res["old"][1]):
+            assert torch.allclose(ta, tb, rtol=2e-5, atol=2e-6), (name, float((ta - tb).abs().max()))
+
+
+def test_starved_grids_get_small_tiles_and_full_grids_keep_theirs(monkeypatch):
+    """The instance cost model charges a grid of fewer workgroups than CUs for the CUs it leaves empty (cvvae_api.hip instance_cost):
+    a 512-channel per-frame conv at 1x32x32 runs on 64-pixel tiles, the same layer at 17x512^2's 5x64x64 level and the 128-channel
+    layers at 256^2 keep the tiles of rounds 1-5; the choice is made per batch item (a batch of clips == single-clip calls, bit for
+    bit)."""
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+
+    def picked(cin, cout, shape, **env):
+        for k_, v in env.items():
+            monkeypatch.setenv(k_, v)
+        x = torch.randn(*shape, cin).bfloat16().cuda()
+        pw = ops.pack_weight((torch.randn(cout, cin, 9) / (cin * 9) ** 0.5).bfloat16().cuda(), torch.zeros(cout).cuda(), (1, 3, 3))
+        gn = ops.gn_stats(x, torch.ones(cin).cuda(), torch.zeros(cin).cuda(), 1e-6)
+        seen = []
+        ops.PROFILE = lambda d, pw_, launch: (seen.append(ops.conv_kernel_name(d)), launch())
+        try:
+            y = ops.conv(x, pw, pad=P2D, pad_mode_t=ZERO, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=gn)
+        finally:
+            ops.PROFILE = None
+            for k_ in env:
+                monkeypatch.delenv(k_)
+        assert torch.isfinite(y.float()).all()
+        return seen[0]
+
+    small = picked(512, 512, (1, 1, 32, 32))
+    assert "_t1x2x32_" in small or "_t1x4x32_" in small, small
+    batch = picked(512, 512, (4, 1, 32, 32))              # four clips: 4 x 64 workgroups fill the chip -- the per-item choice stays
+    assert batch == small, (batch, small)
+    big = picked(128, 128, (1, 17, 512, 512))
+    assert "_t1x16x32_" in big or "_t1x8x32_w1x4x1_" in big, big    # (the four-wave tile: ops sets cvvae_conv_desc.four_wave)
+    forced = picked(512, 512, (1, 1, 32, 32), CVVAE_CONV_FORCE="1x8x32:2x4x1:2")
+    assert "_t1x8x32_" in forced, forced

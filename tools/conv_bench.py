@@ -48,6 +48,11 @@ CASES = {
     "c2d128res": (128, 128, (1, 3, 3), 17, 512, 512, P2D, 1, False),
     "c2d256res": (256, 256, (1, 3, 3), 9, 256, 256, P2D, 1, False),
     "c2d512res": (512, 512, (1, 3, 3), 9, 128, 128, P2D, 1, False),
+    # the small-frame 512-channel layers of cfg 1 / cfg 2 (17x256^2 and 1x256^2 clips): few workgroups, 14 MB of weights per layer
+    "mid512_32": (512, 512, (3, 3, 3), 5, 32, 32, P1, 1, False),
+    "c2d512_32res": (512, 512, (1, 3, 3), 5, 32, 32, P2D, 1, False),
+    "c2d512_32T1res": (512, 512, (1, 3, 3), 1, 32, 32, P2D, 1, False),
+    "c2d512_64T1res": (512, 512, (1, 3, 3), 1, 64, 64, P2D, 1, False),
 }
 
 

@@ -70,6 +70,15 @@ static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 0;
 #elif CFG == 9 // c2d128, four-wave instance (two workgroups per CU)
 #define INST 1,3,3, 1,1,1, 1,8,32, 1,4,1, 2, 1,0
 static const int CIN = 128, COUT = 128, TT_ = 17, HH = 512, WW = 512, PT = 0;
+#elif CFG == 18 // the small-frame 512-channel per-frame conv of cfg 1 (1x32x32: 16 workgroups), 2 pixel slabs x 4 N
+#define INST 1,3,3, 1,1,1, 1,8,32, 2,4,1, 2, 1,0
+static const int CIN = 512, COUT = 512, TT_ = 1, HH = 32, WW = 32, PT = 0;
+#elif CFG == 19 // ... K-group instance
+#define INST 1,3,3, 1,1,1, 1,8,32, 1,4,2, 2, 1,0
+static const int CIN = 512, COUT = 512, TT_ = 1, HH = 32, WW = 32, PT = 0;
+#elif CFG == 20 // the small-frame 512-channel 3x3x3 conv of cfg 2 (5x32x32: 80 workgroups of 128 pixels x 256 channels)
+#define INST 3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0
+static const int CIN = 512, COUT = 512, TT_ = 5, HH = 32, WW = 32, PT = 1;
 #elif CFG == 5 // enc256 without prologue (pro0) for comparison
 #define INST 3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0
 static const int CIN = 256, COUT = 256, TT_ = 9, HH = 256, WW = 256, PT = 2;
