@@ -281,7 +281,11 @@ struct Geo {
   // so the ring is as deep as divides the time group (9 / 8 / 6 records: the DMA has that many k16 steps to arrive)
   static constexpr int GSL = (KT == 3 && KG == 1 ? KH * KW : NTAPS) * KSUB;  // steps of a time group (or of the chunk)
   static constexpr int PFL = GSL % 9 == 0 ? 9 : (GSL % 8 == 0 ? 8 : (GSL % 6 == 0 ? 6 : (GSL % 4 == 0 ? 4 : (GSL % 3 == 0 ? 3 : (GSL % 2 == 0 ? 2 : 1)))));
+#ifdef CVVAE_PF_OVERRIDE   // (probe builds only: tools/probes/conv_probe.hip)
+  static constexpr int PF = CVVAE_PF_OVERRIDE;
+#else
   static constexpr int PF = LD ? (CVVAE_LD_PF ? (GSL % CVVAE_LD_PF == 0 ? CVVAE_LD_PF : PFL) : PFL) : XP ? 3 : (KT == 3 && KH * KW == 1) ? KSUB : (STEPS_W % 9 == 0) ? ((MPS >= 8 || KH * KW < 9) ? 3 : 9) : (STEPS_W % 8 == 0 ? (MPS >= 8 ? 4 : 8) : (STEPS_W % 4 == 0 ? 4 : 3));
+#endif
   // K-group reduction through LDS (KG == 2): each wave parks half of its accumulators (MREP/2 fragments x 4 KiB)
   static constexpr int REDB = KG == 2 ? 8 * (MREP / 2) * 4096 : 0;
   static constexpr int SMEMB = cmax(LDSB, REDB);
@@ -295,7 +299,9 @@ struct Geo {
   static_assert(BM % (32 * WM) == 0, "tile rows must split into 32-row MFMA fragments per wave");
   static_assert(STEPS_W % PF == 0, "weight prefetch ring must divide the steps of a chunk");
   static_assert(SMEMB <= 160 * 1024, "LDS budget");
+#ifndef CVVAE_PF_OVERRIDE
   static_assert(PF * 1024 <= WEIGHT_TAIL_BYTES, "weight prefetch ring reads past the packed buffer's tail");
+#endif
   static_assert(NWV == 4 || NPH <= NPIX || NPIX <= PPP, "split");
 };
 

@@ -9,10 +9,16 @@
 #pragma once
 
 // 3x3x3 stride 1, BN = 256 (Cout >= 256): all 8 waves side by side in N; the 128-pixel tile is for small frames, where
-// 256-pixel tiles leave the last round of workgroups mostly empty (e.g. 288 workgroups on 256 CUs)
+// 256-pixel tiles leave the last round of workgroups mostly empty (e.g. 288 workgroups on 256 CUs) -- with 32-channel chunks first
+// (round 6; a cost tie goes to the first: 16 instead of 32 rounds of stage -> barrier -> 108 MFMAs per wave: 512 -> 512 at 5x32x32
+// 0.200 -> 0.163 ms, profiles/r6_probe_weight_ring.log -- where a twice as deep weight ring, the first suspect, made it SLOWER;
+// the 256-pixel tile with 32-channel chunks is 163,200 of the 163,840 bytes of LDS and -0 / -1.2 / -2.0 / -2.7 % at 256 ch 9x256^2 /
+// 512 ch 9x128^2 / 5x64^2 / 9x64^2, profiles/r6_chunk32.log)
 #define CVVAE_CONV_G1(X) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 0,0) \
+  X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 2, 1,0) \
   X(3,3,3, 1,1,1, 1,8,32, 1,8,1, 1, 1,0) \
+  X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 2, 1,0) \
   X(3,3,3, 1,1,1, 1,4,32, 1,8,1, 1, 1,0)
 // 3x3x3 stride 1, BN = 128 (Cout = 128): 4 N-blocks x 2 K-groups over a 32-channel chunk, reduced through LDS
 #define CVVAE_CONV_G2(X) \

@@ -352,3 +352,49 @@ def test_starved_grids_get_small_tiles_and_full_grids_keep_theirs(monkeypatch):
     assert "_t1x16x32_" in big or "_t1x8x32_w1x4x1_" in big, big    # (the four-wave tile: ops sets cvvae_conv_desc.four_wave)
     forced = picked(512, 512, (1, 1, 32, 32), CVVAE_CONV_FORCE="1x8x32:2x4x1:2")
     assert "_t1x8x32_" in forced, forced
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bfloat16", "float16"])
+@pytest.mark.parametrize("tiles", [("1x8x32:1x8x1:2", "1x8x32:1x8x1:1"), ("1x4x32:1x8x1:2", "1x4x32:1x8x1:1")], ids=["256px", "128px"])
+def test_32_channel_chunks_of_the_3x3x3_tiles(tiles, dtype, monkeypatch):
+    """The BN = 256 tiles of the 3x3x3 conv with 32-channel K chunks (conv_table.h G1, round 6): the same products summed chunk by chunk
+    in another order than under 16-channel chunks -- the stored outputs agree to a rounding of the stored type, the fused GroupNorm
+    tables to fp32 rounding, causal time folds and tile overhang included; and against fp32 conv3d over the same 16-bit operands.
+    (reference op: CausalConv3d, models/vae_blocks3d_sd3.py:16-116)"""
+    import torch.nn.functional as F
+
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+    from tests.test_gpu_grad3d import _pad3
+    cin, cout, (B, T, H, W) = 512, 256, (1, 4, 12, 40)
+    torch.manual_seed(11)
+    x = (torch.randn(B, T, H, W, cin) * 1.5 + 0.3).to(dtype).cuda()
+    w = (torch.randn(cout, cin, 3, 3, 3) / (cin * 27) ** 0.5).to(dtype)
+    b = torch.randn(cout) * 0.1
+    pw = ops.pack_weight_tfolds(w.cuda(), b.cuda())
+    gam, bet = (1.0 + 0.2 * torch.randn(cin)).cuda(), (0.1 * torch.randn(cin)).cuda()
+    gn = ops.gn_stats(x, gam, bet, 1e-6)
+    kw = dict(pad=PC, pad_mode_t=REP, pad_mode_hw=REP, prologue=L.PRO_GN_SILU, gn=gn, gn_out=32)
+    one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    res = []
+    for tile in tiles:
+        monkeypatch.setenv("CVVAE_CONV_FORCE", tile)
+        seen = []
+        ops.PROFILE = lambda d, pw_, launch: (seen.append(ops.conv_kernel_name(d)), launch())
+        try:
+            y, part = ops.conv(x, pw, **kw)
+        finally:
+            ops.PROFILE = None
+        assert seen and f"_c{16 * int(tile[-1])}_" in seen[0] and ("_t" + tile.split(":")[0] + "_") in seen[0], seen
+        res.append((y, ops.gn_finalize(part, one, zero, 1e-6)))
+    monkeypatch.delenv("CVVAE_CONV_FORCE")
+    (ya, ta), (yb, tb) = res
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    d = (ya.float() - yb.float()).abs()
+    assert float((d / yb.float().abs().clamp_min(1.0)).max()) <= 2 * ulp, float(d.max())
+    for u, v in zip(ta, tb):
+        assert torch.allclose(u, v, rtol=5e-5, atol=5e-6), float((u - v).abs().max())
+    a = F.silu(x.float() * gn[0].view(B, 1, 1, 1, cin) + gn[1].view(B, 1, 1, 1, cin)).to(dtype).float().cpu()
+    ref = F.conv3d(_pad3(a.permute(0, 4, 1, 2, 3), PC, REP, REP), w.float(), b)
+    got = ya.float().cpu().permute(0, 4, 1, 2, 3)
+    assert float((got - ref).abs().max()) <= 3 * ulp * float(ref.abs().max()), float((got - ref).abs().max())
