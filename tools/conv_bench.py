@@ -53,6 +53,9 @@ CASES = {
     "c2d512_32res": (512, 512, (1, 3, 3), 5, 32, 32, P2D, 1, False),
     "c2d512_32T1res": (512, 512, (1, 3, 3), 1, 32, 32, P2D, 1, False),
     "c2d512_64T1res": (512, 512, (1, 3, 3), 1, 64, 64, P2D, 1, False),
+    "c2d512_64res": (512, 512, (1, 3, 3), 9, 64, 64, P2D, 1, False),    # cfg 2: 288 workgroups of 256 x 256 = 1.125 rounds
+    "c2d256_128res": (256, 256, (1, 3, 3), 9, 128, 128, P2D, 1, False),
+    "mid256_128": (256, 256, (3, 3, 3), 9, 128, 128, P1, 1, False),
 }
 
 
