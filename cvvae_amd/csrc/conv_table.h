@@ -87,10 +87,13 @@
 // 64-pixel tiles put the same work on 4x as many CUs.  (The 3x3x3 layers of those levels stream 14 MB of weights per workgroup
 // column and want FEWER, larger tiles: not here.)  64-channel chunks first (a cost tie goes to the first): 8 instead of 16 rounds of
 // load -> GroupNorm + SiLU -> LDS -> barrier, -8 % at 512 channels; 128-channel chunks (74 KB of LDS) another -2 %: not kept
-// (profiles/r6_small_layers_v6.log).
+// (profiles/r6_small_layers_v6.log).  K-group forms of the 64- and 128-pixel tiles: half the weight stream per wave, which is the floor
+// of a small tile at 512 input channels (-25 %, profiles/r6_small_layers_kg2.log).
 #define CVVAE_CONV_G14(X) \
   X(1,3,3, 1,1,1, 1,2,32, 2,4,1, 4, 1,0) \
   X(1,3,3, 1,1,1, 1,2,32, 1,8,1, 4, 1,0) \
+  X(1,3,3, 1,1,1, 1,2,32, 1,4,2, 4, 1,0) \
+  X(1,3,3, 1,1,1, 1,4,32, 1,4,2, 4, 1,0) \
   X(1,3,3, 1,1,1, 1,4,32, 2,4,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,2,32, 2,4,1, 2, 1,0) \
   X(1,3,3, 1,1,1, 1,2,32, 1,8,1, 2, 1,0) \

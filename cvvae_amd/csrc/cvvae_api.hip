@@ -201,7 +201,16 @@ static double instance_cost(const cvvae_conv_desc* d, const Instance& e) {
       const double r = wgs / cus;
       const double rounds = r <= 1.0 ? 0.92 + 0.08 * r : r + 0.3 * (ceil(r) - r);
       double c = t_wg * rounds * (double)d->B;
-      if (e.kg == 2) c *= 1.08;
+      // K-group split: three barriers and the accumulator exchange through LDS (+8 %) against HALF the weight stream per wave --
+      // which is the floor of a small tile when K is long: 512 -> 512 1x3x3 at 1x32x32 0.035 -> 0.026 ms, at 1x64x64 0.038 -> 0.029
+      // on the 64 x 128 tile, nothing at 256 channels (0.029 vs 0.030) or 128 (profiles/r6_small_layers_kg2.log)
+      if (e.kg == 2) {
+        const double K = (double)d->Cin * (double)(e.kt * e.kh * e.kw);
+        // (measured behind the GroupNorm + SiLU prologue only; the prologue-free lists keep their DMA-staged twins)
+        const double x = !e.pro || K <= 2304.0 ? 0.0 : (K >= 4608.0 ? 1.0 : (K - 2304.0) / 2304.0);
+        static const bool kg_off = getenv("CVVAE_CONV_SMALL_KG") && atoi(getenv("CVVAE_CONV_SMALL_KG")) == 0;  // (A/B aid, read once)
+        c *= kg_off ? 1.08 : 1.08 - 0.30 * x;
+      }
       if (e.ld) c *= 0.9;
       if (e.wm * e.wn * e.kg == 4) c *= 100.0;  // (four-wave instances: measured on full grids only)
       if (e.st * e.sh * e.sw > 1 && e.ksub == 1) c *= 1.15;

@@ -319,6 +319,53 @@ def test_small_frame_tiles_reproduce_the_256_pixel_tile(case, dtype, monkeypatch
             assert torch.allclose(ta, tb, rtol=2e-5, atol=2e-6), (name, float((ta - tb).abs().max()))
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bfloat16", "float16"])
+@pytest.mark.parametrize("tile", ["1x2x32:1x4x2:4", "1x4x32:1x4x2:4"], ids=["64px", "128px"])
+def test_small_frame_k_group_tiles(tile, dtype, monkeypatch):
+    """The K-group forms of the small tiles (two groups of waves take half of every 64-channel chunk each, accumulators exchanged
+    through LDS): another summation order than the all-K tiles -- the stored outputs agree with the 256-pixel tile's to a rounding
+    of the stored type, residual and fused GroupNorm statistics included, and with fp32 conv2d over the same 16-bit operands.
+    (reference op: ResnetBlock2D conv2 + residual, lvdm/modules/diffusionmodules/model.py:82-143)"""
+    import torch.nn.functional as F
+
+    from cvvae_amd import _lib as L
+    from cvvae_amd import ops
+    cin, cout, (B, T, H, W) = 512, 256, (2, 1, 20, 40)
+    torch.manual_seed(23)
+    x = (torch.randn(B, T, H, W, cin) * 1.5 + 0.3).to(dtype).cuda()
+    w = (torch.randn(cout, cin, 1, 3, 3) / (cin * 9) ** 0.5).to(dtype)
+    b = torch.randn(cout) * 0.1
+    pw = ops.pack_weight(w.reshape(cout, cin, -1).cuda(), b.cuda(), (1, 3, 3))
+    gam, bet = (1.0 + 0.2 * torch.randn(cin)).cuda(), (0.1 * torch.randn(cin)).cuda()
+    gn = ops.gn_stats(x, gam, bet, 1e-6)
+    res_in = torch.randn(B, T, H, W, cout).to(dtype).cuda()
+    kw = dict(pad=P2D, pad_mode_t=ZERO, pad_mode_hw=ZERO, prologue=L.PRO_GN_SILU, gn=gn, residual=res_in, gn_out=32)
+    one, zero = torch.ones(cout, device="cuda"), torch.zeros(cout, device="cuda")
+    outs = []
+    for t_ in (tile, "1x8x32:1x8x1:4"):
+        monkeypatch.setenv("CVVAE_CONV_FORCE", t_)
+        seen = []
+        ops.PROFILE = lambda d, pw_, launch: (seen.append(ops.conv_kernel_name(d)), launch())
+        try:
+            y, part = ops.conv(x, pw, **kw)
+        finally:
+            ops.PROFILE = None
+        assert seen and ("_t" + t_.split(":")[0] + "_w" + t_.split(":")[1] + "_") in seen[0], seen
+        outs.append((y, ops.gn_finalize(part, one, zero, 1e-6)))
+    monkeypatch.delenv("CVVAE_CONV_FORCE")
+    (ya, ta), (yb, tb) = outs
+    ulp = 2.0 ** -8 if dtype == torch.bfloat16 else 2.0 ** -11
+    d = (ya.float() - yb.float()).abs()
+    assert float((d / yb.float().abs().clamp_min(1.0)).max()) <= 2 * ulp, float(d.max())
+    for u, v in zip(ta, tb):
+        assert torch.allclose(u, v, rtol=5e-5, atol=5e-6), float((u - v).abs().max())
+    a = F.silu(x.float() * gn[0].view(B, 1, 1, 1, cin) + gn[1].view(B, 1, 1, 1, cin)).to(dtype).float().cpu()
+    ref = F.conv2d(a.reshape(B * T, H, W, cin).permute(0, 3, 1, 2), w.float()[:, :, 0], b, padding=1)
+    ref = ref + res_in.float().cpu().reshape(B * T, H, W, cout).permute(0, 3, 1, 2)
+    got = ya.float().cpu().reshape(B * T, H, W, cout).permute(0, 3, 1, 2)
+    assert float((got - ref).abs().max()) <= 3 * ulp * float(ref.abs().max()), float((got - ref).abs().max())
+
+
 def test_starved_grids_get_small_tiles_and_full_grids_keep_theirs(monkeypatch):
     """The instance cost model charges a grid of fewer workgroups than CUs for the CUs it leaves empty (cvvae_api.hip instance_cost):
     a 512-channel per-frame conv at 1x32x32 runs on 64-pixel tiles, the same layer at 17x512^2's 5x64x64 level and the 128-channel

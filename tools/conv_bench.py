@@ -56,6 +56,8 @@ CASES = {
     "c2d512_64res": (512, 512, (1, 3, 3), 9, 64, 64, P2D, 1, False),    # cfg 2: 288 workgroups of 256 x 256 = 1.125 rounds
     "c2d256_128res": (256, 256, (1, 3, 3), 9, 128, 128, P2D, 1, False),
     "mid256_128": (256, 256, (3, 3, 3), 9, 128, 128, P1, 1, False),
+    "c2d256_128T1res": (256, 256, (1, 3, 3), 1, 128, 128, P2D, 1, False),   # cfg 1 (image mode at 256^2): its three upper levels
+    "c2d128_256T1res": (128, 128, (1, 3, 3), 1, 256, 256, P2D, 1, False),
 }
 
 
